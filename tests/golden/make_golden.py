@@ -1,0 +1,408 @@
+#!/usr/bin/env python
+"""Generate golden fixtures by running the REAL reference (/root/reference, read-only) in the build
+container.  Only the resulting .npz data files are committed and travel to the GPU box; the reference
+sources never do.  Re-run with:   python tests/golden/make_golden.py
+
+Shims (in-process, no file edits): tolerant plt.style.use (env_2d.py:14 asks for the
+removed 'seaborn-paper' style) and torch.Tensor.byte -> bool (masks are built with .byte(),
+plan_layer.py:392-406, point_robot_2d.py:66-68; torch>=2 rejects uint8 masks).
+The reference is fp64-only, so everything here is float64.
+"""
+import os, sys
+sys.dont_write_bytecode = True
+import numpy as np
+import matplotlib
+matplotlib.use('Agg')
+import matplotlib.pyplot as plt
+_use = plt.style.use
+plt.style.use = lambda s: (_use(s) if s in plt.style.available else None)
+import torch
+import warnings
+warnings.filterwarnings('ignore')
+torch.Tensor.byte = lambda self: self.bool()
+torch.set_default_dtype(torch.float64)
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from diff_gpmp2.robot_models import PointRobot2D
+from diff_gpmp2.gpmp2.diff_gpmp2_planner import DiffGPMP2Planner
+from diff_gpmp2.gpmp2.plan_layer import PlanLayer
+from diff_gpmp2.gpmp2.gp import GPFactor, PriorFactor
+from diff_gpmp2.gpmp2.obstacle import ObstacleFactor
+from diff_gpmp2.gpmp2.custom_factors import NonHolonomicFactor
+from diff_gpmp2.utils.sdf_utils import sdf_2d, bilinear_interpolate
+from diff_gpmp2.utils.planner_utils import straight_line_trajb
+from oracle.gpmp2_oracle import circles_sdf, C2_CIRCLES
+
+ENV = {'x_lims': [-5.0, 5.0], 'y_lims': [-5.0, 5.0]}
+
+
+def T(x): return torch.as_tensor(np.asarray(x), dtype=torch.float64)
+def N(x): return x.detach().cpu().numpy().copy()
+
+
+def params_2d(n, reg=0.1, max_iters=10):
+  gp = {'Q_c_inv': torch.eye(2), 'K_s': torch.tensor(0.01), 'K_g': torch.tensor(0.01),
+        'K_v': torch.tensor(0.01), 'v_x': [1.0], 'v_y': [1.0]}
+  obs = {'cost_sigma': torch.tensor(0.01), 'epsilon_dist': torch.tensor(0.4)}
+  pl = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
+  opt = {'method': 'gauss_newton', 'reg': reg, 'plan_time': float('inf'), 'max_iters': max_iters,
+         'tol_err': 1e-3, 'tol_delta': 1e-4}
+  return gp, obs, pl, opt
+
+
+def make_planner(B, n, reg=0.1, max_iters=10):
+  gp, obs, pl, opt = params_2d(n, reg, max_iters)
+  robot = PointRobot2D(torch.tensor(0.4), B, n)
+  return DiffGPMP2Planner(gp, obs, pl, opt, ENV, robot, batch_size=B)
+
+
+def rand_start_goal(B, seed=0):
+  g = torch.Generator().manual_seed(seed)
+  s = torch.cat([torch.rand(B, 1, 2, generator=g) * 8 - 4, torch.zeros(B, 1, 2)], -1)
+  e = torch.cat([torch.rand(B, 1, 2, generator=g) * 8 - 4, torch.zeros(B, 1, 2)], -1)
+  return s, e
+
+
+def rand_covs(B, n, dof, seed):
+  g = torch.Generator().manual_seed(seed)
+  a = torch.randn(B, n - 1, dof, dof, generator=g) * 0.3
+  qc = torch.matmul(a, a.transpose(-1, -2)) + 0.5 * torch.eye(dof)
+  ow = (torch.rand(B, n, 1, 1, generator=g) * 1.5 + 0.25) * 1e4
+  eps = torch.rand(B, n, 1, 1, generator=g) * 0.4 + 0.2
+  return qc, ow, eps
+
+
+def save(name, **kw):
+  path = os.path.join(HERE, name + '.npz')
+  np.savez_compressed(path, **{k: (N(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in kw.items()})
+  print('wrote %-28s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024.0))
+
+
+# ------------------------------------------------------------------------------------------------
+# G1: factor-level goldens
+# ------------------------------------------------------------------------------------------------
+def g1_factors():
+  B, n, dof, d = 4, 16, 2, 4
+  dt = 10.0 / (n - 1)
+  g = torch.Generator().manual_seed(11)
+  th = torch.randn(B, n, d, generator=g) * 2.5
+  # GP factor: gp_factor.py:100-110,65-73
+  gpf = GPFactor(dof, dt, n - 1, batch_size=B)
+  qc, ow, eps = rand_covs(B, n, dof, 12)
+  gpf.set_Q_c_inv(qc)
+  e_gp, H1, H2 = gpf.get_error(th)
+  # prior factor: prior_factor.py:15-18
+  pf = PriorFactor(d, torch.tensor(0.01), batch_size=B)
+  mean = torch.randn(B, 1, d, generator=g)
+  pf.set_mean(mean)
+  e_p, H_p = pf.get_error(th[:, 0:1])
+  # obstacle factor on a NON-square random SDF (H=40, W=32): obstacle_factor.py:35-40
+  Hh, Ww = 40, 32
+  sdf = torch.randn(B, 1, Hh, Ww, generator=g)
+  robot = PointRobot2D(torch.tensor(0.4), B, n)
+  of = ObstacleFactor(d, n, torch.tensor(0.4), ENV, robot, B)
+  of.set_eps(eps)
+  th_o = th.clone()
+  # edge points: outside the grid, last row/col cell, exact borders
+  edge = torch.tensor([[6.0, 1.0], [-7.0, 0.3], [0.3, -5.9], [0.3, 5.5], [4.95, 0.0], [0.0, -4.95],
+                       [5.0, 5.0], [-5.0, -5.0], [4.6875, 4.75], [-5.0, 0.0], [0.0, 5.0], [4.99999, -4.99999]])
+  th_o[0, :12, 0:2] = edge
+  e_o, H_o = of.get_error(th_o, sdf)
+  res = 10.0 / Ww
+  d_bi, J_bi = bilinear_interpolate(sdf[:, 0], th_o[:, :, 0:2].contiguous(), res, ENV['x_lims'], ENV['y_lims'])
+  # hinge tie (Q5): constant SDF equal to eps+r
+  sdf_tie = torch.full((B, 1, 16, 16), 0.8)
+  eps_tie = torch.full((B, n, 1, 1), 0.4)
+  of.set_eps(eps_tie)
+  e_t, H_t = of.get_error(th, sdf_tie)
+  save('g1_factors_2d', th=th, dt=dt, qc=qc, Q_inv=gpf.get_inv_cov_full(), e_gp=e_gp, H1=H1, H2=H2,
+       mean=mean, e_p=e_p, H_p=H_p, sdf=sdf, eps=eps, th_o=th_o, e_o=e_o, H_o=H_o, d_bi=d_bi, J_bi=J_bi,
+       sdf_tie=sdf_tie, eps_tie=eps_tie, e_t=e_t, H_t=H_t)
+
+
+def _patched_vel_factor_cls():
+  """VelocityLimitFactor (velocity_limit_factor.py) divides a tensor by 2 with py2 integer semantics;
+  emulate py2 by patching '/2' -> '//2' in an in-memory copy of the source (nothing is written)."""
+  src = open(os.path.join(REF, 'diff_gpmp2/gpmp2/custom_factors/velocity_limit_factor.py')).read()
+  src = src.replace('self.ndims/2', 'int(self.ndims)//2')
+  ns = {}
+  exec(compile(src, 'velocity_limit_factor_py2', 'exec'), ns)
+  return ns['VelocityLimitFactor']
+
+
+def g1_custom():
+  n = 12
+  g = torch.Generator().manual_seed(21)
+  # velocity limit (unbatched, (n,4)): velocity_limit_factor.py:17-29
+  VLF = _patched_vel_factor_cls()
+  vf = VLF(4, n, torch.tensor(0.01), 1)
+  vf.set_v_traj(torch.tensor([1.0]).unsqueeze(0).expand(n, 1), torch.tensor([1.0]).unsqueeze(0).expand(n, 1))
+  tr = torch.randn(n, 4, generator=g) * 1.2
+  tr[0, 2:] = torch.tensor([0.5, -2.0]); tr[1, 2:] = torch.tensor([1.0, -1.0]); tr[2, 2:] = torch.tensor([-1.0, 1.0])
+  c_v, H_v = vf.get_error_full(tr)
+  # non-holonomic (unbatched, (n,6)): nonholonomic_factor.py:16-30
+  nh = NonHolonomicFactor(3, torch.tensor(0.01), n, 1)
+  tr6 = torch.randn(n, 6, generator=g) * 1.5
+  tr6[0] = torch.tensor([0., 0., .3, 1., .5, .1])
+  e_d, H_d = nh.get_error_full(tr6)
+  save('g1_factors_custom', tr=tr, c_v=c_v, H_v=H_v, w_v=vf.get_inv_cov_full(), tr6=tr6, e_d=e_d, H_d=H_d,
+       w_d=nh.get_inv_cov_full())
+
+
+# ------------------------------------------------------------------------------------------------
+# G2: assembled normal equations from the reference's construct_linear_system_batch
+# ------------------------------------------------------------------------------------------------
+def g2_system():
+  for n in (4, 16, 64):
+    B = 3
+    planner = make_planner(B, n)
+    pl = planner.plan_layer
+    start, goal = rand_start_goal(B, seed=n)
+    g = torch.Generator().manual_seed(100 + n)
+    th = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.3
+    sdf_np = circles_sdf(64, C2_CIRCLES)
+    sdf = T(sdf_np)[None, None].repeat(B, 1, 1, 1)
+    qc, ow, eps = rand_covs(B, n, 2, 200 + n)
+    pl.start_prior.set_mean(start); pl.goal_prior.set_mean(goal)
+    pl.gp_prior.set_Q_c_inv(qc); pl.obs_factor.set_inv_cov(ow); pl.obs_factor.set_eps(eps)
+    A, b, K = pl.construct_linear_system_batch(th, sdf)
+    AtK = torch.bmm(A.transpose(1, 2), K)
+    LAM = torch.bmm(AtK, A) + 0.1 * torch.eye(pl.N)[None]
+    R = torch.bmm(AtK, b)
+    d = 4
+    Dg = torch.stack([LAM[:, i * d:(i + 1) * d, i * d:(i + 1) * d] for i in range(n)], 1)
+    Up = torch.stack([LAM[:, i * d:(i + 1) * d, (i + 1) * d:(i + 2) * d] for i in range(n - 1)], 1)
+    save('g2_system_n%d' % n, th=th, start=start, goal=goal, G=64, circles=np.asarray(C2_CIRCLES), qc=qc, ow=ow,
+         eps=eps, Dg=Dg, Up=Up, eta=R.view(B, n, d), M=pl.M, bnorm=torch.norm(b), Anorm=torch.norm(A), Knorm=torch.norm(K))
+
+
+# ------------------------------------------------------------------------------------------------
+# G3/G4: one step and 10 teacher-forced steps (planner.step), C1 real map and C2-shaped mini batch
+# ------------------------------------------------------------------------------------------------
+def c1_inputs(n):
+  im = plt.imread(os.path.join(REF, 'diff_gpmp2/env/simple_2d/5.png'))
+  if im.ndim > 2: im = np.dot(im[..., :3], [0.299, 0.587, 0.114])
+  cell = 10.0 / im.shape[0]
+  sdf = sdf_2d(im, res=cell)                           # padlen=1 -> 202x202 (Q3)
+  start = torch.tensor([[[-4.0, -4.0, 0.0, 0.0]]]); goal = torch.tensor([[[4.0, 4.0, 0.0, 0.0]]])
+  th = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  return T(im)[None, None], T(sdf)[None, None], start, goal, th
+
+
+def g3_c1():
+  out = {}
+  for n in (32, 33, 101):
+    im, sdf, start, goal, th = c1_inputs(n)
+    planner = make_planner(1, n)
+    dth, _, err, err_ext, _, _, _ = planner.step(th, start, goal, im, sdf)
+    out['n%d_err0' % n] = err; out['n%d_dth0' % n] = dth; out['n%d_errext0' % n] = err_ext
+    if n == 32:
+      ths = [th]; errs = []; errexts = []; dths = []
+      for k in range(10):
+        dth, _, err, err_ext, _, _, _ = planner.step(ths[-1], start, goal, im, sdf)
+        dths.append(dth); errs.append(err); errexts.append(err_ext); ths.append(ths[-1] + dth)
+      out.update(sdf=sdf[0, 0], start=start, goal=goal, th_hist=torch.stack(ths, 0), dth_hist=torch.stack(dths, 0),
+                 err_hist=torch.stack(errs, 0), errext_hist=torch.stack(errexts, 0),
+                 err_after10=planner.error_batch(ths[-1], sdf))
+      usg, ugp, uobs = planner.unweighted_errors_batch(ths[3], sdf)
+      out.update(unw_sg=usg, unw_gp=ugp, unw_obs=uobs)
+  save('g3_c1', **out)
+
+
+def g3_c2mini():
+  B, n, Gsz = 8, 64, 256
+  start, goal = rand_start_goal(B, seed=0)
+  th0 = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  sdf = T(circles_sdf(Gsz, C2_CIRCLES))[None, None].repeat(B, 1, 1, 1)
+  im = (sdf > 0).double()
+  planner = make_planner(B, n)
+  out = dict(start=start, goal=goal, G=Gsz, circles=np.asarray(C2_CIRCLES))
+  # static covariances, 10 teacher-forced steps
+  ths = [th0]; dths = []; errs = []; errexts = []
+  for k in range(10):
+    dth, _, err, err_ext, qc_s, ow_s, eps_s = planner.step(ths[-1], start, goal, im, sdf)
+    dths.append(dth); errs.append(err); errexts.append(err_ext); ths.append(ths[-1] + dth)
+  out.update(th_hist=torch.stack(ths, 0), dth_hist=torch.stack(dths, 0), err_hist=torch.stack(errs, 0),
+             errext_hist=torch.stack(errexts, 0))
+  # random SPD per-state covariances through PlanLayer.forward (plan_layer.py:87-99)
+  qc, ow, eps = rand_covs(B, n, 2, 7)
+  th1 = ths[2]
+  dth, err, err_ext = planner.plan_layer(th1, start, goal, im, sdf, qc, ow, eps)
+  out.update(cov_qc=qc, cov_ow=ow, cov_eps=eps, cov_th=th1, cov_dth=dth, cov_err=err, cov_errext=err_ext)
+  # per-sample SDFs (3 random circles each, G=96)
+  g = torch.Generator().manual_seed(1)
+  cc = torch.rand(B, 3, 2, generator=g) * 7 - 3.5
+  rr = torch.rand(B, 3, 1, generator=g) * 0.6 + 0.4
+  circ = torch.cat([cc, rr], -1)
+  sdf_ps = torch.stack([T(circles_sdf(96, [tuple(c) for c in N(circ[b])])) for b in range(B)], 0)[:, None]
+  dth, _, err, err_ext, _, _, _ = planner.step(th0, start, goal, (sdf_ps > 0).double(), sdf_ps)
+  out.update(ps_circles=circ, ps_G=96, ps_dth=dth, ps_err=err, ps_errext=err_ext)
+  save('g3_c2mini', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# forward() (GN to convergence) on the C1 plumbing and a small batch
+# ------------------------------------------------------------------------------------------------
+def g4_forward():
+  n = 32
+  im, sdf, start, goal, th = c1_inputs(n)
+  planner = make_planner(1, n, max_iters=12)
+  import io, contextlib
+  with contextlib.redirect_stdout(io.StringIO()):
+    thf, _, e_init, e_final, e_iter, ee_iter, k, _ = planner.forward(th, start, goal, im, sdf)
+  out = dict(c1_th_final=thf, c1_err_init=e_init, c1_err_final=e_final, c1_err_iter=np.asarray(e_iter),
+             c1_errext_iter=np.asarray(ee_iter), c1_iters=k, c1_max_iters=12, c1_tol_delta=1e-4)
+  # obstacle-free map => converges by tol_delta in a few iterations (exercises the early exit)
+  B, n2 = 3, 16
+  start2, goal2 = rand_start_goal(B, seed=5)
+  g = torch.Generator().manual_seed(6)
+  th2 = straight_line_trajb(start2[:, :, :2], goal2[:, :, :2], 10.0, n2 - 1, 2) + torch.randn(B, n2, 4, generator=g) * 0.2
+  sdf2 = torch.full((B, 1, 32, 32), 3.0)
+  gp, obs, plp, opt = params_2d(n2, max_iters=20)
+  opt['tol_delta'] = 2e-3
+  pl2 = DiffGPMP2Planner(gp, obs, plp, opt, ENV, PointRobot2D(torch.tensor(0.4), 1, n2), batch_size=1)
+  with contextlib.redirect_stdout(io.StringIO()):
+    thf2, _, ei2, ef2, eit2, eeit2, k2, _ = pl2.forward(th2, start2, goal2, (sdf2 > 0).double(), sdf2)
+  maxlen = max(len(e) for e in eit2)
+  pad = lambda L: np.asarray([list(e) + [np.nan] * (maxlen - len(e)) for e in L])
+  out.update(free_th0=th2, free_start=start2, free_goal=goal2, free_th_final=thf2, free_err_init=ei2, free_err_final=ef2,
+             free_err_iter=pad(eit2), free_errext_iter=pad(eeit2), free_iters=k2, free_max_iters=20, free_tol_delta=2e-3)
+  save('g4_forward', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# G5: autograd through one step (reference autograd over plan_layer.py:152-234)
+# ------------------------------------------------------------------------------------------------
+def g5_grads():
+  B, n, Gsz = 4, 16, 48
+  start, goal = rand_start_goal(B, seed=3)
+  g = torch.Generator().manual_seed(31)
+  th = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.2
+  circ = ((-1.0, -1.0, 1.5), (2.0, 1.5, 1.2), (0.5, -2.5, 1.0))
+  sdf = T(circles_sdf(Gsz, circ))[None, None].repeat(B, 1, 1, 1)
+  qc, ow, eps = rand_covs(B, n, 2, 32)
+  gbar = torch.randn(B, n, 4, generator=g)
+  gext = torch.randn(B, 1, 1, generator=g)
+  planner = make_planner(B, n)
+  leaves = [x.clone().requires_grad_(True) for x in (th, sdf, start, goal, qc, ow, eps)]
+  dth, err, err_ext = planner.plan_layer(leaves[0], leaves[2], leaves[3], (sdf > 0).double(), leaves[1], leaves[4], leaves[5], leaves[6])
+  loss = (gbar * dth).sum()
+  grads = torch.autograd.grad(loss, leaves, retain_graph=True, allow_unused=True)
+  loss_e = (gext * err_ext).sum()
+  grads_e = torch.autograd.grad(loss_e, leaves, allow_unused=True)
+  z = lambda gr, x: torch.zeros_like(x) if gr is None else gr
+  names = ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps')
+  out = dict(th=th, G=Gsz, circles=np.asarray(circ), start=start, goal=goal, qc=qc, ow=ow, eps=eps, gbar=gbar, gext=gext,
+             dth=dth, err=err, err_ext=err_ext, err_requires_grad=bool(err.requires_grad))
+  for nm, gr, ge, x in zip(names, grads, grads_e, leaves):
+    out['g_' + nm] = z(gr, x); out['ge_' + nm] = z(ge, x)
+    out['ge_none_' + nm] = ge is None
+  save('g5_grads', **out)
+
+
+# ------------------------------------------------------------------------------------------------
+# C3 / C4: the reference's batched path is broken for these; goldens are built from
+# the reference's own UNBATCHED factor functions + its own masks (create_factor_masks), per trajectory.
+# ------------------------------------------------------------------------------------------------
+def _dense_from_ref(pl, th1, start1, goal1, sdf1, e_extra, H_extra, w_extra, kind):
+  """Assemble A,b,K for ONE trajectory with the reference's masks; base factors via the reference's
+  batched functions on a batch of 1, extra (vel/dyn) factor rows from the unbatched reference outputs."""
+  A = torch.zeros(1, pl.M, pl.N); b = torch.zeros(1, pl.M, 1); K = torch.zeros(1, pl.M, pl.M)
+  e_p, H_p = pl.start_prior.get_error(th1[:, 0:1]); e_g, H_g = pl.goal_prior.get_error(th1[:, -1:])
+  e_gp, H1, H2 = pl.gp_prior.get_error(th1)
+  A.masked_scatter_(pl.mask_Astart[None], H_p); b.masked_scatter_(pl.mask_bstart[None], e_p)
+  K.masked_scatter_(pl.mask_Kstart[None], pl.start_prior.get_inv_cov()[0:1])
+  A.masked_scatter_(pl.mask_A1gp[None], H1); A.masked_scatter_(pl.mask_A2gp[None], H2)
+  b.masked_scatter_(pl.mask_bgp[None], e_gp); K.masked_scatter_(pl.mask_Kgp[None], pl.gp_prior.get_inv_cov_full()[0:1])
+  A.masked_scatter_(pl.mask_Agoal[None], H_g); b.masked_scatter_(pl.mask_bgoal[None], e_g)
+  K.masked_scatter_(pl.mask_Kgoal[None], pl.goal_prior.get_inv_cov()[0:1])
+  e_o, H_o = sdf1
+  A.masked_scatter_(pl.mask_Aobs[None], H_o); b.masked_scatter_(pl.mask_bobs[None], e_o)
+  K.masked_scatter_(pl.mask_Kobs[None], pl.obs_factor.get_inv_cov_full()[0:1])
+  mA, mb, mK = (pl.mask_Adyn, pl.mask_bdyn, pl.mask_Kdyn) if kind == 'dyn' else (pl.mask_Avel, pl.mask_bvel, pl.mask_Kvel)
+  A.masked_scatter_(mA[None], H_extra); b.masked_scatter_(mb[None], e_extra); K.masked_scatter_(mK[None], w_extra)
+  return A, b, K
+
+
+def g3_c3_vel():
+  """2D point robot + velocity-limit factors (config 3), B=4, n=16."""
+  B, n = 4, 16
+  gp, obs, plp, opt = params_2d(n)
+  plp['use_vel_limits'] = True
+  VLF = _patched_vel_factor_cls()
+  import diff_gpmp2.gpmp2.plan_layer as plmod
+  plmod.VelocityLimitFactor = VLF            # py2-semantics copy (in memory only)
+  gp['v_x'] = [1.0]; gp['v_y'] = [1.0]
+  robot = PointRobot2D(torch.tensor(0.4), 1, n)
+  pl = PlanLayer(gp, obs, plp, opt, ENV, robot, None, 1, False)
+  start, goal = rand_start_goal(B, seed=9)
+  g = torch.Generator().manual_seed(91)
+  th = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.4
+  th[:, :, 2:] = th[:, :, 2:] * 2.0          # push some velocities past the 1.0 limit
+  sdf = T(circles_sdf(64, C2_CIRCLES))[None, None]
+  qc1 = torch.eye(2)[None, None].repeat(1, n - 1, 1, 1)
+  ow1 = torch.full((1, n, 1, 1), 1e4); eps1 = torch.full((1, n, 1, 1), 0.4)
+  dths, errs = [], []
+  for i in range(B):
+    t1 = th[i:i + 1]
+    pl.start_prior.set_mean(start[i:i + 1]); pl.goal_prior.set_mean(goal[i:i + 1])
+    pl.gp_prior.set_Q_c_inv(qc1); pl.obs_factor.set_inv_cov(ow1); pl.obs_factor.set_eps(eps1)
+    eo = pl.obs_factor.get_error(t1, sdf)
+    c_v, H_v = pl.vel_factor.get_error_full(t1[0])
+    A, b, K = _dense_from_ref(pl, t1, None, None, eo, c_v, H_v, pl.vel_factor.get_inv_cov_full(), 'vel')
+    dth = pl.solve_linear_system_batch(A, b, K, delta=0.1)
+    err = 0.5 * torch.bmm(torch.bmm(b.transpose(1, 2), K), b) / pl.M      # == error_batch's sum (plan_layer.py:273-308)
+    dths.append(dth); errs.append(err)
+  save('g3_c3_vel', th=th, start=start, goal=goal, G=64, circles=np.asarray(C2_CIRCLES), dth=torch.cat(dths, 0),
+       err=torch.cat(errs, 0), M=pl.M)
+
+
+def g3_c4_xyh():
+  """Non-holonomic (x,y,theta) robot, d=6 (config 4), B=4, n=16.  PointRobotXYH has no batched sphere
+  model in the reference, so the obstacle rows come from the reference's
+  hinge_loss_signed_batch on state[0:2] with H_fk = I_6[0:2,:] (point_robot_xyh.py:28-36)."""
+  from diff_gpmp2.gpmp2.obstacle.obstacle_cost import HingeLossObstacleCost
+  B, n, dof, d = 4, 16, 3, 6
+  gp = {'Q_c_inv': torch.eye(3), 'K_s': torch.tensor(0.01), 'K_g': torch.tensor(0.01), 'K_d': torch.tensor(0.01)}
+  obs = {'cost_sigma': torch.tensor(0.01), 'epsilon_dist': torch.tensor(0.2)}
+  plp = {'dof': 3, 'state_dim': 6, 'total_time_sec': 10.0, 'total_time_step': n - 1, 'non_holonomic': True}
+  opt = {'method': 'gauss_newton', 'reg': 0.0, 'plan_time': float('inf'), 'max_iters': 10, 'tol_err': 1e-4, 'tol_delta': 1e-3}
+
+  class _XYH(object):      # nlinks/sphere radius only -- what PlanLayer.__init__ touches (plan_layer.py:42)
+    nlinks = 1
+    def get_sphere_radii(self): return torch.tensor(0.4)
+  pl = PlanLayer(gp, obs, plp, opt, ENV, _XYH(), None, 1, False)
+  g = torch.Generator().manual_seed(41)
+  sp = torch.rand(B, 1, 2, generator=g) * 8 - 4; gl = torch.rand(B, 1, 2, generator=g) * 8 - 4
+  start = torch.cat([sp, torch.zeros(B, 1, 1), torch.zeros(B, 1, 3)], -1)
+  goal = torch.cat([gl, torch.full((B, 1, 1), np.pi / 2), torch.zeros(B, 1, 3)], -1)
+  th = straight_line_trajb(start[:, :, :3], goal[:, :, :3], 10.0, n - 1, 3) + torch.randn(B, n, 6, generator=g) * 0.2
+  Gsz = 128
+  sdf = T(circles_sdf(Gsz, C2_CIRCLES))[None, None]
+  hl = HingeLossObstacleCost(ENV)
+  qc1 = torch.eye(3)[None, None].repeat(1, n - 1, 1, 1)
+  ow1 = torch.full((1, n, 1, 1), 1e4); eps1 = torch.full((1, n, 1, 1), 0.2)
+  H_fk = torch.zeros(2, 6); H_fk[0, 0] = 1; H_fk[1, 1] = 1
+  dths, errs = [], []
+  for i in range(B):
+    t1 = th[i:i + 1]
+    pl.start_prior.set_mean(start[i:i + 1]); pl.goal_prior.set_mean(goal[i:i + 1])
+    pl.gp_prior.set_Q_c_inv(qc1); pl.obs_factor.set_inv_cov(ow1)
+    e_o, H_e = hl.hinge_loss_signed_batch(t1[:, :, 0:2].reshape(1, n, 1, 2), torch.tensor(0.4), eps1, sdf)
+    H_o = torch.einsum('bsij,jk->bsik', H_e, H_fk)
+    e_d, H_d = pl.dyn_factor.get_error_full(t1[0])
+    A, b, K = _dense_from_ref(pl, t1, None, None, (e_o, H_o), e_d, H_d, pl.dyn_factor.get_inv_cov_full(), 'dyn')
+    dth = pl.solve_linear_system_batch(A, b, K, delta=0.0)
+    err = 0.5 * torch.bmm(torch.bmm(b.transpose(1, 2), K), b) / pl.M
+    dths.append(dth); errs.append(err)
+  save('g3_c4_xyh', th=th, start=start, goal=goal, G=Gsz, circles=np.asarray(C2_CIRCLES), dth=torch.cat(dths, 0),
+       err=torch.cat(errs, 0), M=pl.M)
+
+
+if __name__ == '__main__':
+  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh()
