@@ -1,0 +1,159 @@
+"""ctypes binding of the C-ABI declared in include/dgpmp2_hip.h.
+
+The product path loads dgpmp2_amd/lib/libdgpmp2_hip.so (built in-tree by __graft_entry__.build()) and
+fails loudly when it is missing -- there is no CPU fallback.  The binding class is parameterised by
+(library, symbol prefix) only so that the test-suite can drive tests/emul's CPU wavefront emulator,
+which exports the same entry points with the prefix `emul_`, through the very same marshalling code.
+"""
+import ctypes as C
+import os
+
+DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
+DGP_F32, DGP_F64 = 0, 1
+DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
+DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
+DGP_ABI_VERSION = 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')
+
+
+class DgpConfig(C.Structure):
+  _fields_ = [('struct_size', C.c_uint32), ('num_states', C.c_int32), ('dof', C.c_int32), ('nlinks', C.c_int32),
+              ('io_dtype', C.c_int32), ('flags', C.c_uint32), ('total_time_sec', C.c_double),
+              ('x_lims', C.c_double * 2), ('y_lims', C.c_double * 2), ('K_s', C.c_double), ('K_g', C.c_double),
+              ('reg', C.c_double), ('sphere_radius', C.c_double), ('Q_c_inv', C.c_double * 9),
+              ('cost_sigma', C.c_double), ('epsilon_dist', C.c_double), ('K_d', C.c_double), ('K_v', C.c_double),
+              ('v_x', C.c_double), ('v_y', C.c_double)]
+
+
+class DgpSdf(C.Structure):
+  _fields_ = [('data', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32), ('batch_stride', C.c_int64)]
+
+
+class DgpCovs(C.Structure):
+  _fields_ = [('qc_mode', C.c_int32), ('qc_inv', C.c_void_p), ('obs_w', C.c_void_p), ('eps', C.c_void_p)]
+
+
+class DgpError(RuntimeError):
+  def __init__(self, code, msg):
+    super(DgpError, self).__init__('dgpmp2_hip error %d: %s' % (code, msg))
+    self.code = code
+
+
+class CApi(object):
+  """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
+
+  SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'gn_step', 'gn_solve',
+             'eval_errors', 'gn_step_backward')
+
+  def __init__(self, path, prefix='dgp_'):
+    if not os.path.exists(path):
+      raise ImportError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                        '(hipcc --offload-arch=gfx950).  dgpmp2_amd has no CPU fallback.' % path)
+    self.path, self.prefix = path, prefix
+    self.lib = C.CDLL(path)
+    f = lambda name: getattr(self.lib, prefix + name)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    self.abi_version = f('abi_version'); self.abi_version.restype = C.c_int; self.abi_version.argtypes = []
+    self.last_error = f('last_error'); self.last_error.restype = C.c_char_p; self.last_error.argtypes = []
+    self.create = f('create'); self.create.restype = C.c_int; self.create.argtypes = [C.POINTER(DgpConfig), C.POINTER(vp)]
+    self.destroy = f('destroy'); self.destroy.restype = None; self.destroy.argtypes = [vp]
+    self.num_factor_rows = f('num_factor_rows'); self.num_factor_rows.restype = C.c_int; self.num_factor_rows.argtypes = [vp]
+    self.gn_step = f('gn_step'); self.gn_step.restype = C.c_int
+    self.gn_step.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp]
+    self.gn_solve = f('gn_solve'); self.gn_solve.restype = C.c_int
+    self.gn_solve.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), i32, dbl, vp, vp, vp, vp, vp, vp, vp]
+    self.eval_errors = f('eval_errors'); self.eval_errors.restype = C.c_int
+    self.eval_errors.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp]
+    self.gn_step_backward = f('gn_step_backward'); self.gn_step_backward.restype = C.c_int
+    self.gn_step_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, i64,
+                                      vp, vp, vp, vp]
+    v = self.abi_version()
+    if v != DGP_ABI_VERSION:
+      raise ImportError('%s: ABI version %d, binding expects %d' % (path, v, DGP_ABI_VERSION))
+
+  def check(self, rc):
+    if rc != DGP_OK:
+      raise DgpError(rc, (self.last_error() or b'').decode('utf-8', 'replace'))
+
+
+_api = None
+
+
+def get_api():
+  """The product library (HIP).  Raises ImportError if it has not been built."""
+  global _api
+  if _api is None:
+    _api = CApi(LIB_PATH, 'dgp_')
+  return _api
+
+
+def make_config(num_states, dof, io_dtype, total_time_sec, x_lims, y_lims, K_s, K_g, reg, sphere_radius, Q_c_inv,
+                cost_sigma, epsilon_dist, non_holonomic=False, use_vel_limits=False, K_d=0.0, K_v=0.0, v_x=0.0, v_y=0.0,
+                nlinks=1):
+  cfg = DgpConfig()
+  cfg.struct_size = C.sizeof(DgpConfig)
+  cfg.num_states, cfg.dof, cfg.nlinks, cfg.io_dtype = int(num_states), int(dof), int(nlinks), int(io_dtype)
+  cfg.flags = (DGP_FLAG_NONHOLONOMIC if non_holonomic else 0) | (DGP_FLAG_VEL_LIMITS if use_vel_limits else 0)
+  cfg.total_time_sec = float(total_time_sec)
+  cfg.x_lims[0], cfg.x_lims[1] = float(x_lims[0]), float(x_lims[1])
+  cfg.y_lims[0], cfg.y_lims[1] = float(y_lims[0]), float(y_lims[1])
+  cfg.K_s, cfg.K_g, cfg.reg, cfg.sphere_radius = float(K_s), float(K_g), float(reg), float(sphere_radius)
+  q = [float(v) for row in Q_c_inv for v in row]
+  if len(q) != int(dof) * int(dof):
+    raise ValueError('Q_c_inv must be dof x dof')
+  for k in range(9):
+    cfg.Q_c_inv[k] = q[k] if k < len(q) else 0.0
+  cfg.cost_sigma, cfg.epsilon_dist = float(cost_sigma), float(epsilon_dist)
+  cfg.K_d, cfg.K_v, cfg.v_x, cfg.v_y = float(K_d), float(K_v), float(v_x), float(v_y)
+  return cfg
+
+
+class Solver(object):
+  """One DgpHandle.  All methods take raw addresses (ints) -- see dgpmp2_amd.gpmp2.plan_layer for the
+  torch-facing layer.  Immutable after construction, hence safe to share between streams/threads."""
+
+  def __init__(self, cfg, api=None):
+    self.api = api if api is not None else get_api()
+    self.cfg = cfg
+    h = C.c_void_p()
+    self.api.check(self.api.create(C.byref(cfg), C.byref(h)))
+    self.handle = h
+    self.M = self.api.num_factor_rows(h)
+    self.n, self.dof, self.d = cfg.num_states, cfg.dof, 2 * cfg.dof
+
+  def __del__(self):
+    h = getattr(self, 'handle', None)
+    if h is not None and h.value:
+      self.api.destroy(h)
+      self.handle = None
+
+  @staticmethod
+  def sdf_arg(ptr, rows, cols, batch_stride):
+    return DgpSdf(ptr, int(rows), int(cols), int(batch_stride))
+
+  @staticmethod
+  def covs_arg(qc_mode=DGP_QC_STATIC, qc_inv=None, obs_w=None, eps=None):
+    return DgpCovs(int(qc_mode), qc_inv, obs_w, eps)
+
+  def gn_step(self, batch, th, start, goal, sdf, covs, dtheta, err=None, err_ext=None, info=None, stream=None):
+    self.api.check(self.api.gn_step(self.handle, batch, th, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,
+                                    dtheta, err, err_ext, info, stream))
+
+  def gn_solve(self, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters=None, err_hist=None,
+               errext_hist=None, err_final=None, info=None, stream=None):
+    self.api.check(self.api.gn_solve(self.handle, batch, th_init, start, goal, C.byref(sdf),
+                                     C.byref(covs) if covs is not None else None, int(max_iters), float(tol_delta), th_out, iters,
+                                     err_hist, errext_hist, err_final, info, stream))
+
+  def eval_errors(self, batch, th, start, goal, sdf, covs, err=None, err_ext=None, unw_sg=None, unw_gp=None, unw_obs=None,
+                  stream=None):
+    self.api.check(self.api.eval_errors(self.handle, batch, th, start, goal, C.byref(sdf),
+                                        C.byref(covs) if covs is not None else None, err, err_ext, unw_sg, unw_gp, unw_obs, stream))
+
+  def gn_step_backward(self, batch, th, start, goal, sdf, covs, g_dtheta, g_err_ext, g_th=None, g_start=None, g_goal=None,
+                       g_sdf=None, g_sdf_batch_stride=0, g_qc_inv=None, g_obs_w=None, g_eps=None, stream=None):
+    self.api.check(self.api.gn_step_backward(self.handle, batch, th, start, goal, C.byref(sdf),
+                                             C.byref(covs) if covs is not None else None, g_dtheta, g_err_ext, g_th, g_start,
+                                             g_goal, g_sdf, int(g_sdf_batch_stride), g_qc_inv, g_obs_w, g_eps, stream))

@@ -1,0 +1,155 @@
+// dgp_host.h -- host-side logic behind the C-ABI (no HIP in here): config validation, the constants of
+// PlanLayer.__init__ (plan_layer.py:14-81) and per-call argument marshalling into dgp::GnParams.
+// Shared by dgpmp2_hip.hip (the product library) and tests/emul (the CPU wavefront emulator used by tests).
+#pragma once
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+#include "gn_lane.h"
+#include "gn_backward.h"
+#include "../../include/dgpmp2_hip.h"
+
+struct DgpHandle {
+  DgpConfig cfg;
+  int d;                // state_dim
+  int lpt;              // lanes per trajectory (16/32/64)
+  int M;                // plan_layer.py:43-45
+  dgp::GnParams base;   // constants filled once
+};
+
+namespace dgp_host {
+
+inline char* err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int create(const DgpConfig* cfg, DgpHandle** out) {
+  if (!cfg || !out) return fail(DGP_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(DgpConfig))
+    return fail(DGP_EINVAL, "DgpConfig size mismatch: caller %u, library %zu", cfg->struct_size, sizeof(DgpConfig));
+  if (cfg->dof != 2 && cfg->dof != 3) return fail(DGP_EUNSUPPORTED, "dof must be 2 or 3, got %d", cfg->dof);
+  if (cfg->nlinks != 1) return fail(DGP_EUNSUPPORTED, "only nlinks == 1 (point robots) is implemented, got %d", cfg->nlinks);
+  if (cfg->num_states < 2) return fail(DGP_EINVAL, "num_states must be >= 2, got %d", cfg->num_states);
+  if (cfg->num_states > 64) return fail(DGP_EUNSUPPORTED, "num_states > 64 is not implemented yet, got %d", cfg->num_states);
+  if (cfg->io_dtype != DGP_F32 && cfg->io_dtype != DGP_F64) return fail(DGP_EINVAL, "bad io_dtype %d", cfg->io_dtype);
+  if ((cfg->flags & DGP_FLAG_NONHOLONOMIC) && cfg->dof != 3)
+    return fail(DGP_EINVAL, "the non-holonomic factor needs the (x,y,theta) robot, dof == 3");
+  if (cfg->flags & ~(DGP_FLAG_NONHOLONOMIC | DGP_FLAG_VEL_LIMITS)) return fail(DGP_EINVAL, "unknown flag bits 0x%x", cfg->flags);
+  if (!(cfg->total_time_sec > 0.0)) return fail(DGP_EINVAL, "total_time_sec must be positive");
+  if (!(cfg->x_lims[1] > cfg->x_lims[0]) || !(cfg->y_lims[1] > cfg->y_lims[0])) return fail(DGP_EINVAL, "empty x/y limits");
+  if (!(cfg->K_s > 0.0) || !(cfg->K_g > 0.0) || !(cfg->cost_sigma > 0.0)) return fail(DGP_EINVAL, "K_s, K_g, cost_sigma must be positive");
+  if ((cfg->flags & DGP_FLAG_NONHOLONOMIC) && !(cfg->K_d > 0.0)) return fail(DGP_EINVAL, "K_d must be positive");
+  if ((cfg->flags & DGP_FLAG_VEL_LIMITS) && !(cfg->K_v > 0.0)) return fail(DGP_EINVAL, "K_v must be positive");
+  DgpHandle* h = new (std::nothrow) DgpHandle();
+  if (!h) return fail(DGP_EINVAL, "out of host memory");
+  h->cfg = *cfg;
+  const int n = cfg->num_states, dof = cfg->dof;
+  h->d = 2 * dof;
+  h->lpt = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+  h->M = h->d * ((n - 1) + 2) + n * cfg->nlinks;                       // plan_layer.py:43
+  if (cfg->flags & DGP_FLAG_NONHOLONOMIC) h->M += n;                    // :44
+  if (cfg->flags & DGP_FLAG_VEL_LIMITS) h->M += dof * n;                // :45
+  dgp::GnParams& p = h->base;
+  memset(&p, 0, sizeof(p));
+  p.n = n;
+  p.flags = cfg->flags;
+  p.dt = cfg->total_time_sec * 1.0 / (double)(n - 1) * 1.0;             // plan_layer.py:31
+  p.qa = 12.0 * pow(p.dt, -3.0);                                        // gp_factor.py:66-68
+  p.qb = -6.0 * pow(p.dt, -2.0);
+  p.qc_ = 4.0 * pow(p.dt, -1.0);
+  p.w_s = 1.0 / pow(cfg->K_s, 2.0);                                     // plan_layer.py:64-65
+  p.w_g = 1.0 / pow(cfg->K_g, 2.0);
+  p.reg = cfg->reg;
+  p.radius = cfg->sphere_radius;
+  p.eps_static = cfg->epsilon_dist;
+  p.obs_w_fix = 1.0 / pow(cfg->cost_sigma, 2.0);                        // plan_layer.py:74
+  for (int k = 0; k < 9; ++k) p.qc_fix[k] = cfg->Q_c_inv[k];
+  p.w_d = (cfg->flags & DGP_FLAG_NONHOLONOMIC) ? 1.0 / pow(cfg->K_d, 2.0) : 0.0;
+  p.w_v = (cfg->flags & DGP_FLAG_VEL_LIMITS) ? 1.0 / pow(cfg->K_v, 2.0) : 0.0;
+  p.vmax[0] = cfg->v_x; p.vmax[1] = cfg->v_y;
+  p.M = (double)h->M;
+  *out = h;
+  return DGP_OK;
+}
+
+// Fill the per-call part of the kernel arguments; returns DGP_OK or an error code.
+inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                     const DgpCovs* covs, dgp::GnParams& p) {
+  if (!h) return fail(DGP_EINVAL, "null handle");
+  if (batch <= 0) return fail(DGP_EINVAL, "batch must be positive, got %d", batch);
+  if (!th || !start || !goal) return fail(DGP_EINVAL, "th/start/goal must be non-null device pointers");
+  if (!sdf || !sdf->data) return fail(DGP_EINVAL, "sdf must be non-null");
+  if (sdf->rows < 1 || sdf->cols < 1) return fail(DGP_EINVAL, "sdf grid must be at least 1x1, got %dx%d", sdf->rows, sdf->cols);
+  if (sdf->batch_stride < 0) return fail(DGP_EINVAL, "negative sdf batch stride");
+  p = h->base;
+  p.B = batch;
+  p.th = th; p.start = start; p.goal = goal;
+  p.sdf = sdf->data; p.sdf_rows = sdf->rows; p.sdf_cols = sdf->cols; p.sdf_bstride = sdf->batch_stride;
+  // obstacle_cost.py:34 and sdf_utils.py:57-58, evaluated exactly as Python does (fp64)
+  p.res = (h->cfg.x_lims[1] - h->cfg.x_lims[0]) / (double)sdf->cols;
+  p.orig_px = (0. - h->cfg.x_lims[0] / p.res);
+  p.orig_py = (0. - h->cfg.y_lims[0] / p.res);
+  p.qc_mode = DGP_QC_STATIC; p.qc = nullptr; p.obs_w = nullptr; p.eps = nullptr;
+  if (covs) {
+    if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_QFULL) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+    if ((covs->qc_mode == DGP_QC_STATIC) != (covs->qc_inv == nullptr))
+      return fail(DGP_EINVAL, "qc_inv must be NULL iff qc_mode == DGP_QC_STATIC");
+    p.qc_mode = covs->qc_mode; p.qc = covs->qc_inv; p.obs_w = covs->obs_w; p.eps = covs->eps;
+  }
+  return DGP_OK;
+}
+
+inline int fill_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                     const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, dgp::GnParams& p) {
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  if (rc != DGP_OK) return rc;
+  if (!dtheta) return fail(DGP_EINVAL, "dtheta must be non-null");
+  p.dtheta = dtheta; p.err = err; p.err_ext = err_ext; p.info = info;
+  return DGP_OK;
+}
+
+inline int fill_solve(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf,
+                      const DgpCovs* covs, int32_t max_iters, double tol_delta, void* th_out, int32_t* iters, void* err_hist,
+                      void* errext_hist, void* err_final, int32_t* info, dgp::GnParams& p) {
+  int rc = fill_call(h, batch, th_init, start, goal, sdf, covs, p);
+  if (rc != DGP_OK) return rc;
+  if (!th_out) return fail(DGP_EINVAL, "th_out must be non-null");
+  if (max_iters < 1) return fail(DGP_EINVAL, "max_iters must be >= 1, got %d", max_iters);
+  p.th_out = th_out; p.iters = iters; p.err_hist = err_hist; p.errext_hist = errext_hist; p.err_final = err_final;
+  p.info = info; p.max_iters = max_iters; p.tol_delta = tol_delta;
+  return DGP_OK;
+}
+
+inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                     const DgpCovs* covs, void* err, void* err_ext, void* unw_sg, void* unw_gp, void* unw_obs, dgp::GnParams& p) {
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  if (rc != DGP_OK) return rc;
+  p.err = err; p.err_ext = err_ext; p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
+  return DGP_OK;
+}
+
+inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                         const DgpCovs* covs, const void* g_dtheta, const void* g_err_ext, void* g_th, void* g_start, void* g_goal,
+                         void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w, void* g_eps, dgp::GnParams& p,
+                         dgp::GnGradParams& g) {
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  if (rc != DGP_OK) return rc;
+  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
+  g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
+  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
+  return DGP_OK;
+}
+
+}  // namespace dgp_host

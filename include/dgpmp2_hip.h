@@ -1,0 +1,158 @@
+/* dgpmp2_hip.h -- C-ABI of the MI355X-native inner Gauss-Newton solver for dGPMP2.
+ *
+ * The reference (mhmukadam/dgpmp2) has NO FFI: its boundary for this path is a Python API,
+ *   PlanLayer.forward(thb,startb,goalb,imb,sdfb,qc_inv_trajb,obscov_inv_trajb,eps_trajb)
+ *       -> (dthetab, err, err_ext)                         diff_gpmp2/gpmp2/plan_layer.py:87-99
+ *   DiffGPMP2Planner.step(...) / .forward(...)              diff_gpmp2/gpmp2/diff_gpmp2_planner.py:176-211 / :92-174
+ *   PlanLayer.error_batch / error_ext_batch / gp_error / obs_error / start_goal_error
+ *                                                           plan_layer.py:273-345, :374-388
+ * Each entry point below names the reference function it replaces.  The host-side mirror of the
+ * Python classes (same names, arguments, return tuples) lives in dgpmp2_amd/gpmp2/ and calls these
+ * through ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every data pointer is a BORROWED DEVICE pointer (torch tensor.data_ptr()), contiguous row-major
+ *    with exactly the torch shapes quoted; element type is the handle's io_dtype (all tensors alike).
+ *  - all arithmetic inside the kernels is IEEE binary64 (the reference is fp64-only).
+ *  - calls are asynchronous on the HIP stream passed as `stream` (a hipStream_t cast to void*;
+ *    NULL = the null stream).  Nothing is allocated, freed or synchronised inside a call.
+ *  - return value: DGP_OK or a negative DGP_E* code; never throws.  dgp_last_error() gives the text
+ *    of the calling thread's last failure.
+ *  - a handle is immutable after dgp_create() => the same handle may be used from several threads
+ *    and streams concurrently (unlike the reference PlanLayer, which mutates factor state per call).
+ */
+#ifndef DGPMP2_HIP_H
+#define DGPMP2_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DGP_ABI_VERSION 1
+
+/* status codes */
+#define DGP_OK              0
+#define DGP_EINVAL         -1   /* bad argument (NULL pointer, size out of range, bad enum)            */
+#define DGP_EUNSUPPORTED   -2   /* valid request outside what the kernels implement (e.g. nlinks != 1) */
+#define DGP_EHIP           -3   /* HIP runtime error (launch failure, no device)                       */
+
+/* io_dtype */
+#define DGP_F32 0
+#define DGP_F64 1
+
+/* flags */
+#define DGP_FLAG_NONHOLONOMIC 1u   /* planner_params['non_holonomic'] (plan_layer.py:32), needs dof == 3 */
+#define DGP_FLAG_VEL_LIMITS   2u   /* planner_params['use_vel_limits'] (plan_layer.py:34)                 */
+
+/* GP covariance input modes (plan_layer.py:90-91; diff_gpmp2_planner.py:247-290) */
+#define DGP_QC_STATIC   0   /* qc_inv == NULL: gp_params['Q_c_inv'] for every factor (diff_gpmp2_planner.py:41-46)  */
+#define DGP_QC_PERSTATE 1   /* qc_inv (B, n-1, dof, dof): Q^-1 built as in gp_factor.py:65-73                       */
+#define DGP_QC_QFULL    2   /* qc_inv (B, n-1, d, d) is Q^-1 itself ('q_full', plan_layer.py:90)                    */
+
+/* Constructor arguments of PlanLayer / DiffGPMP2Planner that the math depends on
+ * (plan_layer.py:14-81).  All lengths in the reference's units. */
+typedef struct DgpConfig {
+  uint32_t struct_size;      /* = sizeof(DgpConfig), ABI guard                                           */
+  int32_t  num_states;       /* n = planner_params['total_time_step'] + 1          (plan_layer.py:30)    */
+  int32_t  dof;              /* planner_params['dof']: 2 (point robot) or 3 (x,y,theta); d = 2*dof       */
+  int32_t  nlinks;           /* robot_model.nlinks; only 1 is implemented                                */
+  int32_t  io_dtype;         /* DGP_F32 or DGP_F64                                                       */
+  uint32_t flags;            /* DGP_FLAG_*                                                               */
+  double   total_time_sec;   /* planner_params['total_time_sec']; dt = total_time_sec/(n-1) (:31)        */
+  double   x_lims[2];        /* env_params['x_lims']                                                     */
+  double   y_lims[2];        /* env_params['y_lims']                                                     */
+  double   K_s, K_g;         /* gp_params['K_s'], ['K_g']: prior sigma, weight 1/K^2 (:64-65)            */
+  double   reg;              /* optim_params['reg']: delta added to the diagonal (:96,:219)              */
+  double   sphere_radius;    /* robot_model.get_sphere_radii()  (obstacle_cost.py:30)                    */
+  double   Q_c_inv[9];       /* gp_params['Q_c_inv'] (dof x dof, row-major): static GP weight and the    */
+                             /* FIXED weight of err_ext (plan_layer.py:70-73,80)                         */
+  double   cost_sigma;       /* obs_params['cost_sigma']: static / fixed obstacle weight 1/sigma^2 (:74) */
+  double   epsilon_dist;     /* obs_params['epsilon_dist']: static epsilon                               */
+  double   K_d;              /* gp_params['K_d'] (non-holonomic factor sigma)                            */
+  double   K_v, v_x, v_y;    /* gp_params['K_v'], ['v_x'], ['v_y'] (velocity-limit factor)               */
+} DgpConfig;
+
+typedef struct DgpHandle DgpHandle;
+
+/* Signed-distance field argument: sdfb (B,1,H',W') of PlanLayer.forward (only sdfb[:,0] is read,
+ * obstacle_cost.py:35).  batch_stride is in ELEMENTS between consecutive samples' grids; 0 means one
+ * grid shared by the whole batch (an expand()ed tensor). */
+typedef struct DgpSdf {
+  const void* data;
+  int32_t     rows;          /* H' */
+  int32_t     cols;          /* W'; res = (x_lims[1]-x_lims[0])/W'  (obstacle_cost.py:34)     */
+  int64_t     batch_stride;
+} DgpSdf;
+
+/* Per-call covariance inputs = the three trailing arguments of PlanLayer.forward. */
+typedef struct DgpCovs {
+  int32_t     qc_mode;       /* DGP_QC_*                                                                 */
+  const void* qc_inv;        /* see DGP_QC_*; NULL iff DGP_QC_STATIC                                     */
+  const void* obs_w;         /* obscov_inv_trajb (B,n,1,1) or NULL = static 1/cost_sigma^2               */
+  const void* eps;           /* eps_trajb (B,n,1,1) or NULL = static epsilon_dist                        */
+} DgpCovs;
+
+int         dgp_abi_version(void);
+const char* dgp_last_error(void);
+
+/* PlanLayer.__init__ (plan_layer.py:14-81).  Host-only; validates cfg, precomputes constants. */
+int  dgp_create(const DgpConfig* cfg, DgpHandle** out);
+void dgp_destroy(DgpHandle* h);
+
+/* M of plan_layer.py:43-45 (rows of the dense system; the normaliser of err) for this handle. */
+int  dgp_num_factor_rows(const DgpHandle* h);
+
+/* One batched Gauss-Newton step == PlanLayer.forward (plan_layer.py:87-99):
+ * factor evaluation (gp_factor.py:100-110, prior_factor.py:15-18, obstacle_factor.py:35-40 ->
+ * obstacle_cost.py:29-38 -> sdf_utils.py:38-107, custom_factors/), assembly of the block-tridiagonal
+ * A^T K A + delta I and A^T K b (plan_layer.py:152-220) and the solve (plan_layer.py:226-228), plus
+ * err (error_batch, :273-308) and err_ext (error_ext_batch, :310-345) at the INPUT trajectory.
+ *   th (B,n,d)  start,goal (B,1,d)  ->  dtheta (B,n,d)  err (B,1,1)  err_ext (B,1,1)
+ *   info (B) int32, optional: 0 ok, 1 = a non-positive pivot was met (system not SPD; the reference
+ *   raises from torch.cholesky there).  err / err_ext may be NULL. */
+int dgp_gn_step(const DgpHandle* h, int32_t batch,
+                const void* th, const void* start, const void* goal,
+                const DgpSdf* sdf, const DgpCovs* covs,
+                void* dtheta, void* err, void* err_ext, int32_t* info, void* stream);
+
+/* Fused Gauss-Newton loop == DiffGPMP2Planner.forward's inner `while True` (diff_gpmp2_planner.py:122-156)
+ * for every trajectory of the batch at once, the trajectory staying in registers across iterations.
+ * Per trajectory: repeat {dtheta,err,err_ext = step(th); th += dtheta; j++} until
+ * ||dtheta||_F < tol_delta or j >= max_iters (utils/planner_utils.py:3-16; the last dtheta IS applied).
+ *   th_out (B,n,d); iters (B) int32; err_hist, errext_hist (B,max_iters), entries at or past iters[b] untouched;
+ *   err_final (B): error_batch at th_out (diff_gpmp2_planner.py:145,162).  Optional outputs may be NULL. */
+int dgp_gn_solve(const DgpHandle* h, int32_t batch,
+                 const void* th_init, const void* start, const void* goal,
+                 const DgpSdf* sdf, const DgpCovs* covs,
+                 int32_t max_iters, double tol_delta,
+                 void* th_out, int32_t* iters, void* err_hist, void* errext_hist, void* err_final,
+                 int32_t* info, void* stream);
+
+/* Factor evaluation only == PlanLayer.error_batch / error_ext_batch (plan_layer.py:273-345) and the
+ * unweighted errors of DiffGPMP2Planner.unweighted_errors_batch (diff_gpmp2_planner.py:229-237 ->
+ * plan_layer.py:374-388).  Any output may be NULL.  err, err_ext, unw_sg, unw_gp, unw_obs: (B). */
+int dgp_eval_errors(const DgpHandle* h, int32_t batch,
+                    const void* th, const void* start, const void* goal,
+                    const DgpSdf* sdf, const DgpCovs* covs,
+                    void* err, void* err_ext, void* unw_sg, void* unw_gp, void* unw_obs, void* stream);
+
+/* Backward of dgp_gn_step (the reference gets it from torch autograd over plan_layer.py:152-234;
+ * consumers: learning/train_planner.py:366-374, examples/diff_gpmp2_2d_example.py:77).
+ * Given g_dtheta = dL/d(dtheta) (B,n,d) and g_err_ext = dL/d(err_ext) (B) (either may be NULL = 0),
+ * recomputes the step and writes dL/d{th,start,goal} (same shapes), dL/d(qc_inv) (shape of the
+ * qc_mode), dL/d(obs_w), dL/d(eps) (B,n), and ACCUMULATES dL/d(sdf) into g_sdf with atomics
+ * (g_sdf has the layout described by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped. */
+int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
+                         const void* th, const void* start, const void* goal,
+                         const DgpSdf* sdf, const DgpCovs* covs,
+                         const void* g_dtheta, const void* g_err_ext,
+                         void* g_th, void* g_start, void* g_goal,
+                         void* g_sdf, int64_t g_sdf_batch_stride,
+                         void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DGPMP2_HIP_H */

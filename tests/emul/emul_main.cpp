@@ -1,0 +1,148 @@
+// Wavefront emulator (TEST INFRASTRUCTURE ONLY -- never part of the product path).
+// Compiles the very same per-lane program the HIP kernel runs (dgpmp2_amd/csrc/gn_lane.h) for the host and
+// executes one wavefront as 64 lock-stepped threads; a cross-lane fetch is "publish, barrier, read, barrier".
+// Lets the CPU-only test-suite check the kernel logic (factor evaluation, assembly, block PCR, modes)
+// against the oracle before any GPU time is spent.  Built by tests/test_lane_emulator.py with g++.
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <thread>
+#include <vector>
+
+#define DGP_HD inline
+#include "../../dgpmp2_amd/csrc/dgp_host.h"
+
+namespace {
+
+struct WaveShared {
+  pthread_barrier_t bar;
+  double slot[64];
+  int islot[64];
+};
+
+pthread_mutex_t g_atomic_mutex = PTHREAD_MUTEX_INITIALIZER;
+
+struct HostCtx {
+  WaveShared* ws;
+  int lane_, wave_;
+  int lane() const { return lane_; }
+  int wave() const { return wave_; }
+  double fetch(double v, int src) {
+    ws->slot[lane_] = v;
+    pthread_barrier_wait(&ws->bar);
+    double r = ws->slot[src & 63];
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
+  int fetch_i(int v, int src) {
+    ws->islot[lane_] = v;
+    pthread_barrier_wait(&ws->bar);
+    int r = ws->islot[src & 63];
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
+  bool any(bool pred) {
+    ws->islot[lane_] = pred ? 1 : 0;
+    pthread_barrier_wait(&ws->bar);
+    int r = 0;
+    for (int k = 0; k < 64; ++k) r |= ws->islot[k];
+    pthread_barrier_wait(&ws->bar);
+    return r != 0;
+  }
+  template <typename T>
+  void atomic_add(T* p, T v) {
+    pthread_mutex_lock(&g_atomic_mutex); *p += v; pthread_mutex_unlock(&g_atomic_mutex);
+  }
+};
+
+template <int DOF, int LPT, typename IO>
+void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int wave) {
+  WaveShared ws;
+  pthread_barrier_init(&ws.bar, nullptr, 64);
+  std::vector<std::thread> th;
+  for (int l = 0; l < 64; ++l) {
+    th.emplace_back([&, l]() {
+      HostCtx cx{&ws, l, wave};
+      if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_STEP>(p, cx);
+      else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_SOLVE>(p, cx);
+      else if (mode == dgp::MODE_EVAL) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_EVAL>(p, cx);
+      else dgp::gn_backward_lane_program<DOF, LPT, IO>(p, *g, cx);
+    });
+  }
+  for (auto& t : th) t.join();
+  pthread_barrier_destroy(&ws.bar);
+}
+
+template <int DOF, typename IO>
+void run_all(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int lpt) {
+  const int tpw = 64 / lpt;
+  const int waves = (p.B + tpw - 1) / tpw;
+  for (int w = 0; w < waves; ++w) {
+    if (lpt == 16) run_wave<DOF, 16, IO>(p, g, mode, w);
+    else if (lpt == 32) run_wave<DOF, 32, IO>(p, g, mode, w);
+    else run_wave<DOF, 64, IO>(p, g, mode, w);
+  }
+}
+
+void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
+  const bool f64 = h->cfg.io_dtype == DGP_F64;
+  if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, h->lpt); else run_all<2, float>(p, g, mode, h->lpt); }
+  else { if (f64) run_all<3, double>(p, g, mode, h->lpt); else run_all<3, float>(p, g, mode, h->lpt); }
+}
+
+}  // namespace
+
+// Same entry points as include/dgpmp2_hip.h with the prefix emul_, on HOST pointers (stream ignored).
+extern "C" {
+
+int emul_abi_version(void) { return DGP_ABI_VERSION; }
+const char* emul_last_error(void) { return dgp_host::err_buf(); }
+int emul_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create(cfg, out); }
+void emul_destroy(DgpHandle* h) { delete h; }
+int emul_num_factor_rows(const DgpHandle* h) { return h ? h->M : DGP_EINVAL; }
+
+int emul_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                 const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void*) {
+  dgp::GnParams p;
+  int rc = dgp_host::fill_step(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, p);
+  if (rc != DGP_OK) return rc;
+  run(h, p, nullptr, dgp::MODE_STEP);
+  return DGP_OK;
+}
+
+int emul_gn_solve(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf,
+                  const DgpCovs* covs, int32_t max_iters, double tol_delta, void* th_out, int32_t* iters, void* err_hist,
+                  void* errext_hist, void* err_final, int32_t* info, void*) {
+  dgp::GnParams p;
+  int rc = dgp_host::fill_solve(h, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist,
+                                errext_hist, err_final, info, p);
+  if (rc != DGP_OK) return rc;
+  run(h, p, nullptr, dgp::MODE_SOLVE);
+  return DGP_OK;
+}
+
+int emul_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                     const DgpCovs* covs, void* err, void* err_ext, void* unw_sg, void* unw_gp, void* unw_obs, void*) {
+  dgp::GnParams p;
+  int rc = dgp_host::fill_eval(h, batch, th, start, goal, sdf, covs, err, err_ext, unw_sg, unw_gp, unw_obs, p);
+  if (rc != DGP_OK) return rc;
+  run(h, p, nullptr, dgp::MODE_EVAL);
+  return DGP_OK;
+}
+
+int emul_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                          const DgpCovs* covs, const void* g_dtheta, const void* g_err_ext, void* g_th, void* g_start, void* g_goal,
+                          void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w, void* g_eps, void*) {
+  dgp::GnParams p;
+  dgp::GnGradParams g;
+  int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
+                                   g_sdf_batch_stride, g_qc_inv, g_obs_w, g_eps, p, g);
+  if (rc != DGP_OK) return rc;
+  if (!dgp::kBackwardImplemented) return dgp_host::fail(DGP_EUNSUPPORTED, "backward is not implemented yet");
+  run(h, p, &g, 3);
+  return DGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""Test harness: drives the C-ABI (include/dgpmp2_hip.h) from numpy inputs, through either
+  - the HIP library on cuda:0  (backend 'hip', used by the -m gpu parity tests), or
+  - tests/emul's CPU wavefront emulator of the same per-lane program (backend 'emul', CPU-only tests).
+Both go through dgpmp2_amd._capi, i.e. the same marshalling the product uses.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+from dgpmp2_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL_DIR = os.path.join(ROOT, 'tests', 'emul')
+EMUL_LIB = os.path.join(EMUL_DIR, 'libgn_emul.so')
+
+
+def build_emulator(force=False):
+  src = os.path.join(EMUL_DIR, 'emul_main.cpp')
+  deps = [src] + [os.path.join(ROOT, 'dgpmp2_amd', 'csrc', f) for f in ('gn_lane.h', 'gn_backward.h', 'dgp_host.h')] + \
+         [os.path.join(ROOT, 'include', 'dgpmp2_hip.h')]
+  if force or not os.path.exists(EMUL_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMUL_LIB) for d in deps):
+    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-Wno-unknown-pragmas', '-fPIC', '-shared',
+                           '-pthread', src, '-o', EMUL_LIB])
+  return EMUL_LIB
+
+
+_emul_api = None
+
+
+def emul_api():
+  global _emul_api
+  if _emul_api is None:
+    _emul_api = _capi.CApi(build_emulator(), 'emul_')
+  return _emul_api
+
+
+def config_from_oracle(p, io):
+  """oracle.OracleParams -> DgpConfig."""
+  return _capi.make_config(num_states=p.n, dof=p.dof, io_dtype=_capi.DGP_F64 if io == 'f64' else _capi.DGP_F32,
+                           total_time_sec=p.total_time_sec, x_lims=p.x_lims, y_lims=p.y_lims, K_s=p.K_s, K_g=p.K_g, reg=p.reg,
+                           sphere_radius=p.radius, Q_c_inv=p.Q_c_inv, cost_sigma=p.cost_sigma, epsilon_dist=p.epsilon_dist,
+                           non_holonomic=p.non_holonomic, use_vel_limits=p.use_vel_limits, K_d=p.K_d, K_v=p.K_v, v_x=p.v_x, v_y=p.v_y,
+                           nlinks=p.nlinks)
+
+
+class Backend(object):
+  """numpy in / numpy out driver.  kind: 'emul' (host memory) or 'hip' (cuda:0 through torch)."""
+
+  def __init__(self, kind):
+    self.kind = kind
+    if kind == 'emul':
+      self.api = emul_api()
+    else:
+      import torch
+      self.torch = torch
+      self.api = _capi.get_api()
+    self._keep = []
+
+  # -- memory ------------------------------------------------------------------------------------
+  def _np_dtype(self, io): return np.float64 if io == 'f64' else np.float32
+
+  def to_dev(self, a, io=None, dtype=None):
+    if a is None: return None, None
+    dt = dtype if dtype is not None else self._np_dtype(io)
+    a = np.ascontiguousarray(np.asarray(a), dtype=dt)
+    if self.kind == 'emul':
+      self._keep.append(a)
+      return a, a.ctypes.data
+    t = self.torch.from_numpy(a).to('cuda:0')
+    self._keep.append(t)
+    return t, t.data_ptr()
+
+  def empty(self, shape, io=None, dtype=None, fill=None):
+    dt = dtype if dtype is not None else self._np_dtype(io)
+    a = np.full(shape, np.nan if fill is None and dt != np.int32 else (fill if fill is not None else -1), dtype=dt)
+    return self.to_dev(a, dtype=dt)
+
+  def to_np(self, obj):
+    if obj is None: return None
+    if self.kind == 'emul': return np.array(obj, dtype=np.float64 if obj.dtype != np.int32 else np.int32)
+    self.torch.cuda.synchronize()
+    a = obj.cpu().numpy()
+    return a.astype(np.float64) if a.dtype != np.int32 else a
+
+  def stream(self):
+    if self.kind == 'emul': return None
+    return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+  # -- argument marshalling -------------------------------------------------------------------------
+  def _common(self, p, io, th, start, goal, sdf, qc, ow, eps, q_full):
+    self._keep = []
+    B = th.shape[0]
+    solver = _capi.Solver(config_from_oracle(p, io), api=self.api)
+    _, th_p = self.to_dev(th, io)
+    _, st_p = self.to_dev(start, io)
+    _, go_p = self.to_dev(goal, io)
+    sdf = np.asarray(sdf)
+    assert sdf.ndim == 4 and sdf.shape[1] == 1
+    shared = sdf.shape[0] == 1 and B >= 1
+    _, sdf_p = self.to_dev(sdf, io)
+    H, W = sdf.shape[-2], sdf.shape[-1]
+    sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
+    mode = _capi.DGP_QC_STATIC if qc is None else (_capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE)
+    _, qc_p = self.to_dev(qc, io)
+    _, ow_p = self.to_dev(ow, io)
+    _, eps_p = self.to_dev(eps, io)
+    covs = solver.covs_arg(mode, qc_p, ow_p, eps_p)
+    return solver, B, th_p, st_p, go_p, sdf_arg, covs
+
+  # -- entry points ------------------------------------------------------------------------------------
+  def step(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+    """-> dtheta (B,n,d), err (B,), err_ext (B,), info (B,)"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    dth, dth_p = self.empty(th.shape, io)
+    err, err_p = self.empty((B,), io)
+    eex, eex_p = self.empty((B,), io)
+    info, info_p = self.empty((B,), dtype=np.int32)
+    solver.gn_step(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, err_p, eex_p, info_p, self.stream())
+    return self.to_np(dth), self.to_np(err), self.to_np(eex), self.to_np(info)
+
+  def solve(self, p, th, start, goal, sdf, max_iters, tol_delta, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+    """-> th_out, iters, err_hist (B,max_iters; NaN where untouched), errext_hist, err_final, info"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    tho, tho_p = self.empty(th.shape, io)
+    its, its_p = self.empty((B,), dtype=np.int32)
+    eh, eh_p = self.empty((B, max_iters), io)
+    eeh, eeh_p = self.empty((B, max_iters), io)
+    ef, ef_p = self.empty((B,), io)
+    info, info_p = self.empty((B,), dtype=np.int32)
+    solver.gn_solve(B, th_p, st_p, go_p, sdf_arg, covs, max_iters, tol_delta, tho_p, its_p, eh_p, eeh_p, ef_p, info_p, self.stream())
+    return self.to_np(tho), self.to_np(its), self.to_np(eh), self.to_np(eeh), self.to_np(ef), self.to_np(info)
+
+  def eval_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+    """-> err, err_ext, unw_sg, unw_gp, unw_obs  (each (B,))"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    outs = [self.empty((B,), io) for _ in range(5)]
+    solver.eval_errors(B, th_p, st_p, go_p, sdf_arg, covs, *[o[1] for o in outs], stream=self.stream())
+    return tuple(self.to_np(o[0]) for o in outs)
+
+  def backward(self, p, th, start, goal, sdf, g_dtheta, g_err_ext, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+    """-> dict of gradients: th, start, goal, sdf, qc, ow, eps (numpy fp64)"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    n = th.shape[1]
+    _, gd_p = self.to_dev(g_dtheta, io)
+    _, ge_p = self.to_dev(g_err_ext, io)
+    gth, gth_p = self.empty(th.shape, io)
+    gst, gst_p = self.empty(np.asarray(start).shape, io)
+    ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
+    sdf = np.asarray(sdf)
+    gsdf, gsdf_p = self.empty(sdf.shape, io, fill=0.0)
+    gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
+    gow, gow_p = self.empty((B, n), io)
+    gep, gep_p = self.empty((B, n), io)
+    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    solver.gn_step_backward(B, th_p, st_p, go_p, sdf_arg, covs, gd_p, ge_p, gth_p, gst_p, ggo_p, gsdf_p, stride, gqc_p, gow_p,
+                            gep_p, self.stream())
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc),
+                ow=self.to_np(gow), eps=self.to_np(gep))

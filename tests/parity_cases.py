@@ -1,0 +1,219 @@
+"""Parity cases shared by the CPU wavefront-emulator tests (tests/test_lane_emulator.py, -m "not gpu")
+and the GPU tests proper (tests/test_hip_parity.py, -m gpu).  Each case feeds the same seeded inputs to a
+harness.Backend and to the numpy oracle / golden fixtures and compares.
+
+Tolerances (max-norm relative error, conftest.rel_err):
+  fp64 I/O : 1e-9   (fp64 block-PCR vs fp64 Cholesky + explicit inverses; cond(Lambda) ~ 1e4..2e5)
+  fp32 I/O : 1e-5   (BASELINE.json north_star: "within 1e-5 relative fp32"); inputs are rounded to fp32
+                    first and the oracle is fed exactly those rounded values.
+"""
+import numpy as np
+from conftest import rel_err
+from oracle import gpmp2_oracle as O
+
+TOL = {'f64': 1e-9, 'f32': 1e-5}
+TOL_ERR = {'f64': 1e-11, 'f32': 2e-6}
+
+
+def rnd(a, io):
+  """Round inputs to the I/O dtype (what the kernel will actually read), back to fp64 for the oracle."""
+  return np.asarray(a, dtype=np.float32).astype(np.float64) if io == 'f32' else np.asarray(a, dtype=np.float64)
+
+
+def P2d(n, **kw):
+  return O.OracleParams(dof=2, total_time_step=n - 1, **kw)
+
+
+def check_step(be, p, th, start, goal, sdf, io, qc=None, ow=None, eps=None, q_full=False, ref=None, tag=''):
+  th, start, goal, sdf = rnd(th, io), rnd(start, io), rnd(goal, io), rnd(sdf, io)
+  qc_, ow_, eps_ = [None if c is None else rnd(c, io) for c in (qc, ow, eps)]
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc_, ow=None if ow_ is None else ow_.reshape(th.shape[0], -1),
+                                eps=None if eps_ is None else eps_.reshape(th.shape[0], -1), q_full=q_full, io=io)
+  B = th.shape[0]
+  sdf_full = np.broadcast_to(sdf, (B,) + sdf.shape[1:])
+  sq, so, se = p.static_covs(B)
+  o_qc = sq if qc_ is None else qc_
+  o_ow = so if ow_ is None else ow_.reshape(so.shape)
+  o_eps = se if eps_ is None else eps_.reshape(se.shape)
+  r_dth, r_err, r_eex = O.plan_layer_forward(th, start, goal, sdf_full, o_qc, o_ow, o_eps, p, q_full=q_full)
+  assert np.all(info == 0), tag
+  assert rel_err(dth, r_dth) < TOL[io], (tag, rel_err(dth, r_dth))
+  assert rel_err(err, r_err.reshape(-1)) < TOL_ERR[io], (tag, rel_err(err, r_err.reshape(-1)))
+  assert rel_err(eex, r_eex.reshape(-1)) < TOL_ERR[io], (tag, rel_err(eex, r_eex.reshape(-1)))
+  if ref is not None and io == 'f64':      # golden straight from the reference
+    g_dth, g_err, g_eex = ref
+    assert rel_err(dth, g_dth) < TOL[io], (tag, 'golden', rel_err(dth, g_dth))
+    if g_err is not None: assert rel_err(err, np.reshape(g_err, -1)) < TOL_ERR[io], (tag, 'golden err')
+    if g_eex is not None: assert rel_err(eex, np.reshape(g_eex, -1)) < TOL_ERR[io], (tag, 'golden err_ext')
+  return dth, err, eex
+
+
+# ---------------------------------------------------------------------------------------------------
+def case_c2mini_static(be, golden, io, steps=(0, 4, 9), nb=8):
+  """C2-shaped mini batch (n=64 -> one trajectory per wavefront), shared 256x256 SDF, static covariances,
+  teacher-forced against the reference's own trajectory history."""
+  g = golden('g3_c2mini')
+  p = P2d(64)
+  G = int(g['G'])
+  sdf = O.circles_sdf(G, g['circles'])[None, None]
+  for k in steps:
+    check_step(be, p, g['th_hist'][k][:nb], g['start'][:nb], g['goal'][:nb], sdf, io,
+               ref=(g['dth_hist'][k][:nb], g['err_hist'][k][:nb], g['errext_hist'][k][:nb]), tag='c2mini step %d' % k)
+
+
+def case_c2mini_covs(be, golden, io, nb=8):
+  """per-state SPD Q_c^-1, obstacle weights and epsilons (the learned-mode tensor shapes), and the same
+  system passed as full Q^-1 ('q_full')."""
+  g = golden('g3_c2mini')
+  p = P2d(64)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  ref = (g['cov_dth'][:nb], g['cov_err'][:nb], g['cov_errext'][:nb])
+  d1, e1, x1 = check_step(be, p, g['cov_th'][:nb], g['start'][:nb], g['goal'][:nb], sdf, io, qc=g['cov_qc'][:nb],
+                          ow=g['cov_ow'][:nb], eps=g['cov_eps'][:nb], ref=ref, tag='covs per-state')
+  if io == 'f64':
+    Qf = O.calc_Q_inv_batch(g['cov_qc'][:nb], p.dt)
+    d2, e2, x2 = check_step(be, p, g['cov_th'][:nb], g['start'][:nb], g['goal'][:nb], sdf, io, qc=Qf, ow=g['cov_ow'][:nb],
+                            eps=g['cov_eps'][:nb], q_full=True, ref=ref, tag='covs q_full')
+    assert rel_err(d2, d1) < 1e-12
+
+
+def case_c2mini_per_sample_sdf(be, golden, io, nb=8):
+  g = golden('g3_c2mini')
+  p = P2d(64)
+  Gp = int(g['ps_G'])
+  sdf_ps = np.stack([O.circles_sdf(Gp, g['ps_circles'][b]) for b in range(nb)], 0)[:, None]
+  check_step(be, p, g['th_hist'][0][:nb], g['start'][:nb], g['goal'][:nb], sdf_ps, io,
+             ref=(g['ps_dth'][:nb], g['ps_err'][:nb], g['ps_errext'][:nb]), tag='per-sample sdf')
+
+
+def case_c1(be, golden, io, steps=(0, 3, 9)):
+  """BASELINE config 1 plumbing: real map 5.png (202x202 SDF incl. 1px pad), n=32 (two trajectories per wave)."""
+  g = golden('g3_c1')
+  p = P2d(32)
+  sdf = g['sdf'][None, None]
+  for k in steps:
+    check_step(be, p, g['th_hist'][k], g['start'], g['goal'], sdf, io,
+               ref=(g['dth_hist'][k], g['err_hist'][k], g['errext_hist'][k]), tag='c1 step %d' % k)
+  if io == 'f64':
+    th0 = O.straight_line_trajb(g['start'][:, :, :2], g['goal'][:, :, :2], 10.0, 32, 2)     # n = 33 -> 64 lanes, 31 idle
+    check_step(be, O.OracleParams(dof=2, total_time_step=32), th0, g['start'], g['goal'], sdf, io,
+               ref=(g['n33_dth0'], g['n33_err0'], g['n33_errext0']), tag='c1 n=33')
+
+
+def case_small_ragged(be, golden, io):
+  """n = 4 and 16 (16 lanes per trajectory, 4 trajectories per wave) with B = 3 (ragged last wave),
+  random per-state covariances; fixtures g2_system_*."""
+  for n in (4, 16):
+    g = golden('g2_system_n%d' % n)
+    p = P2d(n)
+    sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+    check_step(be, p, g['th'], g['start'], g['goal'], sdf, io, qc=g['qc'], ow=g['ow'], eps=g['eps'], tag='ragged n=%d' % n)
+  # B = 5 with n = 20 (32 lanes per trajectory, odd batch)
+  rs = np.random.RandomState(5)
+  n, B = 20, 5
+  p = P2d(n)
+  start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + rs.randn(B, n, 4) * 0.2
+  sdf = O.circles_sdf(80, O.C2_CIRCLES)[None, None]
+  check_step(be, p, th, start, goal, sdf, io, tag='ragged n=20 B=5')
+
+
+def case_edges(be, golden, io):
+  """Points outside the grid / in the last row-col cell (dist = 0, J = 0 exactly => cost eps+r with
+  zero Jacobian), a non-square SDF, and a hinge tie dist == eps + r (Q5)."""
+  g = golden('g1_factors_2d')
+  n, B = 16, 4
+  p = P2d(n)
+  rs = np.random.RandomState(3)
+  start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  check_step(be, p, g['th_o'], start, goal, g['sdf'], io, eps=g['eps'], tag='edges non-square')
+  check_step(be, p, g['th'], start, goal, g['sdf_tie'], io, tag='hinge tie')
+
+
+def case_c3_vel(be, golden, io):
+  g = golden('g3_c3_vel')
+  B, n = g['th'].shape[:2]
+  p = O.OracleParams(dof=2, total_time_step=n - 1, use_vel_limits=True)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  check_step(be, p, g['th'], g['start'], g['goal'], sdf, io, ref=(g['dth'], g['err'], None), tag='c3 vel limits')
+
+
+def case_c4_xyh(be, golden, io):
+  g = golden('g3_c4_xyh')
+  B, n = g['th'].shape[:2]
+  p = O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, epsilon_dist=0.2, reg=0.0)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  check_step(be, p, g['th'], g['start'], g['goal'], sdf, io, ref=(g['dth'], g['err'], None), tag='c4 xyh')
+
+
+def case_eval_errors(be, golden, io):
+  g = golden('g3_c1')
+  p = P2d(32)
+  th = rnd(g['th_hist'][3], io); start = rnd(g['start'], io); goal = rnd(g['goal'], io); sdf = rnd(g['sdf'][None, None], io)
+  err, eex, usg, ugp, uobs = be.eval_errors(p, th, start, goal, sdf, io=io)
+  qc, ow, eps = p.static_covs(1)
+  Q = O.calc_Q_inv_batch(qc, p.dt)
+  r_err = O.error_batch(th, start, goal, sdf, Q, ow, eps, p)
+  r_sg, r_gp, r_obs = O.unweighted_errors_batch(th, start, goal, sdf, eps, p)
+  t = TOL_ERR[io]
+  assert rel_err(err, r_err.reshape(-1)) < t and rel_err(eex, r_err.reshape(-1)) < t
+  assert rel_err(usg, r_sg.reshape(-1)) < max(t, 1e-7 if io == 'f32' else 0) or abs(float(usg[0]) - float(r_sg.item())) < 1e-12
+  assert rel_err(ugp, r_gp.reshape(-1)) < t and rel_err(uobs, r_obs.reshape(-1)) < t
+  if io == 'f64':
+    assert rel_err(err, g['err_hist'][3].reshape(-1)) < t
+    assert rel_err(ugp, g['unw_gp'].reshape(-1)) < t and rel_err(uobs, g['unw_obs'].reshape(-1)) < t
+
+
+def case_solve(be, golden, io):
+  """Fused GN loop vs DiffGPMP2Planner.forward: C1 to max_iters, and an obstacle-free batch that exits early
+  by tol_delta at different iteration counts per trajectory."""
+  g = golden('g4_forward'); c1 = golden('g3_c1')
+  p = P2d(32)
+  th0 = O.straight_line_trajb(c1['start'][:, :, :2], c1['goal'][:, :, :2], 10.0, 31, 2)
+  mi = int(g['c1_max_iters'])
+  th0r, st, go, sdf = rnd(th0, io), rnd(c1['start'], io), rnd(c1['goal'], io), rnd(c1['sdf'][None, None], io)
+  tho, its, eh, eeh, ef, info = be.solve(p, th0r, st, go, sdf, mi, float(g['c1_tol_delta']), io=io)
+  assert list(its) == list(g['c1_iters']) and np.all(info == 0)
+  if io == 'f64':
+    assert rel_err(tho, g['c1_th_final']) < 1e-7
+    assert rel_err(eh[0], g['c1_err_iter'][0]) < 1e-8 and rel_err(eeh[0], g['c1_errext_iter'][0]) < 1e-8
+    assert rel_err(ef, g['c1_err_final']) < 1e-8
+  else:     # 12 un-forced iterations in fp32 I/O: compare with the oracle run on the rounded inputs, loosely
+    r_th, _, r_ef, r_eh, _, r_it = O.planner_forward(th0r, st, go, sdf, p, mi, float(g['c1_tol_delta']))
+    assert rel_err(tho, r_th) < 1e-4 and rel_err(eh[0], r_eh[0]) < 1e-4
+  # early exit
+  p = P2d(16)
+  sdf = np.full((1, 1, 32, 32), 3.0)
+  mi = int(g['free_max_iters'])
+  tho, its, eh, eeh, ef, info = be.solve(p, rnd(g['free_th0'], io), rnd(g['free_start'], io), rnd(g['free_goal'], io), sdf, mi,
+                                         float(g['free_tol_delta']), io=io)
+  if io == 'f64':
+    assert list(its) == list(g['free_iters'])
+    assert rel_err(tho, g['free_th_final']) < 1e-8
+    for b in range(3):
+      k = int(its[b])
+      assert rel_err(eh[b, :k], g['free_err_iter'][b][:k]) < 1e-8
+      assert np.all(np.isnan(eh[b, k:]))                # entries past iters[b] untouched
+    assert rel_err(ef, g['free_err_final']) < 1e-8
+  else:
+    assert np.all(np.abs(its - np.asarray(g['free_iters'])) <= 1)
+
+
+def case_not_spd(be, golden, io):
+  """A strongly negative `reg` makes Lambda indefinite: the reference raises from torch.cholesky; the C-ABI
+  reports it per trajectory through info."""
+  n, B = 16, 2
+  p = P2d(n, reg=-1.0e7)
+  rs = np.random.RandomState(1)
+  start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  sdf = np.full((1, 1, 16, 16), 3.0)
+  _, _, _, info = be.step(p, th, start, goal, sdf, io=io)
+  assert np.all(info == 1)
+
+
+ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, case_c1, case_small_ragged, case_edges,
+             case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd]

@@ -1,0 +1,76 @@
+"""CPU-only: the C-ABI shared library loads and exports every symbol include/dgpmp2_hip.h declares; host-side
+argument validation works without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import pytest
+from dgpmp2_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def api():
+  if not os.path.exists(_capi.LIB_PATH):
+    import __graft_entry__
+    __graft_entry__.build()
+  return _capi.get_api()
+
+
+def test_exports_every_declared_symbol(api):
+  hdr = open(os.path.join(ROOT, 'include', 'dgpmp2_hip.h')).read()
+  hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+  declared = set(re.findall(r'\b(dgp_[a-z_]+)\s*\(', hdr))
+  assert declared == set('dgp_' + s for s in _capi.CApi.SYMBOLS)
+  for name in declared:
+    assert hasattr(api.lib, name), name
+  assert api.abi_version() == _capi.DGP_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+  # sizes implied by the header on LP64: see DgpConfig/DgpSdf/DgpCovs in include/dgpmp2_hip.h
+  assert C.sizeof(_capi.DgpConfig) == 6 * 4 + 8 * (1 + 2 + 2 + 2 + 1 + 1 + 9 + 1 + 1 + 1 + 3)
+  assert C.sizeof(_capi.DgpSdf) == 24 and C.sizeof(_capi.DgpCovs) == 32
+
+
+def _cfg(**kw):
+  base = dict(num_states=64, dof=2, io_dtype=_capi.DGP_F32, total_time_sec=10.0, x_lims=(-5, 5), y_lims=(-5, 5), K_s=0.01,
+              K_g=0.01, reg=0.1, sphere_radius=0.4, Q_c_inv=[[1, 0], [0, 1]], cost_sigma=0.01, epsilon_dist=0.4)
+  base.update(kw)
+  return _capi.make_config(**base)
+
+
+def test_create_destroy_and_M(api):
+  s = _capi.Solver(_cfg())
+  assert s.M == 4 * (63 + 2) + 64                          # plan_layer.py:43
+  s2 = _capi.Solver(_cfg(use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0))
+  assert s2.M == 4 * 65 + 64 + 2 * 64                       # plan_layer.py:45
+  s3 = _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], non_holonomic=True, K_d=0.01))
+  assert s3.M == 6 * 65 + 64 + 64                           # plan_layer.py:44
+
+
+@pytest.mark.parametrize('kw,code', [
+    (dict(dof=4, Q_c_inv=[[1, 0, 0, 0]] * 4), _capi.DGP_EUNSUPPORTED),
+    (dict(nlinks=2), _capi.DGP_EUNSUPPORTED),
+    (dict(num_states=1), _capi.DGP_EINVAL),
+    (dict(non_holonomic=True, K_d=0.01), _capi.DGP_EINVAL),       # needs dof == 3
+    (dict(K_s=0.0), _capi.DGP_EINVAL),
+    (dict(x_lims=(5, -5)), _capi.DGP_EINVAL),
+])
+def test_create_rejects_bad_config(api, kw, code):
+  with pytest.raises(_capi.DgpError) as e:
+    _capi.Solver(_cfg(**kw))
+  assert e.value.code == code and len(str(e.value)) > 20
+
+
+def test_calls_validate_arguments_without_gpu(api):
+  s = _capi.Solver(_cfg())
+  sdf = s.sdf_arg(None, 256, 256, 0)
+  with pytest.raises(_capi.DgpError) as e:
+    s.gn_step(8, 0x1000, 0x1000, 0x1000, sdf, None, 0x1000)
+  assert e.value.code == _capi.DGP_EINVAL and 'sdf' in str(e.value)
+  sdf = s.sdf_arg(0x1000, 256, 256, 0)
+  with pytest.raises(_capi.DgpError):
+    s.gn_step(0, 0x1000, 0x1000, 0x1000, sdf, None, 0x1000)
+  with pytest.raises(_capi.DgpError):
+    s.gn_step(8, 0x1000, 0x1000, 0x1000, sdf, s.covs_arg(_capi.DGP_QC_PERSTATE, None), 0x1000)

@@ -1,0 +1,72 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (dgpmp2_amd/lib/libdgpmp2_hip.so), against the
+numpy oracle on the same seeded inputs and against the golden fixtures generated from the reference."""
+import numpy as np
+import pytest
+import harness
+import parity_cases as PC
+from conftest import rel_err
+from oracle import gpmp2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def be():
+  import torch
+  assert torch.cuda.is_available(), 'the -m gpu tests need a GPU'
+  return harness.Backend('hip')
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('case', PC.ALL_CASES, ids=lambda c: c.__name__)
+def test_hip_case(be, golden, case, io):
+  case(be, golden, io)
+
+
+def _c2_inputs(B, n, G, seed=0, perturb=0.0):
+  rs = np.random.RandomState(seed)
+  start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  if perturb: th = th + rs.randn(B, n, 4) * perturb
+  sdf = O.circles_sdf(G, O.C2_CIRCLES)[None, None]
+  return th, start, goal, sdf
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+def test_hip_c2_full_size_properties(be, io):
+  """BASELINE config 2 at full size (B=4096, n=64, 256x256 SDF): the dense oracle cannot run 4096 trajectories in
+  seconds, so check (a) a random subset of 64 trajectories against the oracle, (b) batch-independence: the result
+  for a trajectory does not depend on its batch neighbours or position, (c) determinism across launches."""
+  B, n, G = 4096, 64, 256
+  p = PC.P2d(n)
+  th, start, goal, sdf = _c2_inputs(B, n, G, seed=0, perturb=0.05)
+  th, start, goal, sdf = PC.rnd(th, io), PC.rnd(start, io), PC.rnd(goal, io), PC.rnd(sdf, io)
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, io=io)
+  assert np.all(info == 0) and np.all(np.isfinite(dth))
+  idx = np.random.RandomState(1).choice(B, 64, replace=False)
+  qc, ow, eps = p.static_covs(64)
+  r_dth, r_err, r_eex = O.plan_layer_forward(th[idx], start[idx], goal[idx], np.broadcast_to(sdf, (64, 1, G, G)), qc, ow, eps, p)
+  assert rel_err(dth[idx], r_dth) < PC.TOL[io]
+  assert rel_err(err[idx], r_err.reshape(-1)) < PC.TOL_ERR[io] and rel_err(eex[idx], r_eex.reshape(-1)) < PC.TOL_ERR[io]
+  perm = np.random.RandomState(2).permutation(B)
+  dth2, err2, _, _ = be.step(p, th[perm], start[perm], goal[perm], sdf, io=io)
+  assert np.array_equal(dth2, dth[perm]) and np.array_equal(err2, err[perm])
+  dth3, _, _, _ = be.step(p, th, start, goal, sdf, io=io)
+  assert np.array_equal(dth3, dth)
+
+
+def test_hip_c2_ten_iterations_reduce_error(be):
+  """10 GN iterations on the C2 workload (fused loop): error decreases overall and equals 10 chained steps."""
+  B, n, G = 256, 64, 256
+  p = PC.P2d(n)
+  th, start, goal, sdf = _c2_inputs(B, n, G, seed=3)
+  tho, its, eh, eeh, ef, info = be.solve(p, th, start, goal, sdf, 10, 0.0, io='f64')
+  assert np.all(its == 10) and np.all(info == 0)
+  assert np.all(ef <= eh[:, 0] * (1 + 1e-9))
+  cur = th.copy()
+  for k in range(10):
+    dth, err, _, _ = be.step(p, cur, start, goal, sdf, io='f64')
+    assert rel_err(err, eh[:, k]) < 1e-12
+    cur = cur + dth
+  assert rel_err(cur, tho) < 1e-12
