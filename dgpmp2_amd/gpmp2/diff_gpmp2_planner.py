@@ -1,0 +1,254 @@
+"""DiffGPMP2Planner -- host-side mirror of the reference's diff_gpmp2.gpmp2.diff_gpmp2_planner.DiffGPMP2Planner
+(diff_gpmp2_planner.py:15-299): same constructor dicts, same step() / forward() / error_* signatures and return tuples,
+so the reference's outer loops (learning/train_planner.py:297-403, datasets/generate_optimal_paths_gpmp2.py:181-184,
+examples/diff_gpmp2_*) run unchanged on top of the HIP solver.
+
+  step()    -> one launch of the fused GN kernel (PlanLayer.forward), differentiable.
+  forward() -> the reference loops over samples and iterates each to convergence in Python
+               (diff_gpmp2_planner.py:104-156); here the whole batch runs in ONE launch of the fused multi-iteration
+               kernel (dgp_gn_solve), every trajectory with its own convergence test, when no autograd graph is needed;
+               with requires_grad inputs it falls back to chained differentiable step() calls (the reference keeps the
+               graph across iterations, examples/diff_gpmp2_2d_example.py:77), still batched.
+
+The learned-covariance modules (LearnModuleConv / LearnModuleFCN, stock torch.nn in the reference) are out of this
+build's scope: pass your own modules as `learn_module_conv` / `learn_module_fcn`; get_covariances() (the plumbing between
+their output vector and the solver's covariance inputs, diff_gpmp2_planner.py:247-290) is provided.
+"""
+import time
+
+import torch
+import torch.nn as nn
+
+from .plan_layer import PlanLayer, _f, _stream
+from ..utils.planner_utils import check_convergence
+
+
+class DiffGPMP2Planner(nn.Module):
+  def __init__(self, gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params=None, batch_size=1,
+               use_cuda=False, learn_module_conv=None, learn_module_fcn=None):
+    super(DiffGPMP2Planner, self).__init__()
+    self.use_cuda = torch.cuda.is_available() if use_cuda else False
+    if not torch.cuda.is_available():
+      raise RuntimeError('dgpmp2_amd.DiffGPMP2Planner needs a ROCm GPU: the solver has no CPU path')
+    self.device = torch.device('cuda')
+    self.dof = planner_params['dof']
+    self.state_dim = planner_params['state_dim']
+    self.total_time_sec = planner_params['total_time_sec']
+    self.total_time_step = planner_params['total_time_step']
+    self.num_traj_states = self.total_time_step + 1
+    self.num_gp_factors = self.num_traj_states - 1
+    self.num_obs_factors = self.num_traj_states
+    self.optim_params, self.gp_params, self.obs_params = optim_params, gp_params, obs_params
+    self.robot_model, self.env_params, self.learn_params = robot_model, env_params, learn_params
+    self.model_type = 'feed_forward'
+    self.non_holonomic = planner_params['non_holonomic'] if 'non_holonomic' in planner_params else False
+    self.use_vel_limits = planner_params['use_vel_limits'] if 'use_vel_limits' in planner_params else False
+    self.batch_size = batch_size
+    nl = robot_model.nlinks
+    dd = torch.get_default_dtype()
+    mk = lambda shape, v: (torch.zeros(*shape, dtype=dd, device=self.device) + torch.as_tensor(v, dtype=dd, device=self.device))
+    self.fixed_conv = False
+    self.learn_eps = False
+    self.dynamics_mode = None
+    if learn_params is None:
+      # static covariances (diff_gpmp2_planner.py:40-52)
+      self.qc_inv_traj = mk((self.num_gp_factors, self.dof, self.dof), gp_params['Q_c_inv'])
+      self.obscov_inv_traj = mk((self.num_traj_states, nl, 1), 1.0 / _f(obs_params['cost_sigma']) ** 2.0)
+      self.eps_traj = mk((self.num_traj_states, nl, 1), _f(obs_params['epsilon_dist']))
+      self.learn_module_conv = None
+      self.learn_module_fcn = None
+    else:
+      # diff_gpmp2_planner.py:53-88
+      lp = learn_params
+      self.model_type = lp['model']['type'] if 'type' in lp['model'] else False
+      self.learn_eps = lp['dgpmp2']['learn_eps'] if 'learn_eps' in lp['dgpmp2'] else False
+      self.sdf_predict = lp['dgpmp2']['sdf_predict']
+      self.use_dtheta = lp['dgpmp2']['dtheta_predict'] if 'dtheta_predict' in lp['dgpmp2'] else False
+      self.dynamics_mode = lp['dgpmp2']['dynamics_mode']
+      if self.dynamics_mode == 'fix_dynamics':
+        self.qc_inv_traj = mk((self.num_gp_factors, self.dof, self.dof), gp_params['Q_c_inv'])
+      if not self.learn_eps:
+        self.eps = obs_params['epsilon_dist']
+        self.eps_traj = mk((self.num_traj_states, nl, 1), _f(obs_params['epsilon_dist']))
+      self.fixed_conv = lp['dgpmp2']['fixed_conv'] if 'fixed_conv' in lp['dgpmp2'] else False
+      if learn_module_fcn is None:
+        raise NotImplementedError('learn_params given but no learn modules: the CNN/FCN covariance predictors are stock torch.nn '
+                                  'and outside this build; pass them as learn_module_conv= / learn_module_fcn=')
+      self.learn_module_conv = learn_module_conv
+      self.learn_module_fcn = learn_module_fcn
+    self.plan_layer = PlanLayer(gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params,
+                                self.batch_size, self.use_cuda)
+
+  # -- helpers ------------------------------------------------------------------------------------------
+  @staticmethod
+  def _static_view(t, B, like):
+    """(…)-shaped static covariance -> (B,…) expand()ed view in the dtype of `like`, tagged so that PlanLayer passes the
+    handle's constants instead of streaming B copies (the reference materialises them with .repeat, :202-205)."""
+    v = t.to(like.dtype).unsqueeze(0).expand(B, *t.shape)
+    v._dgp_static = True
+    return v
+
+  def _predict(self, th_in, conv_out, hiddenb, im_in=None):
+    """Learned mode: run the user's modules and turn their output into covariances (diff_gpmp2_planner.py:183-199)."""
+    if not self.fixed_conv:
+      conv_out, _ = self.learn_module_conv(im_in)
+    if self.model_type == 'feed_forward':
+      out = self.learn_module_fcn(th_in, conv_out); hidden = None
+    else:
+      out, hidden = self.learn_module_fcn(th_in, conv_out, hiddenb)
+    B = th_in.shape[0]
+    eps = None
+    if self.dynamics_mode == 'fix_dynamics':
+      r = self.get_covariances(out, self.dynamics_mode, self.learn_eps)
+      obscov, eps = (r if self.learn_eps else (r, None))
+      qc = self._static_view(self.qc_inv_traj, B, th_in)
+    else:
+      r = self.get_covariances(out, self.dynamics_mode, self.learn_eps)
+      qc, obscov = r[0], r[1]
+      if self.learn_eps: eps = r[2]
+    if eps is None:
+      eps = self._static_view(self.eps_traj, B, th_in)
+    return qc, obscov, eps, hidden
+
+  # -- reference API --------------------------------------------------------------------------------------
+  def step(self, th_currb, startb, goalb, imb, sdfb, conv_out=None, dtheta_currb=None, hiddenb=None):
+    """One iteration of non-linear optimisation on a batch of environments (diff_gpmp2_planner.py:176-211).
+    -> (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr)"""
+    B = th_currb.shape[0]
+    hidden = None
+    if self.learn_module_fcn is not None:
+      im_in = None
+      if not self.fixed_conv:
+        im_in = torch.cat((imb, sdfb), dim=1) if self.sdf_predict else imb
+      th_in = torch.cat((th_currb, dtheta_currb), dim=-1) if self.use_dtheta else th_currb
+      qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._predict(th_in, conv_out, hiddenb, im_in)
+    else:
+      qc_inv_curr = self._static_view(self.qc_inv_traj, B, th_currb)
+      obscov_inv_curr = self._static_view(self.obscov_inv_traj, B, th_currb)
+      eps_curr = self._static_view(self.eps_traj, B, th_currb)
+    dthetab, err_oldb, err_ext_oldb = self.plan_layer(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
+    hidden_newb = hidden if hiddenb is not None else None
+    return dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr
+
+  def forward(self, th_initb, startb, goalb, imb, sdfb, hiddenb=None):
+    """Gauss-Newton to convergence for every sample (diff_gpmp2_planner.py:92-174).
+    -> (th_currb, hidden_newb, err_initb, err_finalb, err_per_iterb, err_ext_per_iterb, jb, timeb); the err_* / jb / timeb
+    entries are python lists with one item per sample, as in the reference."""
+    start_t = time.time()
+    B = th_initb.shape[0]
+    max_iters = int(self.optim_params['max_iters'])
+    tol_delta = float(self.optim_params['tol_delta'])
+    plan_time = float(self.optim_params['plan_time']) if 'plan_time' in self.optim_params else float('inf')
+    needs_graph = torch.is_grad_enabled() and any(t.requires_grad for t in (th_initb, startb, goalb, sdfb))
+    if self.learn_module_fcn is None and not needs_graph and plan_time == float('inf'):
+      return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t)
+    return self._forward_stepwise(th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t)
+
+  def _forward_fused(self, th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t):
+    pl = self.plan_layer
+    pl._check_inputs(th_initb, startb, goalb)
+    B = th_initb.shape[0]
+    dt, dev = th_initb.dtype, th_initb.device
+    solver = pl._solver(dt)
+    sdf_arg, keep = pl._sdf_arg(solver, sdfb, dt)
+    th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
+    th_out = torch.empty_like(th0)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    eh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
+    eeh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
+    ef = torch.empty(B, dtype=dt, device=dev)
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    solver.gn_solve(B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sdf_arg, None, max_iters, tol_delta, th_out.data_ptr(),
+                    iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _stream())
+    pl.last_info = info
+    pl._last = (st, go, None, None, None)
+    jb = iters.cpu().tolist()                       # synchronises
+    eh_c, eeh_c, ef_c = eh.cpu(), eeh.cpu(), ef.cpu()
+    t = time.time() - start_t
+    err_per_iterb = [eh_c[b, :jb[b]].tolist() for b in range(B)]
+    err_ext_per_iterb = [eeh_c[b, :jb[b]].tolist() for b in range(B)]
+    err_initb = [e[0] for e in err_per_iterb]
+    return th_out, None, err_initb, ef_c.tolist(), err_per_iterb, err_ext_per_iterb, jb, [t] * B
+
+  def _forward_stepwise(self, th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t):
+    """Differentiable / learned / time-limited variant: chained batched step() calls with a per-trajectory freeze once
+    ||dtheta|| < tol_delta (each sample sees exactly the iterations the reference's per-sample loop would run)."""
+    B = th_initb.shape[0]
+    th = th_initb
+    active = torch.ones(B, dtype=torch.bool, device=th.device)
+    jb = torch.zeros(B, dtype=torch.int64, device=th.device)
+    errs, errs_ext, acts = [], [], []
+    hidden = hiddenb
+    conv_out = None
+    dtheta = torch.zeros_like(th_initb)
+    if self.learn_module_fcn is not None and self.fixed_conv:
+      conv_out, _ = self.learn_module_conv(torch.cat((imb, sdfb), dim=1) if self.sdf_predict else imb)
+    j = 0
+    while True:
+      dtheta, hidden_new, err_old, err_ext_old, _, _, _ = self.step(th, startb, goalb, imb, sdfb, conv_out, dtheta, hidden)
+      if hiddenb is not None: hidden = hidden_new
+      errs.append(err_old.detach().reshape(B)); errs_ext.append(err_ext_old.detach().reshape(B)); acts.append(active.clone())
+      th = th + dtheta * active.view(B, 1, 1).to(th.dtype)
+      j += 1
+      jb = jb + active.to(jb.dtype)
+      nrm = torch.norm(dtheta.detach().reshape(B, -1), dim=1)
+      active = active & ~(nrm < tol_delta)
+      if j >= max_iters or not bool(active.any()):
+        break
+      if time.time() - start_t > plan_time:
+        print('Plan time over')
+        break
+    err_final = self.plan_layer.error_batch(th.detach(), sdfb).reshape(B).cpu().tolist()
+    E = torch.stack(errs, 1).cpu(); EE = torch.stack(errs_ext, 1).cpu(); jl = jb.cpu().tolist()
+    t = time.time() - start_t
+    err_per_iterb = [E[b, :jl[b]].tolist() for b in range(B)]
+    err_ext_per_iterb = [EE[b, :jl[b]].tolist() for b in range(B)]
+    hidden_newb = hidden if hiddenb is not None else None
+    return th, hidden_newb, [e[0] for e in err_per_iterb], err_final, err_per_iterb, err_ext_per_iterb, jl, [t] * B
+
+  def error_batch(self, thb, sdfb):
+    return self.plan_layer.error_batch(thb, sdfb)
+
+  def error_ext_batch(self, thb, sdfb):
+    return self.plan_layer.error_ext_batch(thb, sdfb)
+
+  def unweighted_errors_batch(self, thb, sdfb):
+    """diff_gpmp2_planner.py:229-237 -> (err_sg, err_gp, err_obs), each (B,1,1)."""
+    return self.plan_layer.unweighted_errors(thb, sdfb)
+
+  def get_covariances(self, out, mode='diag_identity', learn_eps=False):
+    """Learn-module output (B,1,out_dim) -> covariance tensors (diff_gpmp2_planner.py:247-290).
+    fix_dynamics: obscov[, eps];  diag_identity: q^2 I;  qc_full: q q^T (dof);  q_full: q q^T (state_dim);  'diag' raises."""
+    nl = self.robot_model.nlinks
+    B = out.shape[0]
+    n_obs = self.num_obs_factors * nl
+    if mode == 'fix_dynamics':
+      n_gp = 0
+      qc_inv_traj = None
+    elif mode == 'diag_identity':
+      n_gp = self.num_gp_factors
+      q = out[:, 0, 0:n_gp].reshape(B, self.num_gp_factors, 1, 1)
+      qc_inv_traj = (q * q.transpose(2, 3)) * torch.eye(self.dof, device=out.device, dtype=out.dtype)
+    elif mode == 'diag':
+      raise NotImplementedError
+    elif mode == 'qc_full':
+      n_gp = self.num_gp_factors * self.dof
+      q = out[:, 0, 0:n_gp].reshape(B, self.num_gp_factors, self.dof, 1)
+      qc_inv_traj = q * q.transpose(2, 3)
+    elif mode == 'q_full':
+      n_gp = self.num_gp_factors * self.state_dim
+      q = out[:, 0, 0:n_gp].reshape(B, self.num_gp_factors, self.state_dim, 1)
+      qc_inv_traj = q * q.transpose(2, 3)
+    else:
+      raise ValueError('unknown dynamics_mode %r' % (mode,))
+    o = out[:, 0, n_gp:n_gp + n_obs].reshape(B, self.num_obs_factors, nl, 1)
+    obscov_inv_traj = o * o.transpose(2, 3)
+    if learn_eps:
+      e = out[:, 0, n_gp + n_obs:].reshape(B, self.num_obs_factors, nl, 1)
+      eps_traj = e * e.transpose(2, 3)
+      if mode == 'fix_dynamics':
+        return obscov_inv_traj, eps_traj
+      return qc_inv_traj, obscov_inv_traj, eps_traj
+    if mode == 'fix_dynamics':
+      return obscov_inv_traj
+    return qc_inv_traj, obscov_inv_traj

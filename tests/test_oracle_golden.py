@@ -156,3 +156,19 @@ def test_g3_c4_nonholonomic_xyh(golden):
   qc, ow, eps = p.static_covs(B)
   dth, err, _ = O.plan_layer_forward(g['th'], g['start'], g['goal'], sdf, qc, ow, eps, p)
   assert rel_err(dth, g['dth']) < TOL and rel_err(err, g['err']) < 1e-12
+
+
+def test_dense_torch_baseline(golden):
+  """The PyTorch-CPU dense restatement that bench.py times as cpu_baseline reproduces the reference's outputs."""
+  import torch
+  from oracle import dense_torch as DT
+  g = golden('g3_c2mini')
+  B, n = 8, 64
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G))))
+  T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+  dth, err, err_ext = DT.plan_layer_forward(T(g['cov_th']), T(g['start']), T(g['goal']), sdf, T(g['cov_qc']), T(g['cov_ow']),
+                                            T(g['cov_eps']), DT.params_from_oracle(p))
+  assert rel_err(dth.numpy(), g['cov_dth']) < TOL
+  assert rel_err(err.numpy(), g['cov_err']) < 1e-12 and rel_err(err_ext.numpy(), g['cov_errext']) < 1e-12
