@@ -63,16 +63,28 @@ def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
   qc = torch.from_numpy(p.static_covs(B)[0]); ow = torch.from_numpy(p.static_covs(B)[1]); eps = torch.from_numpy(p.static_covs(B)[2])
   sdf = sdf_cpu.double().expand(B, 1, GRID, GRID)
   ts = []
+  inverse_impl = 'torch.inverse'
   with torch.no_grad():
-    for k in range(steps + 1):
+    k = 0
+    while k < steps + 1:
       th = th_hist_cpu[k % len(th_hist_cpu)][:B].double()
       t0 = time.perf_counter()
-      DT.plan_layer_forward(th, start_cpu[:B].double(), goal_cpu[:B].double(), sdf, qc, ow, eps, P)
+      try:
+        DT.plan_layer_forward(th, start_cpu[:B].double(), goal_cpu[:B].double(), sdf, qc, ow, eps, P)
+      except RuntimeError:
+        # some hosts' MKL rejects batched torch.inverse ("Parameter 6 was incorrect on entry to DLASWP" -> "Pivots given to
+        # lu_solve ..."): form the two explicit inverses with triangular solves against I instead and start over
+        if inverse_impl != 'torch.inverse': raise
+        inverse_impl = 'torch.linalg.solve_triangular(u, I) (torch.inverse fails in MKL on this host)'
+        DT.set_explicit_inverse('solve_triangular')
+        ts, k = [], 0
+        continue
       ts.append(time.perf_counter() - t0)
+      k += 1
   t_chunk = float(np.median(ts[1:]))
   return {'value': 1.0 / (t_chunk * (B_PER_GPU / B)), 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'kind': 'port',
           'sample': 'dense PyTorch-CPU fp64 restatement of PlanLayer.forward on %d of the 4096 trajectories, 1 warm-up + %d timed '
-                    'steps, median %.3f s per %d-trajectory step, scaled by 4096/%d' % (B, steps, t_chunk, B, B),
+                    'steps, median %.3f s per %d-trajectory step, scaled by 4096/%d; explicit inverses via %s' % (B, steps, t_chunk, B, B, inverse_impl),
           'torch_threads': torch.get_num_threads()}
 
 

@@ -8,6 +8,10 @@ which exports the same entry points with the prefix `emul_`, through the very sa
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE the HIP library is dlopen'ed: torch ships its own libamdhip64.so.7 /
+# libhsa-runtime64; loading ours first would bind /opt/rocm's copies and leave the process with two runtimes ("no ROCm-capable
+# device" on the first launch).  With torch first, our library's libamdhip64.so.7 dependency resolves to the one already loaded.
+
 DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64 = 0, 1
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2

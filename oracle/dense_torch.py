@@ -10,6 +10,24 @@ tests/test_oracle_golden.py::test_dense_torch_baseline.
 import torch
 
 
+_EXPLICIT_INVERSE = 'inverse'
+
+
+def set_explicit_inverse(kind):
+  """'inverse' (torch.inverse, what the reference calls, plan_layer.py:227-228) or 'solve_triangular' (explicit inverse of
+  the triangular factor by a triangular solve against I; used on hosts whose MKL build rejects batched torch.inverse)."""
+  global _EXPLICIT_INVERSE
+  assert kind in ('inverse', 'solve_triangular')
+  _EXPLICIT_INVERSE = kind
+
+
+def _tri_inverse(t, upper):
+  if _EXPLICIT_INVERSE == 'inverse':
+    return torch.inverse(t)
+  I = torch.eye(t.shape[-1], dtype=t.dtype).expand_as(t)
+  return torch.linalg.solve_triangular(t, I, upper=upper)
+
+
 def _phi(dof, dt, dtype):
   I = torch.eye(dof, dtype=dtype)
   return torch.cat((torch.cat((I, dt * I), 1), torch.cat((torch.zeros(dof, dof, dtype=dtype), I), 1)), 0)
@@ -91,8 +109,8 @@ def plan_layer_forward(th, start, goal, sdf, qc, ow, eps, P):
   LAM = torch.bmm(AtK, A) + P['reg'] * Id
   R = torch.bmm(AtK, b)
   u = torch.linalg.cholesky(LAM).mH
-  z = torch.bmm(torch.inverse(u.transpose(1, 2)), R)
-  dth = torch.bmm(torch.inverse(u), z).view(B, n, d)
+  z = torch.bmm(_tri_inverse(u.transpose(1, 2), upper=False), R)
+  dth = torch.bmm(_tri_inverse(u, upper=True), z).view(B, n, d)
   # plan_layer.py:97-98: two more full factor evaluations
   e_s, e_g, e_gp, _, e_o, _ = _factors(th, start, goal, sdf, eps, P)
   err = _error(e_s, e_g, e_gp, e_o, Q_inv, ow, P)

@@ -14,9 +14,9 @@ DEV = 'cuda:0'
 
 def ref_params(n, dtype=torch.float64, max_iters=10, tol_delta=1e-4):
   """param dicts exactly as examples/configs/gpmp2_2d_params.yaml + robot_2d.yaml + env_2d_params.yaml load them"""
-  gp_params = {'Q_c_inv': torch.eye(2, dtype=dtype), 'K_s': torch.tensor(0.01), 'K_g': torch.tensor(0.01),
-               'K_v': torch.tensor(0.01), 'v_x': [1.0], 'v_y': [1.0]}
-  obs_params = {'cost_sigma': torch.tensor(0.01), 'epsilon_dist': torch.tensor(0.4)}
+  t = lambda v: torch.tensor(v, dtype=dtype)     # the reference loads its YAML under a float64 default dtype (SURVEY Q1)
+  gp_params = {'Q_c_inv': torch.eye(2, dtype=dtype), 'K_s': t(0.01), 'K_g': t(0.01), 'K_v': t(0.01), 'v_x': [1.0], 'v_y': [1.0]}
+  obs_params = {'cost_sigma': t(0.01), 'epsilon_dist': t(0.4)}
   planner_params = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
   optim_params = {'method': 'gauss_newton', 'reg': 0.1, 'plan_time': float('inf'), 'max_iters': max_iters, 'tol_err': 1e-3,
                   'tol_delta': tol_delta}
@@ -28,7 +28,7 @@ def make_planner(n, B=1, **kw):
   from dgpmp2_amd.robot_models import PointRobot2D
   from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
   gp, ob, pp, op, ev = ref_params(n, **kw)
-  robot = PointRobot2D(torch.tensor(0.4), B, n, use_cuda=True)
+  robot = PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n, use_cuda=True)
   return DiffGPMP2Planner(gp, ob, pp, op, ev, robot, batch_size=B, use_cuda=True)
 
 
