@@ -50,12 +50,28 @@ def make_inputs(B, n, G, device, seed=0):
   return f(th0), f(start), f(goal), f(sdf)
 
 
+def usable_cores():
+  """Host cores this process may really use: min(affinity, cgroup CPU quota).  (The GPU boxes expose 256 logical CPUs but
+  cap the container at 16 through cgroup cpu.max; running 256 threads against that quota is ~100x slower.)"""
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  try:
+    if os.path.exists('/sys/fs/cgroup/cpu.max'):
+      q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+      if q != 'max': n = min(n, max(1, int(int(q) / int(per))))
+    elif os.path.exists('/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+      q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+      if q > 0: n = min(n, max(1, q // per))
+  except (OSError, ValueError):
+    pass
+  return n
+
+
 def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
   """The reference's dense PyTorch-CPU op sequence (oracle/dense_torch.py, kind 'port'), fp64, all host cores, on a
   bounded sample: `chunk` of the 4096 trajectories, 1 warm-up + `steps` timed steps; scaled to whole-batch steps/s."""
   from oracle import dense_torch as DT
   from oracle.gpmp2_oracle import OracleParams
-  cores = os.cpu_count() or 1
+  cores = usable_cores()
   torch.set_num_threads(cores)
   p = OracleParams(dof=DOF, total_time_step=N_STATES - 1)
   P = DT.params_from_oracle(p)
