@@ -3,6 +3,7 @@
 // Shared by dgpmp2_hip.hip (the product library) and tests/emul (the CPU wavefront emulator used by tests).
 #pragma once
 #include <stdio.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
@@ -14,10 +15,13 @@
 struct DgpHandle {
   DgpConfig cfg;
   int d;                // state_dim
-  int lpt;              // lanes per trajectory (16/32/64)
   int M;                // plan_layer.py:43-45
+  int force_lpt, force_c;   // >0: launch shape pinned by the environment variable DGP_FORCE_SHAPE="LPT,C" (tuning aid)
   dgp::GnParams base;   // constants filled once
 };
+
+// Launch shape: LPT lanes per trajectory x C consecutive states per lane, LPT*C >= n.
+struct DgpShape { int lpt, c; };
 
 namespace dgp_host {
 
@@ -34,6 +38,32 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+// Shapes the kernels are instantiated for (see DGP_FOR_EACH_SHAPE in dgpmp2_hip.hip): LPT in {16,32,64} x C in {1,2,4}.
+constexpr int kMaxStates = 256;
+inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || lpt == 64) && (c == 1 || c == 2 || c == 4); }
+
+// Pick (LPT, C) for n states and a batch of B trajectories.  More states per lane (larger C) means less arithmetic per
+// trajectory (the local elimination is O(C) per lane while every PCR round costs the same whatever LPT is) but fewer
+// wavefronts; MI355X has 1024 SIMDs, so C grows only while the launch still has about one wavefront per SIMD.
+inline DgpShape choose_shape(const DgpHandle* h, int B) {
+  if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
+  const int n = h->cfg.num_states;
+  DgpShape best{64, 4};
+  double best_cost = 1e300;
+  for (int c = 1; c <= 4; c *= 2)
+    for (int lpt = 16; lpt <= 64; lpt *= 2) {
+      if (lpt * c < n) continue;
+      int rounds = 0;
+      for (int s = 1; s < lpt; s <<= 1) ++rounds;
+      const double per_wave = 600.0 * rounds + 650.0 * (c - 1) + 250.0 * c + (c > 1 ? 300.0 : 0.0);   // instruction estimate
+      const double waves = (double)((B + (64 / lpt) - 1) / (64 / lpt));
+      const double passes = waves <= 1024.0 ? 1.0 : waves / 1024.0;        // wavefronts per SIMD, at least one
+      const double cost = per_wave * passes;
+      if (cost < best_cost) { best_cost = cost; best = DgpShape{lpt, c}; }
+    }
+  return best;
+}
+
 inline int create(const DgpConfig* cfg, DgpHandle** out) {
   if (!cfg || !out) return fail(DGP_EINVAL, "null argument");
   *out = nullptr;
@@ -42,7 +72,7 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   if (cfg->dof != 2 && cfg->dof != 3) return fail(DGP_EUNSUPPORTED, "dof must be 2 or 3, got %d", cfg->dof);
   if (cfg->nlinks != 1) return fail(DGP_EUNSUPPORTED, "only nlinks == 1 (point robots) is implemented, got %d", cfg->nlinks);
   if (cfg->num_states < 2) return fail(DGP_EINVAL, "num_states must be >= 2, got %d", cfg->num_states);
-  if (cfg->num_states > 64) return fail(DGP_EUNSUPPORTED, "num_states > 64 is not implemented yet, got %d", cfg->num_states);
+  if (cfg->num_states > kMaxStates) return fail(DGP_EUNSUPPORTED, "num_states > %d is not implemented, got %d", kMaxStates, cfg->num_states);
   if (cfg->io_dtype != DGP_F32 && cfg->io_dtype != DGP_F64) return fail(DGP_EINVAL, "bad io_dtype %d", cfg->io_dtype);
   if ((cfg->flags & DGP_FLAG_NONHOLONOMIC) && cfg->dof != 3)
     return fail(DGP_EINVAL, "the non-holonomic factor needs the (x,y,theta) robot, dof == 3");
@@ -57,7 +87,12 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   h->cfg = *cfg;
   const int n = cfg->num_states, dof = cfg->dof;
   h->d = 2 * dof;
-  h->lpt = n <= 16 ? 16 : (n <= 32 ? 32 : 64);
+  h->force_lpt = h->force_c = 0;
+  if (const char* fs = getenv("DGP_FORCE_SHAPE")) {
+    int l = 0, c = 0;
+    if (sscanf(fs, "%d,%d", &l, &c) == 2 && shape_supported(l, c) && l * c >= n) { h->force_lpt = l; h->force_c = c; }
+    else { delete h; return fail(DGP_EINVAL, "DGP_FORCE_SHAPE=%s is not a supported LPT,C pair covering n=%d", fs, n); }
+  }
   h->M = h->d * ((n - 1) + 2) + n * cfg->nlinks;                       // plan_layer.py:43
   if (cfg->flags & DGP_FLAG_NONHOLONOMIC) h->M += n;                    // :44
   if (cfg->flags & DGP_FLAG_VEL_LIMITS) h->M += dof * n;                // :45

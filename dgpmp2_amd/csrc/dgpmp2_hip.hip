@@ -29,10 +29,10 @@ struct DevCtx {
   __device__ __forceinline__ void atomic_add(double* p, double v) const { atomicAdd(p, v); }
 };
 
-template <int DOF, int LPT, typename IO, int MODE>
+template <int DOF, int LPT, int C, typename IO, int MODE>
 __global__ void __launch_bounds__(64) gn_kernel(const dgp::GnParams p) {
   DevCtx cx;
-  dgp::gn_lane_program<DOF, LPT, IO, MODE>(p, cx);
+  dgp::gn_lane_program<DOF, LPT, C, IO, MODE>(p, cx);
 }
 
 template <int DOF, int LPT, typename IO>
@@ -41,31 +41,34 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   dgp::gn_backward_lane_program<DOF, LPT, IO>(p, g, cx);
 }
 
-template <int DOF, int LPT, typename IO>
+template <int DOF, int LPT, int C, typename IO>
 hipError_t launch_mode(int mode, const dgp::GnParams& p, hipStream_t s) {
   constexpr int TPW = 64 / LPT;
   const unsigned grid = (unsigned)((p.B + TPW - 1) / TPW);
   switch (mode) {
-    case dgp::MODE_STEP: hipLaunchKernelGGL((gn_kernel<DOF, LPT, IO, dgp::MODE_STEP>), dim3(grid), dim3(64), 0, s, p); break;
-    case dgp::MODE_SOLVE: hipLaunchKernelGGL((gn_kernel<DOF, LPT, IO, dgp::MODE_SOLVE>), dim3(grid), dim3(64), 0, s, p); break;
-    default: hipLaunchKernelGGL((gn_kernel<DOF, LPT, IO, dgp::MODE_EVAL>), dim3(grid), dim3(64), 0, s, p); break;
+    case dgp::MODE_STEP: hipLaunchKernelGGL((gn_kernel<DOF, LPT, C, IO, dgp::MODE_STEP>), dim3(grid), dim3(64), 0, s, p); break;
+    case dgp::MODE_SOLVE: hipLaunchKernelGGL((gn_kernel<DOF, LPT, C, IO, dgp::MODE_SOLVE>), dim3(grid), dim3(64), 0, s, p); break;
+    default: hipLaunchKernelGGL((gn_kernel<DOF, LPT, C, IO, dgp::MODE_EVAL>), dim3(grid), dim3(64), 0, s, p); break;
   }
   return hipGetLastError();
 }
 
+// every (LPT, C) of dgp_host::shape_supported
+#define DGP_FOR_EACH_SHAPE(X) X(16, 1) X(32, 1) X(64, 1) X(16, 2) X(32, 2) X(64, 2) X(16, 4) X(32, 4) X(64, 4)
+
 template <int DOF, typename IO>
-hipError_t launch_lpt(int lpt, int mode, const dgp::GnParams& p, hipStream_t s) {
-  switch (lpt) {
-    case 16: return launch_mode<DOF, 16, IO>(mode, p, s);
-    case 32: return launch_mode<DOF, 32, IO>(mode, p, s);
-    default: return launch_mode<DOF, 64, IO>(mode, p, s);
-  }
+hipError_t launch_shape(DgpShape sh, int mode, const dgp::GnParams& p, hipStream_t s) {
+#define DGP_CASE(L, CC) if (sh.lpt == L && sh.c == CC) return launch_mode<DOF, L, CC, IO>(mode, p, s);
+  DGP_FOR_EACH_SHAPE(DGP_CASE)
+#undef DGP_CASE
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, hipStream_t s) {
+  const DgpShape sh = dgp_host::choose_shape(h, p.B);
   const bool f64 = h->cfg.io_dtype == DGP_F64;
-  if (h->cfg.dof == 2) return f64 ? launch_lpt<2, double>(h->lpt, mode, p, s) : launch_lpt<2, float>(h->lpt, mode, p, s);
-  return f64 ? launch_lpt<3, double>(h->lpt, mode, p, s) : launch_lpt<3, float>(h->lpt, mode, p, s);
+  if (h->cfg.dof == 2) return f64 ? launch_shape<2, double>(sh, mode, p, s) : launch_shape<2, float>(sh, mode, p, s);
+  return f64 ? launch_shape<3, double>(sh, mode, p, s) : launch_shape<3, float>(sh, mode, p, s);
 }
 
 template <int DOF, typename IO>
@@ -134,8 +137,8 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   const bool f64 = h->cfg.io_dtype == DGP_F64;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e;
-  if (h->cfg.dof == 2) e = f64 ? launch_bwd_lpt<2, double>(h->lpt, p, g, s) : launch_bwd_lpt<2, float>(h->lpt, p, g, s);
-  else e = f64 ? launch_bwd_lpt<3, double>(h->lpt, p, g, s) : launch_bwd_lpt<3, float>(h->lpt, p, g, s);
+  if (h->cfg.dof == 2) e = f64 ? launch_bwd_lpt<2, double>(64, p, g, s) : launch_bwd_lpt<2, float>(64, p, g, s);
+  else e = f64 ? launch_bwd_lpt<3, double>(64, p, g, s) : launch_bwd_lpt<3, float>(64, p, g, s);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step_backward launch failed: %s", hipGetErrorString(e));
   return DGP_OK;
 }

@@ -1,13 +1,14 @@
 // gn_lane.h -- the per-lane program of the fused Gauss-Newton kernel.
 //
-// Mapping (MI355X, wave64): one trajectory occupies LPT consecutive lanes of a wavefront
-// (LPT = 16/32/64, the next power of two >= n), lane i of the group OWNS support state i.
-// Every lane
-//   1. loads its state x_i, gets x_{i-1}, x_{i+1} from its neighbours with cross-lane moves,
-//   2. evaluates the factors touching state i and writes the i-th block row of the block-tridiagonal
-//      normal equations  (D_i sym dxd, U_i dxd, eta_i)  straight into registers,
-//   3. takes part in a block parallel-cyclic-reduction (PCR) solve: log2(LPT) rounds, in each round a lane
-//      inverts its own D_i, fetches (D^-1, U, eta) of lanes i-s and i+s, and eliminates them.
+// Mapping (MI355X, wave64): one trajectory occupies LPT consecutive lanes of a wavefront (LPT = 8..64) and every
+// lane OWNS C consecutive support states (n <= LPT*C).  Every lane
+//   1. loads its C states, gets the two states across its lane boundaries with cross-lane moves,
+//   2. evaluates the factors touching its states and writes their block rows of the block-tridiagonal normal
+//      equations (D sym dxd, U dxd, eta) straight into registers,
+//   3. eliminates its C-1 interior rows locally (block Thomas with a left spike), which leaves ONE row per lane,
+//   4. takes part in a block parallel-cyclic-reduction (PCR) solve over the LPT lanes: log2(LPT) rounds, in each
+//      round a lane inverts its own D, fetches (D^-1, U, eta) of lanes j-s and j+s, and eliminates them,
+//   5. recovers its interior unknowns from the two neighbouring separator unknowns.
 // Lambda never exists in memory.  All arithmetic is fp64 (the reference is fp64-only).
 //
 // The program is written against a tiny "lane context" (cross-lane fetch + ids) so that the very same
@@ -286,44 +287,41 @@ DGP_HD double quad(const Sym<D>& Q, const double (&e)[D]) {      // e^T Q e
 }
 
 // ---------------------------------------------------------------------------------------------------
-// factor evaluation for the state owned by this lane -> block row (Dm, U, r) and error partial sums
+// factor evaluation for ONE support state (row g of the block-tridiagonal system)
+//   -> diagonal block Dm, coupling U to row g+1, eta r, and the partial error sums.
+// Qm is Q^-1 of the GP factor (g-1 -> g) (ignored for g == 0); Q returns Q^-1 of the factor (g -> g+1) so that
+// the caller can hand it to the next row instead of loading it twice.
 // ---------------------------------------------------------------------------------------------------
-template <int DOF>
-struct LaneEval {
-  static constexpr int D = 2 * DOF;
-  Sym<D> Dm;          // diagonal block
-  Mat<D> U;           // coupling to the next state: block (i, i+1) = -Phi^T Q_i^-1
-  double r[D];        // eta_i
-  double e, eext;     // partial sums of err / err_ext (un-normalised)
+struct ErrAcc {
+  double e, eext;          // partial sums of err / err_ext (un-normalised)
   double usg, ugp, uobs;   // unweighted partials (plan_layer.py:374-388)
 };
 
 template <int DOF, typename IO, bool ASSEMBLE>
-DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const double (&x)[2 * DOF],
-                       const double (&xm)[2 * DOF], const double (&xp)[2 * DOF], LaneEval<DOF>& o) {
+DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
+                       const double (&xp)[2 * DOF], const Sym<2 * DOF>& Qm, Sym<2 * DOF>& Q, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U,
+                       double (&r)[2 * DOF], ErrAcc& acc) {
   constexpr int D = 2 * DOF;
   const int n = p.n;
-  o.e = 0.0; o.eext = 0.0; o.usg = 0.0; o.ugp = 0.0; o.uobs = 0.0;
   if (ASSEMBLE) {
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      o.r[a] = 0.0;
+      r[a] = 0.0;
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        o.U.v[a][c] = 0.0;
-        if (c >= a) o.Dm(a, c) = (a == c) ? 1.0 : 0.0;     // padding lanes: identity row, x = 0
+        U.v[a][c] = 0.0;
+        if (c >= a) Dm(a, c) = (a == c) ? 1.0 : 0.0;       // padding rows: identity row, x = 0
       }
     }
   }
   if (!valid) return;
   if (ASSEMBLE) {
 #pragma unroll
-    for (int a = 0; a < D; ++a) o.Dm(a, a) = p.reg;        // delta I (plan_layer.py:219)
+    for (int a = 0; a < D; ++a) Dm(a, a) = p.reg;          // delta I (plan_layer.py:219)
   }
   // ---- start / goal priors: e = mu - x, H = +I, weight I/K^2 (prior_factor.py:15-18; plan_layer.py:64-68)
-  if (i == 0 || i == n - 1) {
-    const bool is_start = (i == 0);
-    // n == 1 cannot happen (n >= 2 enforced by the host); i==0 and i==n-1 are distinct lanes
+  if (g == 0 || g == n - 1) {
+    const bool is_start = (g == 0);                        // n >= 2 (host-enforced): rows 0 and n-1 are distinct
     const void* mu = is_start ? p.start : p.goal;
     const double w = is_start ? p.w_s : p.w_g;
     double s2 = 0.0;
@@ -331,15 +329,14 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
     for (int a = 0; a < D; ++a) {
       const double ea = ld<IO>(mu, b * D + a) - x[a];
       s2 += ea * ea;
-      if (ASSEMBLE) { o.Dm(a, a) += w; o.r[a] += w * ea; }
+      if (ASSEMBLE) { Dm(a, a) += w; r[a] += w * ea; }
     }
-    o.e += 0.5 * w * s2; o.eext += 0.5 * w * s2; o.usg += 0.5 * s2;
+    acc.e += 0.5 * w * s2; acc.eext += 0.5 * w * s2; acc.usg += 0.5 * s2;
   }
-  // ---- GP factor (i -> i+1), owned by lane i: e = x_{i+1} - Phi x_i (gp_factor.py:105)
+  // ---- GP factor (g -> g+1), owned by row g: e = x_{g+1} - Phi x_g (gp_factor.py:105)
   const double dt = p.dt;
-  if (i < n - 1) {
-    Sym<D> Q;
-    load_Qinv<DOF, IO>(p, b, i, Q);
+  if (g < n - 1) {
+    load_Qinv<DOF, IO>(p, b, g, Q);
     double e[D];
 #pragma unroll
     for (int a = 0; a < DOF; ++a) {
@@ -347,17 +344,17 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
       e[DOF + a] = xp[DOF + a] - x[DOF + a];
     }
     const double q = quad<D>(Q, e);
-    o.e += 0.5 * q;
+    acc.e += 0.5 * q;
     double s2 = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) s2 += e[a] * e[a];
-    o.ugp += 0.5 * s2;
+    acc.ugp += 0.5 * s2;
     if (p.qc_mode == QC_STATIC) {
-      o.eext += 0.5 * q;
+      acc.eext += 0.5 * q;
     } else {
       Sym<D> Qf;
       fixed_Qinv<DOF>(p, Qf);
-      o.eext += 0.5 * quad<D>(Qf, e);                      // plan_layer.py:318-321
+      acc.eext += 0.5 * quad<D>(Qf, e);                    // plan_layer.py:318-321
     }
     if (ASSEMBLE) {
       // PQ = Phi^T Q : rows pos = Q[pos,:], rows vel = dt*Q[pos,:] + Q[vel,:]
@@ -374,23 +371,21 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
       for (int a = 0; a < D; ++a) {
 #pragma unroll
         for (int c = 0; c < DOF; ++c) {
-          if (c >= a) o.Dm(a, c) += PQ[a][c];
-          if (DOF + c >= a) o.Dm(a, DOF + c) += dt * PQ[a][c] + PQ[a][DOF + c];
+          if (c >= a) Dm(a, c) += PQ[a][c];
+          if (DOF + c >= a) Dm(a, DOF + c) += dt * PQ[a][c] + PQ[a][DOF + c];
         }
         double t = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-          o.U.v[a][c] = -PQ[a][c];                         // block (i,i+1) = H1^T Q^-1 H2 = -Phi^T Q^-1
+          U.v[a][c] = -PQ[a][c];                           // block (g,g+1) = H1^T Q^-1 H2 = -Phi^T Q^-1
           t += PQ[a][c] * e[c];
         }
-        o.r[a] += t;                                       // H1^T Q^-1 e
+        r[a] += t;                                         // H1^T Q^-1 e
       }
     }
   }
-  // ---- GP factor (i-1 -> i): contributes Q_{i-1}^-1 to D_i and -Q_{i-1}^-1 e_{i-1} to eta_i
-  if (ASSEMBLE && i > 0) {
-    Sym<D> Q;
-    load_Qinv<DOF, IO>(p, b, i - 1, Q);
+  // ---- GP factor (g-1 -> g): contributes Q_{g-1}^-1 to D_g and -Q_{g-1}^-1 e_{g-1} to eta_g
+  if (ASSEMBLE && g > 0) {
     double e[D];
 #pragma unroll
     for (int a = 0; a < DOF; ++a) {
@@ -402,25 +397,25 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
       double t = 0.0;
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        if (c >= a) o.Dm(a, c) += Q(a, c);
-        t += Q(a, c) * e[c];
+        if (c >= a) Dm(a, c) += Qm(a, c);
+        t += Qm(a, c) * e[c];
       }
-      o.r[a] -= t;
+      r[a] -= t;
     }
   }
   // ---- obstacle factor (obstacle_factor.py:35-40): sphere centre = x[0:2], H = H_e H_fk, H_fk = I_d[0:2,:]
   {
-    const double eps = p.eps ? ld<IO>(p.eps, b * n + i) : p.eps_static;
-    const double w = p.obs_w ? ld<IO>(p.obs_w, b * n + i) : p.obs_w_fix;
+    const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
+    const double w = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
     const IO* grid = (const IO*)p.sdf + b * p.sdf_bstride;
     double c, hx, hy;
     obstacle_eval<IO>(p, grid, x[0], x[1], eps, c, hx, hy);
-    o.e += 0.5 * w * c * c;
-    o.eext += 0.5 * p.obs_w_fix * c * c;                   // plan_layer.py:329-332 (fixed weight, current eps)
-    o.uobs += 0.5 * c * c;
+    acc.e += 0.5 * w * c * c;
+    acc.eext += 0.5 * p.obs_w_fix * c * c;                 // plan_layer.py:329-332 (fixed weight, current eps)
+    acc.uobs += 0.5 * c * c;
     if (ASSEMBLE) {
-      o.Dm(0, 0) += w * hx * hx; o.Dm(0, 1) += w * hx * hy; o.Dm(1, 1) += w * hy * hy;
-      o.r[0] += w * hx * c; o.r[1] += w * hy * c;
+      Dm(0, 0) += w * hx * hx; Dm(0, 1) += w * hx * hy; Dm(1, 1) += w * hy * hy;
+      r[0] += w * hx * c; r[1] += w * hy * c;
     }
   }
   // ---- velocity-limit factor (velocity_limit_factor.py:17-29): '>=' (not '>'), H = -sign(v) e_{dof+a}
@@ -433,8 +428,8 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
       const double c = act ? (av - p.vmax[a]) : 0.0;
       const double sg = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
       const double h = act ? -sg : 0.0;
-      o.e += 0.5 * p.w_v * c * c; o.eext += 0.5 * p.w_v * c * c;
-      if (ASSEMBLE) { o.Dm(DOF + a, DOF + a) += p.w_v * h * h; o.r[DOF + a] += p.w_v * h * c; }
+      acc.e += 0.5 * p.w_v * c * c; acc.eext += 0.5 * p.w_v * c * c;
+      if (ASSEMBLE) { Dm(DOF + a, DOF + a) += p.w_v * h * h; r[DOF + a] += p.w_v * h * c; }
     }
   }
   // ---- non-holonomic factor (nonholonomic_factor.py:16-30), state [x,y,th,vx,vy,w]; H as the reference writes it
@@ -443,16 +438,111 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int i, bool valid, const do
     const double sn = sin(th), cs = cos(th);
     const double e = vy * cs - vx * sn;
     const double h[3] = {-vy * sn + vx * cs, -sn, cs};    // columns 2,3,4
-    o.e += 0.5 * p.w_d * e * e; o.eext += 0.5 * p.w_d * e * e;
+    acc.e += 0.5 * p.w_d * e * e; acc.eext += 0.5 * p.w_d * e * e;
     if (ASSEMBLE) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
 #pragma unroll
-        for (int c = a; c < 3; ++c) o.Dm(2 + a, 2 + c) += p.w_d * h[a] * h[c];
-        o.r[2 + a] += p.w_d * h[a] * e;
+        for (int c = a; c < 3; ++c) Dm(2 + a, 2 + c) += p.w_d * h[a] * h[c];
+        r[2 + a] += p.w_d * h[a] * e;
       }
     }
   }
+}
+
+// small dense helpers on dxd blocks -----------------------------------------------------------------
+template <int D> DGP_HD void sym_times_mat(const Sym<D>& S, const Mat<D>& A, Mat<D>& O) {       // O = S A
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += S(a, k) * A.v[k][c];
+      O.v[a][c] = t;
+    }
+}
+template <int D> DGP_HD void sym_times_vec(const Sym<D>& S, const double (&v)[D], double (&o)[D]) {   // o = S v
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += S(a, k) * v[k];
+    o[a] = t;
+  }
+}
+template <int D> DGP_HD void sub_At_B_sym(Sym<D>& S, const Mat<D>& A, const Mat<D>& B) {          // S -= A^T B (symmetric result)
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double t = S(a, c);
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= A.v[k][a] * B.v[k][c];
+      S(a, c) = t;
+    }
+}
+template <int D> DGP_HD void sub_A_B_sym(Sym<D>& S, const Mat<D>& A, const Mat<D>& B) {           // S -= A B (symmetric result)
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double t = S(a, c);
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= A.v[a][k] * B.v[k][c];
+      S(a, c) = t;
+    }
+}
+template <int D> DGP_HD void sub_At_v(double (&o)[D], const Mat<D>& A, const double (&v)[D]) {    // o -= A^T v
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = o[a];
+#pragma unroll
+    for (int k = 0; k < D; ++k) t -= A.v[k][a] * v[k];
+    o[a] = t;
+  }
+}
+template <int D> DGP_HD void sub_A_v(double (&o)[D], const Mat<D>& A, const double (&v)[D]) {     // o -= A v
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = o[a];
+#pragma unroll
+    for (int k = 0; k < D; ++k) t -= A.v[a][k] * v[k];
+    o[a] = t;
+  }
+}
+template <int D> DGP_HD void neg_At_B(const Mat<D>& A, const Mat<D>& B, Mat<D>& O) {              // O = -A^T B
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= A.v[k][a] * B.v[k][c];
+      O.v[a][c] = t;
+    }
+}
+template <int D> DGP_HD void neg_A_B(const Mat<D>& A, const Mat<D>& B, Mat<D>& O) {               // O = -A B
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= A.v[a][k] * B.v[k][c];
+      O.v[a][c] = t;
+    }
+}
+template <int D> DGP_HD void sub_A_B(Mat<D>& O, const Mat<D>& A, const Mat<D>& B) {               // O -= A B
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = O.v[a][c];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= A.v[a][k] * B.v[k][c];
+      O.v[a][c] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -590,34 +680,192 @@ DGP_HD int group_or(Ctx& cx, int v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// the lane program
+// One Gauss-Newton linear solve for the C rows owned by this lane (rows j*C .. j*C+C-1 of trajectory b).
+//
+//  a. forward block elimination of the lane's C-1 INTERIOR rows (all but its last), carrying the right-hand side
+//     and the "left spike" (the coupling of row 0 to the previous lane's last row):
+//         S_0 = D_0,  S_k = D_k - U_{k-1}^T S_{k-1}^-1 U_{k-1},   G_k = S_k^-1 U_k
+//         z_k = r_k - G_{k-1}^T z_{k-1},   Zl_0 = L_0 = U_{-1}^T,   Zl_k = -G_{k-1}^T Zl_{k-1}
+//  b. back substitution, giving the interior unknowns as an affine function of the two neighbouring SEPARATOR
+//     unknowns (x_ps = last row of the previous lane, x_s = last row of this lane):
+//         x_k = P_k - V_k x_ps - W_k x_s
+//  c. the lane's separator row, with x_{C-2} (own interior) and x'_0 (first interior row of the NEXT lane, whose
+//     P'_0, V'_0, W'_0 are fetched across lanes) substituted, is one row of a block-tridiagonal system over the LPT
+//     lanes -> block PCR (log2 LPT rounds) gives x_s;
+//  d. x_ps is fetched from the previous lane and the interior rows follow from b.
+// With C == 1 there are no interior rows and this is plain block PCR on the original system.
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, typename IO, int MODE, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
+DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
+                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
+  constexpr int D = 2 * DOF;
+  constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
+  const int lane = cx.lane();
+  const int n = p.n;
+  const int src_m = (j >= 1) ? lane - 1 : lane;
+  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  // neighbouring states across the lane boundary
+  double x_prev[D], x_next[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) { x_prev[a] = cx.fetch(x[C - 1][a], src_m); x_next[a] = cx.fetch(x[0][a], src_p); }
+
+  Sym<D> Sinv[CI];
+  Mat<D> G[CI], V[CI], W[CI];
+  double P[CI][D];
+  Sym<D> Qm = {}, Q = {};
+  Mat<D> Uprev = {};     // U of the previous row (k-1)
+  const int g0 = j * C;
+  if (traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
+
+  // ---- a. forward sweep over the interior rows
+#pragma unroll
+  for (int k = 0; k < C - 1; ++k) {
+    const int g = g0 + k;
+    const bool valid = traj_ok && g < n;
+    Sym<D> Dk; Mat<D> Uk; double rk[D];
+    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Qm, Q, Dk, Uk, rk, acc);
+    if (k == 0) {
+      // left spike Zl_0 = L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
+      const bool has_prev = valid && g > 0;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < DOF; ++c) {
+          V[0].v[a][c] = has_prev ? -Qm(a, c) : 0.0;
+          V[0].v[a][DOF + c] = has_prev ? -(p.dt * Qm(a, c) + Qm(a, DOF + c)) : 0.0;
+        }
+#pragma unroll
+      for (int a = 0; a < D; ++a) P[0][a] = rk[a];
+    } else {
+      sub_At_B_sym<D>(Dk, Uprev, G[k - 1]);               // S_k = D_k - U_{k-1}^T G_{k-1}
+#pragma unroll
+      for (int a = 0; a < D; ++a) P[k][a] = rk[a];
+      sub_At_v<D>(P[k], G[k - 1], P[k - 1]);              // z_k = r_k - G_{k-1}^T z_{k-1}
+      neg_At_B<D>(G[k - 1], V[k - 1], V[k]);              // Zl_k = -G_{k-1}^T Zl_{k-1}
+    }
+    sym_inverse<D>(Dk, Sinv[k], ok);
+    sym_times_mat<D>(Sinv[k], Uk, G[k]);                  // G_k = S_k^-1 U_k
+    Uprev = Uk;
+    Qm = Q;
+  }
+  // ---- b. back substitution: P, V, W in place
+  if (C > 1) {
+    {
+      constexpr int k = (C > 1) ? C - 2 : 0;
+      double t[D];
+      sym_times_vec<D>(Sinv[k], P[k], t);
+#pragma unroll
+      for (int a = 0; a < D; ++a) P[k][a] = t[a];
+      Mat<D> T;
+      sym_times_mat<D>(Sinv[k], V[k], T);
+      V[k] = T;
+      W[k] = G[k];
+    }
+#pragma unroll
+    for (int k = C - 3; k >= 0; --k) {
+      double t[D];
+      sym_times_vec<D>(Sinv[k], P[k], t);
+      sub_A_v<D>(t, G[k], P[k + 1]);
+#pragma unroll
+      for (int a = 0; a < D; ++a) P[k][a] = t[a];
+      Mat<D> T;
+      sym_times_mat<D>(Sinv[k], V[k], T);
+      sub_A_B<D>(T, G[k], V[k + 1]);
+      V[k] = T;
+      neg_A_B<D>(G[k], W[k + 1], W[k]);
+    }
+  }
+  // ---- c. separator row -> reduced system row
+  Sym<D> Ds; Mat<D> Us; double rs[D];
+  {
+    const int g = g0 + C - 1;
+    const bool valid = traj_ok && g < n;
+    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Qm, Q, Ds, Us, rs, acc);
+  }
+  if (C > 1) {
+    sub_At_B_sym<D>(Ds, Uprev, W[C > 1 ? C - 2 : 0]);     // D_s -= U_{C-2}^T W_{C-2}
+    sub_At_v<D>(rs, Uprev, P[C > 1 ? C - 2 : 0]);         // r_s -= U_{C-2}^T P_{C-2}
+    // first interior row of the next lane
+    Mat<D> Vn, Wn; double Pn[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      Pn[a] = cx.fetch(P[0][a], src_p);
+#pragma unroll
+      for (int c = 0; c < D; ++c) { Vn.v[a][c] = cx.fetch(V[0].v[a][c], src_p); Wn.v[a][c] = cx.fetch(W[0].v[a][c], src_p); }
+    }
+    // (Us == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
+    sub_A_B_sym<D>(Ds, Us, Vn);                           // D_s -= U_s V'_0
+    sub_A_v<D>(rs, Us, Pn);                               // r_s -= U_s P'_0
+    Mat<D> Ur;
+    neg_A_B<D>(Us, Wn, Ur);                               // U_red = -U_s W'_0
+    Us = Ur;
+  }
+  double xs[D];
+  pcr_solve<D, LPT>(cx, j, Ds, Us, rs, xs, ok);
+#pragma unroll
+  for (int a = 0; a < D; ++a) dx[C - 1][a] = xs[a];
+  // ---- d. interior rows
+  if (C > 1) {
+    double xps[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) xps[a] = cx.fetch(xs[a], src_m);      // V == 0 where there is no previous separator
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k) {
+      double t[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) t[a] = P[k][a];
+      sub_A_v<D>(t, V[k], xps);
+      sub_A_v<D>(t, W[k], xs);
+#pragma unroll
+      for (int a = 0; a < D; ++a) dx[k][a] = t[a];
+    }
+  }
+}
+
+// errors only (no assembly): sums over the lane's C rows
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
+DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF], ErrAcc& acc) {
+  constexpr int D = 2 * DOF;
+  const int lane = cx.lane();
+  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  double x_next[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) x_next[a] = cx.fetch(x[0][a], src_p);
+  Sym<D> Qm = {}, Q = {}, Dk; Mat<D> Uk; double rk[D];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = j * C + k;
+    eval_state<DOF, IO, false>(p, b, g, traj_ok && g < p.n, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, Qm, Q, Dk, Uk, rk, acc);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
+// ---------------------------------------------------------------------------------------------------
+template <int DOF, int LPT, int C, typename IO, int MODE, typename Ctx>
 DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;                 // trajectories per wavefront
   const int lane = cx.lane();
-  const int i = lane & (LPT - 1);               // state index owned by this lane
+  const int j = lane & (LPT - 1);               // lane index inside the trajectory
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
   const bool traj_ok = b < p.B;
-  const bool valid = traj_ok && (i < n);
-  const int src_m = (i >= 1) ? lane - 1 : lane;
-  const int src_p = (i + 1 < LPT) ? lane + 1 : lane;
 
-  double x[D];
+  double x[C][D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) x[a] = valid ? ld<IO>(p.th, (b * n + i) * D + a) : 0.0;
+  for (int k = 0; k < C; ++k) {
+    const int g = j * C + k;
+#pragma unroll
+    for (int a = 0; a < D; ++a) x[k][a] = (traj_ok && g < n) ? ld<IO>(p.th, (b * n + g) * D + a) : 0.0;
+  }
 
   if (MODE == MODE_EVAL) {
-    double xm[D], xp[D];
-#pragma unroll
-    for (int a = 0; a < D; ++a) { xm[a] = 0.0; xp[a] = cx.fetch(x[a], src_p); }
-    LaneEval<DOF> ev;
-    eval_state<DOF, IO, false>(p, b, i, valid, x, xm, xp, ev);
-    const double e = group_sum<LPT>(cx, ev.e), ee = group_sum<LPT>(cx, ev.eext);
-    const double usg = group_sum<LPT>(cx, ev.usg), ugp = group_sum<LPT>(cx, ev.ugp), uobs = group_sum<LPT>(cx, ev.uobs);
-    if (traj_ok && i == 0) {
+    ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+    gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, acc);
+    const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
+    const double usg = group_sum<LPT>(cx, acc.usg), ugp = group_sum<LPT>(cx, acc.ugp), uobs = group_sum<LPT>(cx, acc.uobs);
+    if (traj_ok && j == 0) {
       if (p.err) st<IO>(p.err, b, e / p.M);
       if (p.err_ext) st<IO>(p.err_ext, b, ee / p.M);
       if (p.unw_sg) st<IO>(p.unw_sg, b, usg);
@@ -633,59 +881,64 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   int bad = 0;
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
-    double xm[D], xp[D];
-#pragma unroll
-    for (int a = 0; a < D; ++a) { xm[a] = cx.fetch(x[a], src_m); xp[a] = cx.fetch(x[a], src_p); }
-    LaneEval<DOF> ev;
-    eval_state<DOF, IO, true>(p, b, i, valid, x, xm, xp, ev);
-    const double e = group_sum<LPT>(cx, ev.e), ee = group_sum<LPT>(cx, ev.eext);
-    double dx[D];
+    ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double dx[C][D];
     bool ok = true;
-    pcr_solve<D, LPT>(cx, i, ev.Dm, ev.U, ev.r, dx, ok);
-    bad |= (valid && !ok) ? 1 : 0;
+    gn_linear_solve<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, dx, acc, ok);
+    const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
+    bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
-      if (valid) {
 #pragma unroll
-        for (int a = 0; a < D; ++a) st<IO>(p.dtheta, (b * n + i) * D + a, dx[a]);
+      for (int k = 0; k < C; ++k) {
+        const int g = j * C + k;
+        if (traj_ok && g < n) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) st<IO>(p.dtheta, (b * n + g) * D + a, dx[k][a]);
+        }
       }
-      if (traj_ok && i == 0) {
+      if (traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, e / p.M);
         if (p.err_ext) st<IO>(p.err_ext, b, ee / p.M);
       }
     } else {
       double s2 = 0.0;
 #pragma unroll
-      for (int a = 0; a < D; ++a) s2 += valid ? dx[a] * dx[a] : 0.0;
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) s2 += (traj_ok && j * C + k < n) ? dx[k][a] * dx[k][a] : 0.0;
       s2 = group_sum<LPT>(cx, s2);
       if (active) {
-        if (i == 0) {
+        if (j == 0) {
           if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, e / p.M);
           if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, ee / p.M);
         }
 #pragma unroll
-        for (int a = 0; a < D; ++a) x[a] += valid ? dx[a] : 0.0;         // th_new = th_curr + dtheta (:144)
+        for (int k = 0; k < C; ++k)
+#pragma unroll
+          for (int a = 0; a < D; ++a) x[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;      // th_new = th_curr + dtheta (:144)
         my_iters = it + 1;
-        if (sqrt(s2) < p.tol_delta) active = false;                      // planner_utils.py:4
+        if (sqrt(s2) < p.tol_delta) active = false;                                    // planner_utils.py:4
       }
       if (!cx.any(active)) break;
     }
   }
   bad = group_or<LPT>(cx, bad);
-  if (p.info && traj_ok && i == 0) p.info[b] = bad;
+  if (p.info && traj_ok && j == 0) p.info[b] = bad;
   if (MODE == MODE_SOLVE) {
-    if (valid) {
 #pragma unroll
-      for (int a = 0; a < D; ++a) st<IO>(p.th_out, (b * n + i) * D + a, x[a]);
+    for (int k = 0; k < C; ++k) {
+      const int g = j * C + k;
+      if (traj_ok && g < n) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) st<IO>(p.th_out, (b * n + g) * D + a, x[k][a]);
+      }
     }
-    if (traj_ok && i == 0 && p.iters) p.iters[b] = my_iters;
+    if (traj_ok && j == 0 && p.iters) p.iters[b] = my_iters;
     if (p.err_final) {
-      double xm[D], xp[D];
-#pragma unroll
-      for (int a = 0; a < D; ++a) { xm[a] = 0.0; xp[a] = cx.fetch(x[a], src_p); }
-      LaneEval<DOF> ev;
-      eval_state<DOF, IO, false>(p, b, i, valid, x, xm, xp, ev);
-      const double e = group_sum<LPT>(cx, ev.e);
-      if (traj_ok && i == 0) st<IO>(p.err_final, b, e / p.M);
+      ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+      gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, acc);
+      const double e = group_sum<LPT>(cx, acc.e);
+      if (traj_ok && j == 0) st<IO>(p.err_final, b, e / p.M);
     }
   }
 }

@@ -57,7 +57,7 @@ struct HostCtx {
   }
 };
 
-template <int DOF, int LPT, typename IO>
+template <int DOF, int LPT, int C, typename IO>
 void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int wave) {
   WaveShared ws;
   pthread_barrier_init(&ws.bar, nullptr, 64);
@@ -65,31 +65,35 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
   for (int l = 0; l < 64; ++l) {
     th.emplace_back([&, l]() {
       HostCtx cx{&ws, l, wave};
-      if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_STEP>(p, cx);
-      else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_SOLVE>(p, cx);
-      else if (mode == dgp::MODE_EVAL) dgp::gn_lane_program<DOF, LPT, IO, dgp::MODE_EVAL>(p, cx);
-      else dgp::gn_backward_lane_program<DOF, LPT, IO>(p, *g, cx);
+      if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP>(p, cx);
+      else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE>(p, cx);
+      else if (mode == dgp::MODE_EVAL) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL>(p, cx);
+      else if (C == 1) dgp::gn_backward_lane_program<DOF, LPT, IO>(p, *g, cx);
     });
   }
   for (auto& t : th) t.join();
   pthread_barrier_destroy(&ws.bar);
 }
 
+#define EMUL_FOR_EACH_SHAPE(X) X(16, 1) X(32, 1) X(64, 1) X(16, 2) X(32, 2) X(64, 2) X(16, 4) X(32, 4) X(64, 4)
+
 template <int DOF, typename IO>
-void run_all(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int lpt) {
-  const int tpw = 64 / lpt;
+void run_all(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, DgpShape sh) {
+  const int tpw = 64 / sh.lpt;
   const int waves = (p.B + tpw - 1) / tpw;
   for (int w = 0; w < waves; ++w) {
-    if (lpt == 16) run_wave<DOF, 16, IO>(p, g, mode, w);
-    else if (lpt == 32) run_wave<DOF, 32, IO>(p, g, mode, w);
-    else run_wave<DOF, 64, IO>(p, g, mode, w);
+#define EMUL_CASE(L, CC) if (sh.lpt == L && sh.c == CC) run_wave<DOF, L, CC, IO>(p, g, mode, w);
+    EMUL_FOR_EACH_SHAPE(EMUL_CASE)
+#undef EMUL_CASE
   }
 }
 
 void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
+  DgpShape sh = dgp_host::choose_shape(h, p.B);
+  if (mode == 3) sh = DgpShape{64, 1};
   const bool f64 = h->cfg.io_dtype == DGP_F64;
-  if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, h->lpt); else run_all<2, float>(p, g, mode, h->lpt); }
-  else { if (f64) run_all<3, double>(p, g, mode, h->lpt); else run_all<3, float>(p, g, mode, h->lpt); }
+  if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, sh); else run_all<2, float>(p, g, mode, sh); }
+  else { if (f64) run_all<3, double>(p, g, mode, sh); else run_all<3, float>(p, g, mode, sh); }
 }
 
 }  // namespace

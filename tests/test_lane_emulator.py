@@ -25,3 +25,57 @@ def test_emul_c4_xyh(be, golden): PC.case_c4_xyh(be, golden, 'f64')
 def test_emul_eval_errors(be, golden): PC.case_eval_errors(be, golden, 'f64')
 def test_emul_solve(be, golden): PC.case_solve(be, golden, 'f64')
 def test_emul_not_spd(be, golden): PC.case_not_spd(be, golden, 'f64')
+
+
+# ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)
+import os
+import numpy as np
+from conftest import rel_err
+from oracle import gpmp2_oracle as O
+
+
+@pytest.fixture
+def force_shape():
+  def setter(shape):
+    if shape is None: os.environ.pop('DGP_FORCE_SHAPE', None)
+    else: os.environ['DGP_FORCE_SHAPE'] = shape
+  yield setter
+  os.environ.pop('DGP_FORCE_SHAPE', None)
+
+
+@pytest.mark.parametrize('shape', ['64,1', '32,2', '16,4', '64,2', '32,4', '64,4'])
+def test_emul_shapes_n64(be, golden, force_shape, shape):
+  force_shape(shape)
+  g = golden('g3_c2mini')
+  p = PC.P2d(64)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  PC.check_step(be, p, g['th_hist'][3][:2], g['start'][:2], g['goal'][:2], sdf, 'f64',
+                ref=(g['dth_hist'][3][:2], g['err_hist'][3][:2], g['errext_hist'][3][:2]), tag='shape ' + shape)
+
+
+@pytest.mark.parametrize('shape', ['64,2', '32,4', '64,4', None])
+def test_emul_n101_reference_default_length(be, golden, force_shape, shape):
+  """n = 101 = the reference YAML's total_time_step=100 (examples/configs/gpmp2_2d_params.yaml:6): more states than lanes."""
+  force_shape(shape)
+  g = golden('g3_c1')
+  p = O.OracleParams(dof=2, total_time_step=100)
+  th0 = O.straight_line_trajb(g['start'][:, :, :2], g['goal'][:, :, :2], 10.0, 100, 2)
+  dth, err, eex, info = be.step(p, th0, g['start'], g['goal'], g['sdf'][None, None], io='f64')
+  assert rel_err(dth, g['n101_dth0']) < 1e-9 and rel_err(err, g['n101_err0'].reshape(-1)) < 1e-11 and info[0] == 0
+  assert abs(float(err[0]) - 330.436499542839) < 1e-8          # survey known-answer
+
+
+def test_emul_shapes_xyh_and_solve(be, golden, force_shape):
+  force_shape('16,2')
+  PC.case_c4_xyh(be, golden, 'f64')
+  PC.case_c3_vel(be, golden, 'f64')
+  force_shape('16,4')
+  PC.case_solve(be, golden, 'f64')
+  PC.case_eval_errors(be, golden, 'f64')
+
+
+def test_force_shape_rejects_unsupported(force_shape):
+  from dgpmp2_amd import _capi
+  force_shape('16,2')          # 32 rows < n = 64
+  with pytest.raises(_capi.DgpError):
+    _capi.Solver(harness.config_from_oracle(PC.P2d(64), 'f64'), api=harness.emul_api())
