@@ -1,20 +1,258 @@
-// gn_backward.h -- backward (adjoint) lane program of the fused Gauss-Newton step.  See DESIGN.md.
+// gn_backward.h -- backward (adjoint) lane program of the fused Gauss-Newton step.
+//
+// Forward:  dtheta = Lambda^-1 eta,  Lambda = A^T K A + delta I,  eta = A^T K b   (plan_layer.py:214-228), and
+//           err_ext = sum_f 1/2 e_f^T K_f^fix e_f / M                               (plan_layer.py:310-345).
+// The reference differentiates this with torch autograd over its dense ops; here the adjoint is written out:
+//   lambda = Lambda^-1 gbar                       (gbar = dL/d dtheta; same fused assembly + block solve, other rhs)
+//   dL = lambda^T (d eta - d Lambda dtheta) + ebar d err_ext
+// and, factor by factor (Jacobian H_f, error e_f, weight K_f; u_f = H_f lambda, rho_f = e_f - H_f dtheta):
+//   dL_f = (dH_f lambda)^T K_f rho_f + u_f^T dK_f rho_f + u_f^T K_f (de_f - dH_f dtheta).
+// Every lane recomputes the factors of its C states (nothing but dtheta is kept from the forward pass), owns the
+// gradient rows of those states (no atomics for th / qc / obs_w / eps) and scatters the SDF gradient to the four
+// bilinear taps with atomics.  Floor / clamp indices and the hinge / sign selections are piecewise constant, exactly
+// as torch autograd treats them (sdf_utils.py:64-72, obstacle_cost.py:36-37, velocity_limit_factor.py:20-23).
 #pragma once
 #include "gn_lane.h"
 
 namespace dgp {
 
-static const bool kBackwardImplemented = false;
+static const bool kBackwardImplemented = true;
 
 struct GnGradParams {
-  const void *g_dtheta, *g_err_ext;
+  const void *dtheta;                 // dtheta of the forward pass (B,n,d)
+  const void *g_dtheta, *g_err_ext;   // cotangents; either may be null (= 0)
   void *g_th, *g_start, *g_goal, *g_sdf, *g_qc, *g_obs_w, *g_eps;
   int64_t g_sdf_bstride;
 };
 
-template <int DOF, int LPT, typename IO, typename Ctx>
-DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& g, Ctx& cx) {
-  (void)p; (void)g; (void)cx;
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
+DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, Ctx& cx) {
+  constexpr int D = 2 * DOF;
+  constexpr int TPW = 64 / LPT;
+  const int lane = cx.lane();
+  const int j = lane & (LPT - 1);
+  const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
+  const int n = p.n;
+  const bool traj_ok = b < p.B;
+  const int src_m = (j >= 1) ? lane - 1 : lane;
+  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  const int g0 = j * C;
+
+  double x[C][D], gbar[C][D], lam[C][D];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = g0 + k;
+    const bool valid = traj_ok && g < n;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      x[k][a] = valid ? ld<IO>(p.th, (b * n + g) * D + a) : 0.0;
+      gbar[k][a] = (valid && gp.g_dtheta) ? ld<IO>(gp.g_dtheta, (b * n + g) * D + a) : 0.0;
+      lam[k][a] = 0.0;
+    }
+  }
+  // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
+  if (gp.g_dtheta) {
+    ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+    bool ok = true;
+    gn_linear_solve<DOF, LPT, C, IO, true>(p, cx, b, j, traj_ok, x, gbar, lam, acc, ok);
+  }
+  const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
+
+  // states / adjoints across the lane boundaries
+  double x_prev[D], x_next[D], lam_prev[D], lam_next[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    x_prev[a] = cx.fetch(x[C - 1][a], src_m); x_next[a] = cx.fetch(x[0][a], src_p);
+    lam_prev[a] = cx.fetch(lam[C - 1][a], src_m); lam_next[a] = cx.fetch(lam[0][a], src_p);
+  }
+  const double dt = p.dt;
+  Sym<D> Qf;
+  fixed_Qinv<DOF>(p, Qf);
+
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = g0 + k;
+    if (!(traj_ok && g < n)) continue;
+    const double* xk = x[k];
+    const double* xm = (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0];
+    const double* xp = (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0];
+    const double* lk = lam[k];
+    const double* lm = (k == 0) ? lam_prev : lam[k > 0 ? k - 1 : 0];
+    const double* lp = (k == C - 1) ? lam_next : lam[k < C - 1 ? k + 1 : 0];
+    double dth[D], dth_m[D], dth_p[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      dth[a] = gp.g_dtheta ? ld<IO>(gp.dtheta, (b * n + g) * D + a) : 0.0;
+      dth_m[a] = (gp.g_dtheta && g > 0) ? ld<IO>(gp.dtheta, (b * n + g - 1) * D + a) : 0.0;
+      dth_p[a] = (gp.g_dtheta && g < n - 1) ? ld<IO>(gp.dtheta, (b * n + g + 1) * D + a) : 0.0;
+    }
+    double gx[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) gx[a] = 0.0;
+
+    // ---- priors: e = mu - x, H = I, K = w I  ->  dL = w (lambda + ebar e)^T (dmu - dx)
+    if (g == 0 || g == n - 1) {
+      const bool is_start = (g == 0);
+      const void* mu = is_start ? p.start : p.goal;
+      void* gmu = is_start ? gp.g_start : gp.g_goal;
+      const double w = is_start ? p.w_s : p.w_g;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double ea = ld<IO>(mu, b * D + a) - xk[a];
+        const double t = w * (lk[a] + ebar * ea);
+        gx[a] -= t;
+        if (gmu) st<IO>(gmu, b * D + a, t);
+      }
+    }
+    // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
+    if (g < n - 1) {
+      Sym<D> Q;
+      load_Qinv<DOF, IO>(p, b, g, Q);
+      double e[D], u[D], rho[D];
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) {
+        e[a] = xp[a] - (xk[a] + dt * xk[DOF + a]);
+        e[DOF + a] = xp[DOF + a] - xk[DOF + a];
+        u[a] = (lk[a] + dt * lk[DOF + a]) - lp[a];                         // u = Phi lambda_g - lambda_{g+1}
+        u[DOF + a] = lk[DOF + a] - lp[DOF + a];
+        rho[a] = e[a] - ((dth[a] + dt * dth[DOF + a]) - dth_p[a]);         // rho = e - (Phi dth_g - dth_{g+1})
+        rho[DOF + a] = e[DOF + a] - (dth[DOF + a] - dth_p[DOF + a]);
+      }
+      // dL = u^T Q de + ebar e^T Qfix de,  de = dx_{g+1} - Phi dx_g   ->  this row's share: -Phi^T (Q u + ebar Qfix e)
+      double t[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
+        t[a] = s;
+      }
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) {
+        gx[a] -= t[a];
+        gx[DOF + a] -= dt * t[a] + t[DOF + a];
+      }
+      // dL = u^T dQ^-1 rho  ->  gradient of the covariance input, element by element as autograd over gp_factor.py:65-73
+      // gives it.  The reference solves through torch.cholesky, whose backward returns the SYMMETRISED gradient of
+      // Lambda, so the Lambda part of dL/dQ^-1 is -(u v^T + v u^T)/2 (v = H dtheta = e - rho) and the eta part is u e^T.
+      // For the symmetric covariances every mode of the reference produces this equals u rho^T in every directional
+      // derivative; matching the convention makes the tensors agree entry by entry.
+      if (gp.g_qc) {
+        double Gm[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            const double va = e[a] - rho[a], vc = e[c] - rho[c];
+            Gm[a][c] = u[a] * e[c] - 0.5 * (u[a] * vc + va * u[c]);
+          }
+        if (p.qc_mode == QC_QFULL) {
+          const int64_t base = (b * (n - 1) + g) * (D * D);
+#pragma unroll
+          for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) st<IO>(gp.g_qc, base + a * D + c, Gm[a][c]);
+        } else if (p.qc_mode == QC_PERSTATE) {
+          const int64_t base = (b * (n - 1) + g) * (DOF * DOF);
+#pragma unroll
+          for (int a = 0; a < DOF; ++a)
+#pragma unroll
+            for (int c = 0; c < DOF; ++c)
+              st<IO>(gp.g_qc, base + a * DOF + c,
+                     p.qa * Gm[a][c] + p.qb * (Gm[a][DOF + c] + Gm[DOF + a][c]) + p.qc_ * Gm[DOF + a][DOF + c]);
+        }
+      }
+    }
+    // ---- GP factor (g-1 -> g): this row's share is +(Q_{g-1} u_{g-1} + ebar Qfix e_{g-1})
+    if (g > 0) {
+      Sym<D> Q;
+      load_Qinv<DOF, IO>(p, b, g - 1, Q);
+      double e[D], u[D];
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) {
+        e[a] = xk[a] - (xm[a] + dt * xm[DOF + a]);
+        e[DOF + a] = xk[DOF + a] - xm[DOF + a];
+        u[a] = (lm[a] + dt * lm[DOF + a]) - lk[a];
+        u[DOF + a] = lm[DOF + a] - lk[DOF + a];
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
+        gx[a] += s;
+      }
+    }
+    // ---- obstacle factor: e = c, H = [hx, hy, 0..], K = omega
+    {
+      const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
+      const double w = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
+      const IO* grid = (const IO*)p.sdf + b * p.sdf_bstride;
+      double c, hx, hy;
+      ObsTaps tp;
+      obstacle_eval<IO>(p, grid, xk[0], xk[1], eps, c, hx, hy, &tp);
+      double g_eps = 0.0, g_w = 0.0;
+      if (tp.act) {
+        const double u = hx * lk[0] + hy * lk[1];
+        const double rho = c - (hx * dth[0] + hy * dth[1]);
+        const double al = w * (rho * lk[0] - u * dth[0]);        // coefficient of d hx
+        const double be = w * (rho * lk[1] - u * dth[1]);        // coefficient of d hy
+        const double ga = u * w + ebar * p.obs_w_fix * c;        // coefficient of d c  (c = eps + r - dist)
+        const double ir = 1.0 / p.res;
+        // hx = (wja (d21-d11) + wjb (d22-d12)) / res ; hy = -(wjc (d12-d11) + wjd (d22-d21)) / res ; px = ox + x/res ; py = oy - y/res
+        gx[0] += be * (-tp.cross * ir * ir) - ga * hx;
+        gx[1] += al * (-tp.cross * ir * ir) - ga * hy;
+        g_eps = ga;
+        g_w = u * rho;
+        if (gp.g_sdf) {
+          IO* gs = (IO*)gp.g_sdf + b * gp.g_sdf_bstride;
+          const double wa = tp.wjc * tp.wja, wb = tp.wjd * tp.wja, wc = tp.wjc * tp.wjb, wd = tp.wjd * tp.wjb;
+          cx.atomic_add(gs + tp.i11, (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa));
+          cx.atomic_add(gs + tp.i21, (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb));
+          cx.atomic_add(gs + tp.i12, (IO)(al * (-tp.wjb * ir) + be * (-tp.wjc * ir) - ga * wc));
+          cx.atomic_add(gs + tp.i22, (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd));
+        }
+      }
+      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
+      if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, g_w);
+    }
+    // ---- velocity limits: e = |v| - vmax, H = -sign(v) (piecewise constant), K = w_v
+    if (p.flags & FLAG_VEL_LIMITS) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const double v = xk[DOF + a];
+        const double av = fabs(v);
+        if (av >= p.vmax[a]) {
+          const double sg = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+          const double c = av - p.vmax[a];
+          const double u = -sg * lk[DOF + a];
+          gx[DOF + a] += p.w_v * (u + ebar * c) * sg;            // d c / d v = sign(v)
+        }
+      }
+    }
+    // ---- non-holonomic: e = vy cos - vx sin, H = [0,0,h2,h3,h4,0] as the reference writes it, K = w_d
+    if constexpr (DOF == 3) if (p.flags & FLAG_NONHOLONOMIC) {
+      const double th = xk[2], vx = xk[DOF], vy = xk[DOF + 1];
+      const double sn = sin(th), cs = cos(th);
+      const double e = vy * cs - vx * sn;
+      const double h2 = -vy * sn + vx * cs, h3 = -sn, h4 = cs;
+      const double u = h2 * lk[2] + h3 * lk[3] + h4 * lk[4];
+      const double rho = e - (h2 * dth[2] + h3 * dth[3] + h4 * dth[4]);
+      // dL = w_d [ sum_k (rho lambda_k - u dth_k) dh_k + (u + ebar e) de ]
+      const double a2 = p.w_d * (rho * lk[2] - u * dth[2]);
+      const double a3 = p.w_d * (rho * lk[3] - u * dth[3]);
+      const double a4 = p.w_d * (rho * lk[4] - u * dth[4]);
+      const double ae = p.w_d * (u + ebar * e);
+      // d/dtheta: h2 -> -vy cos - vx sin, h3 -> -cos, h4 -> -sin, e -> -vy sin - vx cos
+      gx[2] += a2 * (-vy * cs - vx * sn) + a3 * (-cs) + a4 * (-sn) + ae * (-vy * sn - vx * cs);
+      gx[DOF] += a2 * cs + ae * (-sn);                             // d/dvx: h2 -> cos, e -> -sin
+      gx[DOF + 1] += a2 * (-sn) + ae * cs;                         // d/dvy: h2 -> -sin, e -> cos
+    }
+    if (gp.g_th) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) st<IO>(gp.g_th, (b * n + g) * D + a, gx[a]);
+    }
+  }
 }
 
 }  // namespace dgp

@@ -1,0 +1,71 @@
+// gn_device.h -- device lane context and kernel entry points (HIP only).
+#pragma once
+#include <hip/hip_runtime.h>
+#ifndef DGP_HD
+#define DGP_HD __host__ __device__ __forceinline__
+#endif
+#include "dgp_host.h"
+
+namespace dgp_dev {
+
+// Device lane context: cross-lane fetches are ds_bpermute (any lane -> any lane inside the wavefront; the LDS
+// crossbar is used, no LDS memory is touched).
+struct DevCtx {
+  __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
+  __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+  __device__ __forceinline__ int fetch_i(int v, int src) const { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+  __device__ __forceinline__ double fetch(double v, int src) const {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+    return __hiloint2double(hi, lo);
+  }
+  __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }
+  __device__ __forceinline__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
+  __device__ __forceinline__ void atomic_add(double* p, double v) const { atomicAdd(p, v); }
+};
+
+template <int DOF, int LPT, int C, typename IO, int MODE>
+__global__ void __launch_bounds__(64) gn_kernel(const dgp::GnParams p) {
+  DevCtx cx;
+  dgp::gn_lane_program<DOF, LPT, C, IO, MODE>(p, cx);
+}
+
+template <int DOF, int LPT, int C, typename IO>
+__global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
+  DevCtx cx;
+  dgp::gn_backward_lane_program<DOF, LPT, C, IO>(p, g, cx);
+}
+
+// every (LPT, C) of dgp_host::shape_supported
+#define DGP_FOR_EACH_SHAPE(X) X(16, 1) X(32, 1) X(64, 1) X(16, 2) X(32, 2) X(64, 2) X(16, 4) X(32, 4) X(64, 4)
+
+// mode: dgp::MODE_* or MODE_BACKWARD
+enum { MODE_BACKWARD = 3 };
+
+template <int DOF, typename IO>
+hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
+  const int tpw = 64 / sh.lpt;
+  const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
+#define DGP_CASE(L, CC)                                                                                                   \
+  if (sh.lpt == L && sh.c == CC) {                                                                                         \
+    switch (mode) {                                                                                                        \
+      case dgp::MODE_STEP: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP>), grid, block, 0, s, p); break;   \
+      case dgp::MODE_SOLVE: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE>), grid, block, 0, s, p); break; \
+      case dgp::MODE_EVAL: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL>), grid, block, 0, s, p); break;   \
+      default: hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO>), grid, block, 0, s, p, *g); break;                  \
+    }                                                                                                                      \
+    return hipGetLastError();                                                                                              \
+  }
+  DGP_FOR_EACH_SHAPE(DGP_CASE)
+#undef DGP_CASE
+  return hipErrorInvalidValue;
+}
+
+}  // namespace dgp_dev
+
+// One translation unit per (dof, io dtype) -- see gn_inst.hip -- so that the 4 x 36 kernels build in parallel.
+hipError_t dgp_launch_2_f32(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+hipError_t dgp_launch_2_f64(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+hipError_t dgp_launch_3_f32(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+hipError_t dgp_launch_3_f64(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);

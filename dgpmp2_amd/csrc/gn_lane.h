@@ -181,9 +181,17 @@ template <typename IO> DGP_HD void st(void* p, int64_t i, double v) { ((IO*)p)[i
 // the `dist <= eps + r` decision equals the CPU oracle's on identical inputs).
 //   utils/sdf_utils.py:57-94, gpmp2/obstacle/obstacle_cost.py:30,36-37
 // ---------------------------------------------------------------------------------------------------
+// Everything the backward needs from one bilinear lookup (same arithmetic as obstacle_eval below).
+struct ObsTaps {
+  int64_t i11, i21, i12, i22;      // element offsets of the four taps inside the grid
+  double wja, wjb, wjc, wjd;       // (fy2-py), (py-fy1), (fx2-px), (px-fx1)
+  double cross;                    // d22 - d12 - d21 + d11
+  bool act;
+};
+
 template <typename IO>
 DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y, double eps, double& cost, double& hx,
-                          double& hy) {
+                          double& hy, ObsTaps* taps = nullptr) {
 #pragma clang fp contract(off)
   const double res = p.res;
   double px = p.orig_px + x / res;                        // :61
@@ -219,6 +227,12 @@ DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y,
   cost = act ? (eps_tot - dist) : 0.0;
   hx = act ? (-1.0 * Jx) : 0.0;                           // :37
   hy = act ? (-1.0 * Jy) : 0.0;
+  if (taps) {
+    taps->i11 = y1 * W + x1; taps->i21 = y1 * W + x2; taps->i12 = y2 * W + x1; taps->i22 = y2 * W + x2;
+    taps->wja = fy2 - py; taps->wjb = py - fy1; taps->wjc = fx2 - px; taps->wjd = px - fx1;
+    taps->cross = d22 - d12 - d21 + d11;
+    taps->act = act;
+  }
 }
 
 // Q^-1 of one GP factor (gp_factor.py:65-73 / plan_layer.py:90)
@@ -433,7 +447,7 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
     }
   }
   // ---- non-holonomic factor (nonholonomic_factor.py:16-30), state [x,y,th,vx,vy,w]; H as the reference writes it
-  if (DOF == 3 && (p.flags & FLAG_NONHOLONOMIC)) {
+  if constexpr (DOF == 3) if (p.flags & FLAG_NONHOLONOMIC) {
     const double th = x[2], vx = x[DOF], vy = x[DOF + 1];
     const double sn = sin(th), cs = cos(th);
     const double e = vy * cs - vx * sn;
@@ -695,9 +709,9 @@ DGP_HD int group_or(Ctx& cx, int v) {
 //  d. x_ps is fetched from the previous lane and the interior rows follow from b.
 // With C == 1 there are no interior rows and this is plain block PCR on the original system.
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, int C, typename IO, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, typename Ctx>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
-                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
+                            const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
   constexpr int D = 2 * DOF;
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
   const int lane = cx.lane();
@@ -724,6 +738,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const bool valid = traj_ok && g < n;
     Sym<D> Dk; Mat<D> Uk; double rk[D];
     eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Qm, Q, Dk, Uk, rk, acc);
+    if (RHS_OVERRIDE) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
+    }
     if (k == 0) {
       // left spike Zl_0 = L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
       const bool has_prev = valid && g > 0;
@@ -781,6 +799,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const int g = g0 + C - 1;
     const bool valid = traj_ok && g < n;
     eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Qm, Q, Ds, Us, rs, acc);
+    if (RHS_OVERRIDE) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) rs[a] = valid ? rhs[C - 1][a] : 0.0;
+    }
   }
   if (C > 1) {
     sub_At_B_sym<D>(Ds, Uprev, W[C > 1 ? C - 2 : 0]);     // D_s -= U_{C-2}^T W_{C-2}
@@ -884,7 +906,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, dx, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, false>(p, cx, b, j, traj_ok, x, x, dx, acc, ok);
     const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {

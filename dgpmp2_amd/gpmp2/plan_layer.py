@@ -79,7 +79,7 @@ class _GNStep(torch.autograd.Function):
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
     ctx.layer = layer
     ctx.static = static
-    ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps)
+    ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)
     ctx.keep = (sdf_keep, cov_keep)
     ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
     return dth, err, eex
@@ -87,7 +87,7 @@ class _GNStep(torch.autograd.Function):
   @staticmethod
   def backward(ctx, g_dth, g_err, g_eex):
     layer = ctx.layer
-    th, start, goal, sdf, qc, ow, eps = ctx.saved_tensors
+    th, start, goal, sdf, qc, ow, eps, dth = ctx.saved_tensors
     B, n, d = th.shape
     solver = layer._solver(th.dtype)
     sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype)
@@ -106,7 +106,7 @@ class _GNStep(torch.autograd.Function):
     g_ow = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[6] and covs.obs_w) else None
     g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[7] and covs.eps) else None
     p = lambda t: None if t is None else t.data_ptr()
-    solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, p(g_dth), p(g_eex), p(g_th), p(g_st),
+    solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
                             p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream())
     if g_sdf is not None and shared and sdf.shape[0] != 1:
       g_sdf = g_sdf.expand(sdf.shape)             # autograd sums an expanded grad back onto the shared grid

@@ -140,14 +140,15 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch,
 
 /* Backward of dgp_gn_step (the reference gets it from torch autograd over plan_layer.py:152-234;
  * consumers: learning/train_planner.py:366-374, examples/diff_gpmp2_2d_example.py:77).
- * Given g_dtheta = dL/d(dtheta) (B,n,d) and g_err_ext = dL/d(err_ext) (B) (either may be NULL = 0),
- * recomputes the step and writes dL/d{th,start,goal} (same shapes), dL/d(qc_inv) (shape of the
- * qc_mode), dL/d(obs_w), dL/d(eps) (B,n), and ACCUMULATES dL/d(sdf) into g_sdf with atomics
- * (g_sdf has the layout described by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped. */
+ * Given the forward inputs, the forward output dtheta (B,n,d), g_dtheta = dL/d(dtheta) (B,n,d) and
+ * g_err_ext = dL/d(err_ext) (B) (either cotangent may be NULL = 0; dtheta may be NULL iff g_dtheta is),
+ * re-assembles the system, solves the adjoint system Lambda lambda = g_dtheta and writes dL/d{th,start,goal}
+ * (same shapes), dL/d(qc_inv) (shape of the qc_mode), dL/d(obs_w), dL/d(eps) (B,n), and ACCUMULATES dL/d(sdf)
+ * into g_sdf with atomics (layout given by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped. */
 int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          const void* th, const void* start, const void* goal,
                          const DgpSdf* sdf, const DgpCovs* covs,
-                         const void* g_dtheta, const void* g_err_ext,
+                         const void* dtheta, const void* g_dtheta, const void* g_err_ext,
                          void* g_th, void* g_start, void* g_goal,
                          void* g_sdf, int64_t g_sdf_batch_stride,
                          void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);

@@ -68,7 +68,7 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
       if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP>(p, cx);
       else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE>(p, cx);
       else if (mode == dgp::MODE_EVAL) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL>(p, cx);
-      else if (C == 1) dgp::gn_backward_lane_program<DOF, LPT, IO>(p, *g, cx);
+      else dgp::gn_backward_lane_program<DOF, LPT, C, IO>(p, *g, cx);
     });
   }
   for (auto& t : th) t.join();
@@ -89,8 +89,7 @@ void run_all(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, DgpSh
 }
 
 void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
-  DgpShape sh = dgp_host::choose_shape(h, p.B);
-  if (mode == 3) sh = DgpShape{64, 1};
+  const DgpShape sh = dgp_host::choose_shape(h, p.B);
   const bool f64 = h->cfg.io_dtype == DGP_F64;
   if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, sh); else run_all<2, float>(p, g, mode, sh); }
   else { if (f64) run_all<3, double>(p, g, mode, sh); else run_all<3, float>(p, g, mode, sh); }
@@ -137,14 +136,14 @@ int emul_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const vo
 }
 
 int emul_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
-                          const DgpCovs* covs, const void* g_dtheta, const void* g_err_ext, void* g_th, void* g_start, void* g_goal,
-                          void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w, void* g_eps, void*) {
+                          const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
+                          void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w,
+                          void* g_eps, void*) {
   dgp::GnParams p;
   dgp::GnGradParams g;
-  int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
+  int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
                                    g_sdf_batch_stride, g_qc_inv, g_obs_w, g_eps, p, g);
   if (rc != DGP_OK) return rc;
-  if (!dgp::kBackwardImplemented) return dgp_host::fail(DGP_EUNSUPPORTED, "backward is not implemented yet");
   run(h, p, &g, 3);
   return DGP_OK;
 }

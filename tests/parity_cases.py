@@ -215,5 +215,92 @@ def case_not_spd(be, golden, io):
   assert np.all(info == 1)
 
 
+def case_backward_golden(be, golden, io):
+  """Backward of one GN step vs the reference's torch autograd (fixture g5_grads: per-state covariances, per-sample
+  SDF copies): cotangent on dtheta, then cotangent on err_ext (whose grads w.r.t. qc / obs_w are None in the reference)."""
+  g = golden('g5_grads')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  tol = 1e-8 if io == 'f64' else 2e-4
+  th, st, go, sdf = rnd(g['th'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io)
+  qc, ow, eps = rnd(g['qc'], io), rnd(g['ow'].reshape(B, n), io), rnd(g['eps'].reshape(B, n), io)
+  dth, _, _, _ = be.step(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
+  r = be.backward(p, th, st, go, sdf, dth, rnd(g['gbar'], io), None, qc=qc, ow=ow, eps=eps, io=io)
+  for k in ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps'):
+    assert rel_err(r[k].reshape(g['g_' + k].shape), g['g_' + k]) < tol, ('g_' + k, rel_err(r[k].reshape(g['g_' + k].shape), g['g_' + k]))
+  r = be.backward(p, th, st, go, sdf, None, None, rnd(g['gext'].reshape(B), io), qc=qc, ow=ow, eps=eps, io=io)
+  for k in ('th', 'sdf', 'start', 'goal', 'eps'):
+    assert rel_err(r[k].reshape(g['ge_' + k].shape), g['ge_' + k]) < (1e-10 if io == 'f64' else 1e-5), 'ge_' + k
+  assert bool(g['ge_none_qc']) and bool(g['ge_none_ow']) and np.all(r['qc'] == 0) and np.all(r['ow'] == 0)
+  assert not bool(g['err_requires_grad'])
+
+
+def _fd_loss(p, th, st, go, sdf, gbar, gext, qc=None, ow=None, eps=None, q_full=False):
+  B = th.shape[0]
+  sq, so, se = p.static_covs(B)
+  dth, _, eex = O.plan_layer_forward(th, st, go, np.broadcast_to(sdf, (B,) + sdf.shape[1:]), sq if qc is None else qc,
+                                     so if ow is None else ow.reshape(so.shape), se if eps is None else eps.reshape(se.shape), p, q_full=q_full)
+  return float(np.sum(gbar * dth) + np.sum(gext * eex.reshape(-1)))
+
+
+def case_backward_fd(be, golden, io):
+  """Backward vs central finite differences of the ORACLE's loss sum(gbar*dtheta) + sum(gext*err_ext), for the
+  configurations the reference cannot differentiate in batch: velocity limits (C3), non-holonomic xyh (C4, d=6),
+  static covariances with a shared SDF, and full Q^-1 input (q_full)."""
+  if io != 'f64': return
+  rs = np.random.RandomState(11)
+
+  def check(p, th, st, go, sdf, qc=None, q_full=False, nprobe=14):
+    B, n, d = th.shape
+    gbar = rs.randn(B, n, d); gext = rs.randn(B)
+    dth, _, _, _ = be.step(p, th, st, go, sdf, qc=qc, q_full=q_full, io='f64')
+    r = be.backward(p, th, st, go, sdf, dth, gbar, gext, qc=qc, q_full=q_full, io='f64')
+    h = 1e-6
+    for name, arr, grad in (('th', th, r['th']), ('start', st, r['start']), ('goal', go, r['goal'])) + \
+                           ((('qc', qc, r['qc']),) if qc is not None else ()):
+      flat = arr.reshape(-1)
+      idx = rs.choice(flat.size, min(nprobe, flat.size), replace=False)
+      for i in idx:
+        if name == 'qc' and q_full:
+          # symmetric perturbation (the kernel reads Q^-1 as a symmetric matrix): move (a,c) and (c,a) together
+          a4 = np.unravel_index(i, arr.shape); a4t = a4[:2] + (a4[3], a4[2])
+          ap, am = arr.copy(), arr.copy()
+          ap[a4] += h; am[a4] -= h
+          if a4 != a4t: ap[a4t] += h; am[a4t] -= h
+          gsum = grad[a4] + (grad[a4t] if a4 != a4t else 0.0)
+        else:
+          ap, am = arr.copy().reshape(-1), arr.copy().reshape(-1)
+          ap[i] += h; am[i] -= h
+          ap, am = ap.reshape(arr.shape), am.reshape(arr.shape)
+          gsum = grad.reshape(-1)[i]
+        args = dict(th=th, st=st, go=go, qc=qc)
+        kp = dict(args); km = dict(args)
+        key = {'th': 'th', 'start': 'st', 'goal': 'go', 'qc': 'qc'}[name]
+        kp[key] = ap; km[key] = am
+        fd = (_fd_loss(p, kp['th'], kp['st'], kp['go'], sdf, gbar, gext, qc=kp['qc'], q_full=q_full) -
+              _fd_loss(p, km['th'], km['st'], km['go'], sdf, gbar, gext, qc=km['qc'], q_full=q_full)) / (2 * h)
+        scale = max(1.0, float(np.abs(grad).max()))
+        assert abs(fd - gsum) < 2e-5 * scale, (name, int(i), fd, float(gsum))
+
+  g = golden('g3_c3_vel')
+  n = g['th'].shape[1]
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  check(O.OracleParams(dof=2, total_time_step=n - 1, use_vel_limits=True), g['th'][:2], g['start'][:2], g['goal'][:2], sdf)
+  g = golden('g3_c4_xyh')
+  n = g['th'].shape[1]
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  check(O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, epsilon_dist=0.2, reg=0.0), g['th'][:2], g['start'][:2],
+        g['goal'][:2], sdf)
+  g = golden('g5_grads')
+  n = g['th'].shape[1]
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  p = P2d(n)
+  check(p, g['th'][:2], g['start'][:2], g['goal'][:2], sdf)                                    # static covariances, shared SDF
+  Qf = O.calc_Q_inv_batch(g['qc'][:2], p.dt)
+  check(p, g['th'][:2], g['start'][:2], g['goal'][:2], sdf, qc=Qf, q_full=True, nprobe=10)     # q_full
+
+
 ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, case_c1, case_small_ragged, case_edges,
-             case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd]
+             case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd, case_backward_golden, case_backward_fd]

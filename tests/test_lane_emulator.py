@@ -25,6 +25,9 @@ def test_emul_c4_xyh(be, golden): PC.case_c4_xyh(be, golden, 'f64')
 def test_emul_eval_errors(be, golden): PC.case_eval_errors(be, golden, 'f64')
 def test_emul_solve(be, golden): PC.case_solve(be, golden, 'f64')
 def test_emul_not_spd(be, golden): PC.case_not_spd(be, golden, 'f64')
+def test_emul_backward_golden(be, golden): PC.case_backward_golden(be, golden, 'f64')
+def test_emul_backward_golden_f32(be, golden): PC.case_backward_golden(be, golden, 'f32')
+def test_emul_backward_fd(be, golden): PC.case_backward_fd(be, golden, 'f64')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)
@@ -79,3 +82,9 @@ def test_force_shape_rejects_unsupported(force_shape):
   force_shape('16,2')          # 32 rows < n = 64
   with pytest.raises(_capi.DgpError):
     _capi.Solver(harness.config_from_oracle(PC.P2d(64), 'f64'), api=harness.emul_api())
+
+
+@pytest.mark.parametrize('shape', ['16,2', '16,4', '32,2'])
+def test_emul_backward_shapes(be, golden, force_shape, shape):
+  force_shape(shape)
+  PC.case_backward_golden(be, golden, 'f64')

@@ -145,3 +145,89 @@ def test_get_covariances_shapes():
   out = torch.randn(2, 1, (n - 1) + 2 * n, device=DEV, dtype=torch.float64)
   qc, ow, eps = planner.get_covariances(out, 'diag_identity', learn_eps=True)
   assert qc.shape == (2, n - 1, 2, 2) and eps.shape == (2, n, 1, 1) and float(qc[0, 0, 0, 1]) == 0.0
+
+
+# ---- autograd through the planner API: reference = torch autograd over plan_layer.py:152-234 ----------
+def test_autograd_matches_reference_grads(golden):
+  """Same experiment as tests/golden/make_golden.py::g5_grads, through dgpmp2_amd's PlanLayer and torch.autograd."""
+  g = golden('g5_grads')
+  B, n, G = 4, 16, int(g['G'])
+  planner = make_planner(n, B)
+  leaves = {}
+  for k in ('th', 'start', 'goal', 'qc', 'ow', 'eps'):
+    leaves[k] = T(g[k]).requires_grad_(True)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1).requires_grad_(True)
+  dth, err, err_ext = planner.plan_layer(leaves['th'], leaves['start'], leaves['goal'], (sdf.detach() > 0).double(), sdf, leaves['qc'],
+                                         leaves['ow'], leaves['eps'])
+  assert not err.requires_grad and err_ext.requires_grad and dth.requires_grad
+  names = ('th', 'start', 'goal', 'qc', 'ow', 'eps')
+  grads = torch.autograd.grad((T(g['gbar']) * dth).sum(), [leaves[k] for k in names] + [sdf], retain_graph=True)
+  for k, gr in zip(names + ('sdf',), grads):
+    assert rel_err(gr.cpu().numpy(), g['g_' + k]) < 1e-8, k
+  grads_e = torch.autograd.grad((T(g['gext']) * err_ext).sum(), [leaves[k] for k in names] + [sdf], allow_unused=True)
+  for k, gr in zip(names + ('sdf',), grads_e):
+    if bool(g['ge_none_' + k]):
+      assert gr is None or float(gr.abs().max()) == 0.0, k       # reference: None (fixed covariances, plan_layer.py:318,330)
+    else:
+      assert rel_err(gr.cpu().numpy(), g['ge_' + k]) < 1e-10, k
+
+
+def test_autograd_shared_sdf_expand_and_static_covs(golden):
+  """Static covariances (step()), one SDF expand()ed over the batch: the SDF gradient is the sum over the batch."""
+  g = golden('g5_grads')
+  B, n, G = 4, 16, int(g['G'])
+  planner = make_planner(n, B)
+  sdf1 = T(O.circles_sdf(G, g['circles']))[None, None].requires_grad_(True)
+  th = T(g['th']).requires_grad_(True)
+  dth, _, err, err_ext, _, _, _ = planner.step(th, T(g['start']), T(g['goal']), None, sdf1.expand(B, 1, G, G))
+  loss = (T(g['gbar']) * dth).sum() + err_ext.sum()
+  loss.backward()
+  # same thing with materialised per-sample copies
+  sdfB = sdf1.detach().repeat(B, 1, 1, 1).requires_grad_(True)
+  th2 = T(g['th']).requires_grad_(True)
+  dth2, _, _, err_ext2, _, _, _ = planner.step(th2, T(g['start']), T(g['goal']), None, sdfB)
+  ((T(g['gbar']) * dth2).sum() + err_ext2.sum()).backward()
+  assert rel_err(th.grad.cpu().numpy(), th2.grad.cpu().numpy()) < 1e-12
+  assert rel_err(sdf1.grad.cpu().numpy(), sdfB.grad.sum(0, keepdim=True).cpu().numpy()) < 1e-10
+
+
+def test_tbptt_outer_loop_runs(golden):
+  """The shape of the reference's learning loop (learning/train_planner.py:297-374): detach -> step -> th + dtheta ->
+  loss on the new trajectory -> backward, with learnable per-state obstacle weights and epsilons feeding the solver."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  start, goal = T(g['start']), T(g['goal'])
+  log_w = torch.full((B, n, 1, 1), float(np.log(1e4)), dtype=torch.float64, device=DEV, requires_grad=True)
+  eps = torch.full((B, n, 1, 1), 0.4, dtype=torch.float64, device=DEV, requires_grad=True)
+  qc = torch.eye(2, dtype=torch.float64, device=DEV).expand(B, n - 1, 2, 2).contiguous()
+  opt = torch.optim.SGD([log_w, eps], lr=1e-3)
+  th = T(g['th_hist'][0])
+  losses = []
+  for t in range(3):
+    th_curr = th.detach().requires_grad_(True)
+    dth, err, err_ext = planner.plan_layer(th_curr, start, goal, None, sdf, qc, log_w.exp(), eps)
+    th_new = th_curr + dth
+    loss = ((th_new - T(g['th_hist'][10])) ** 2).mean() + 1e-3 * planner.error_ext_batch(th_new, sdf).mean()
+    opt.zero_grad(); loss.backward(); opt.step()
+    assert torch.isfinite(log_w.grad).all() and float(log_w.grad.abs().max()) > 0 and float(eps.grad.abs().max()) > 0
+    assert th_curr.grad is not None
+    losses.append(float(loss)); th = th_new
+  assert all(np.isfinite(losses))
+
+
+def test_forward_with_grad_keeps_graph_across_iterations(golden):
+  """examples/diff_gpmp2_2d_example.py:77: th_final.backward(...) through the whole forward()."""
+  from dgpmp2_amd.utils.planner_utils import straight_line_traj
+  c1 = golden('g3_c1')
+  planner = make_planner(32, 1, max_iters=3)
+  start, goal = T(c1['start'][0]), T(c1['goal'][0])
+  th_init = straight_line_traj(start[:, :2], goal[:, :2], 10.0, 31, 2, DEV).requires_grad_(True)
+  sdf = T(c1['sdf'])
+  out = planner.forward(th_init.unsqueeze(0), start.unsqueeze(0), goal.unsqueeze(0), None, sdf.unsqueeze(0).unsqueeze(0))
+  th_final = out[0]
+  assert out[6] == [3] and th_final.requires_grad
+  assert rel_err(th_final.detach().cpu().numpy(), c1['th_hist'][3]) < 1e-9
+  th_final.backward(torch.randn(th_final.shape, dtype=torch.float64, device=DEV))
+  assert th_init.grad is not None and bool(torch.isfinite(th_init.grad).all()) and float(th_init.grad.abs().max()) > 0
