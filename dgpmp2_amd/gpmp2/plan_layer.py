@@ -109,7 +109,9 @@ class _GNStep(torch.autograd.Function):
     solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
                             p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream())
     if g_sdf is not None and shared and sdf.shape[0] != 1:
-      g_sdf = g_sdf.expand(sdf.shape)             # autograd sums an expanded grad back onto the shared grid
+      # the kernel already accumulated all B trajectories into the one shared grid; autograd's expand-backward will sum
+      # the B slices of whatever is returned here, so hand it B equal shares
+      g_sdf = (g_sdf / sdf.shape[0]).expand(sdf.shape)
     r = lambda g, ref: None if g is None else g.reshape(ref.shape).to(ref.dtype)
     return (None, None, g_th, g_st, g_go, r(g_sdf, sdf) if g_sdf is not None else None, r(g_qc, qc), r(g_ow, ow), r(g_eps, eps))
 
