@@ -104,6 +104,25 @@ def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
           'torch_threads': torch.get_num_threads()}
 
 
+def cpu_blocktri(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, steps=5):
+  """"Best CPU" line: the oracle's block-tridiagonal fp64 C restatement (oracle/gn_blocktri.c, OpenMP over trajectories)
+  on the full 4096-trajectory batch, all usable cores."""
+  from oracle import blocktri as BT
+  from oracle.gpmp2_oracle import OracleParams
+  cores = usable_cores()
+  p = OracleParams(dof=DOF, total_time_step=N_STATES - 1)
+  a = lambda t: t.double().numpy()
+  st, go, sdf = a(start_cpu), a(goal_cpu), a(sdf_cpu)
+  ts = []
+  for k in range(steps + 1):
+    th = a(th_hist_cpu[k % len(th_hist_cpu)])
+    t0 = time.perf_counter(); BT.gn_step(p, th, st, go, sdf, nthreads=cores); ts.append(time.perf_counter() - t0)
+  t = float(np.median(ts[1:]))
+  return {'value': 1.0 / t, 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'kind': 'port',
+          'sample': 'block-tridiagonal fp64 C restatement (oracle/gn_blocktri.c), full 4096-trajectory batch, 1 warm-up + %d timed '
+                    'steps, median %.4f s' % (steps, t)}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -196,7 +215,9 @@ def main():
                      'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:
-      out['cpu_baseline'] = cpu_baseline([t.cpu() for t in th_hist], start.cpu(), goal.cpu(), sdf.cpu())
+      hist_cpu = [t.cpu() for t in th_hist]
+      out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())
+      out['cpu_baseline_blocktri'] = cpu_blocktri(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())
     print(json.dumps(out))
   if dist is not None:
     dist.barrier()

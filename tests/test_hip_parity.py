@@ -49,6 +49,13 @@ def test_hip_c2_full_size_properties(be, io):
   r_dth, r_err, r_eex = O.plan_layer_forward(th[idx], start[idx], goal[idx], np.broadcast_to(sdf, (64, 1, G, G)), qc, ow, eps, p)
   assert rel_err(dth[idx], r_dth) < PC.TOL[io]
   assert rel_err(err[idx], r_err.reshape(-1)) < PC.TOL_ERR[io] and rel_err(eex[idx], r_eex.reshape(-1)) < PC.TOL_ERR[io]
+  # (a') EVERY trajectory against the oracle's block-tridiagonal C restatement (oracle/gn_blocktri.c)
+  from oracle import blocktri as BT
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, nthreads=4)
+  assert not c_info.any()
+  per_traj = np.abs(dth - c_dth).reshape(B, -1).max(1) / np.abs(c_dth).reshape(B, -1).max(1)
+  assert per_traj.max() < PC.TOL[io], per_traj.max()
+  assert rel_err(err, c_err) < PC.TOL_ERR[io] and rel_err(eex, c_eex) < PC.TOL_ERR[io]
   perm = np.random.RandomState(2).permutation(B)
   dth2, err2, _, _ = be.step(p, th[perm], start[perm], goal[perm], sdf, io=io)
   assert np.array_equal(dth2, dth[perm]) and np.array_equal(err2, err[perm])

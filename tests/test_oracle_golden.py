@@ -172,3 +172,40 @@ def test_dense_torch_baseline(golden):
                                             T(g['cov_eps']), DT.params_from_oracle(p))
   assert rel_err(dth.numpy(), g['cov_dth']) < TOL
   assert rel_err(err.numpy(), g['cov_err']) < 1e-12 and rel_err(err_ext.numpy(), g['cov_errext']) < 1e-12
+
+
+def test_blocktri_c_oracle_matches_reference_and_numpy_oracle(golden):
+  """oracle/gn_blocktri.c (block-tridiagonal fp64 Thomas) vs the reference's fixtures and the dense numpy oracle."""
+  from oracle import blocktri as BT
+  g = golden('g3_c2mini')
+  B, n = 8, 64
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = O.circles_sdf(G, g['circles'])[None, None]
+  for k in (0, 5, 9):
+    dth, err, eex, info = BT.gn_step(p, g['th_hist'][k], g['start'], g['goal'], sdf, nthreads=2)
+    assert not info.any() and rel_err(dth, g['dth_hist'][k]) < TOL
+    assert rel_err(err, g['err_hist'][k].reshape(-1)) < 1e-12 and rel_err(eex, g['errext_hist'][k].reshape(-1)) < 1e-12
+  dth, err, eex, _ = BT.gn_step(p, g['cov_th'], g['start'], g['goal'], sdf, qc=g['cov_qc'], ow=g['cov_ow'].reshape(B, n),
+                                eps=g['cov_eps'].reshape(B, n))
+  assert rel_err(dth, g['cov_dth']) < TOL and rel_err(err, g['cov_err'].reshape(-1)) < 1e-12 and rel_err(eex, g['cov_errext'].reshape(-1)) < 1e-12
+  Qf = O.calc_Q_inv_batch(g['cov_qc'], p.dt)
+  dth2, _, _, _ = BT.gn_step(p, g['cov_th'], g['start'], g['goal'], sdf, qc=Qf, ow=g['cov_ow'].reshape(B, n), eps=g['cov_eps'].reshape(B, n), q_full=True)
+  assert rel_err(dth2, dth) < 1e-12
+  c1 = golden('g3_c1')
+  p101 = O.OracleParams(dof=2, total_time_step=100)
+  th0 = O.straight_line_trajb(c1['start'][:, :, :2], c1['goal'][:, :, :2], 10.0, 100, 2)
+  dth, err, _, _ = BT.gn_step(p101, th0, c1['start'], c1['goal'], c1['sdf'][None, None])
+  assert rel_err(dth, c1['n101_dth0']) < TOL and abs(err[0] - 330.436499542839) < 1e-9
+  g = golden('g3_c3_vel'); n = g['th'].shape[1]
+  dth, err, _, _ = BT.gn_step(O.OracleParams(dof=2, total_time_step=n - 1, use_vel_limits=True), g['th'], g['start'], g['goal'],
+                              O.circles_sdf(int(g['G']), g['circles'])[None, None])
+  assert rel_err(dth, g['dth']) < TOL and rel_err(err, g['err'].reshape(-1)) < 1e-12
+  g = golden('g3_c4_xyh'); n = g['th'].shape[1]
+  dth, err, _, _ = BT.gn_step(O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, epsilon_dist=0.2, reg=0.0), g['th'],
+                              g['start'], g['goal'], O.circles_sdf(int(g['G']), g['circles'])[None, None])
+  assert rel_err(dth, g['dth']) < TOL and rel_err(err, g['err'].reshape(-1)) < 1e-12
+  # not SPD -> info
+  _, _, _, info = BT.gn_step(P2d(16, reg=-1e7), golden('g2_system_n16')['th'], golden('g2_system_n16')['start'],
+                             golden('g2_system_n16')['goal'], O.circles_sdf(64, O.C2_CIRCLES)[None, None])
+  assert info.all()
