@@ -50,6 +50,16 @@ def make_inputs(B, n, G, device, seed=0):
   return f(th0), f(start), f(goal), f(sdf)
 
 
+def measured_traffic():
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic.json, produced by
+  profiles/tools/pmc_traffic.sh with the guide's gfx950 FETCH_SIZE correction); None when no such measurement is committed."""
+  f = os.path.join(ROOT, 'profiles', 'traffic.json')
+  try:
+    return float(json.load(open(f))['hbm_bytes_per_launch'])
+  except (OSError, ValueError, KeyError):
+    return None
+
+
 def usable_cores():
   """Host cores this process may really use: min(affinity, cgroup CPU quota).  (The GPU boxes expose 256 logical CPUs but
   cap the container at 16 through cgroup cpu.max; running 256 threads against that quota is ~100x slower.)"""
@@ -211,7 +221,7 @@ def main():
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
         'trajectory_steps_per_s': world * args.steps * B / elapsed,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': None, 'kernel': 'gn_kernel<DOF=2,LPT=64,float,STEP>', 'kernel_avg_ms': kernel_ms,
+                     'traffic': measured_traffic(), 'kernel': 'gn_kernel<DOF=2,LPT=%d,C=%d,float,STEP>' % solver.launch_shape(B), 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_launch': bytes_per_launch},
     }
     if world == 1 and not args.no_cpu_baseline:

@@ -48,7 +48,7 @@ class DgpError(RuntimeError):
 class CApi(object):
   """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
 
-  SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'gn_step', 'gn_solve',
+  SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'gn_step', 'gn_solve',
              'eval_errors', 'gn_step_backward')
 
   def __init__(self, path, prefix='dgp_'):
@@ -64,6 +64,8 @@ class CApi(object):
     self.create = f('create'); self.create.restype = C.c_int; self.create.argtypes = [C.POINTER(DgpConfig), C.POINTER(vp)]
     self.destroy = f('destroy'); self.destroy.restype = None; self.destroy.argtypes = [vp]
     self.num_factor_rows = f('num_factor_rows'); self.num_factor_rows.restype = C.c_int; self.num_factor_rows.argtypes = [vp]
+    self.launch_shape = f('launch_shape'); self.launch_shape.restype = C.c_int
+    self.launch_shape.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     self.gn_step = f('gn_step'); self.gn_step.restype = C.c_int
     self.gn_step.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp]
     self.gn_solve = f('gn_solve'); self.gn_solve.restype = C.c_int
@@ -132,6 +134,12 @@ class Solver(object):
     if h is not None and h.value:
       self.api.destroy(h)
       self.handle = None
+
+  def launch_shape(self, batch):
+    """(lanes per trajectory, states per lane) the kernels will run with for this batch size."""
+    l, c = C.c_int32(), C.c_int32()
+    self.api.check(self.api.launch_shape(self.handle, int(batch), C.byref(l), C.byref(c)))
+    return l.value, c.value
 
   @staticmethod
   def sdf_arg(ptr, rows, cols, batch_stride):

@@ -26,6 +26,14 @@ int dgp_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create(
 void dgp_destroy(DgpHandle* h) { delete h; }
 int dgp_num_factor_rows(const DgpHandle* h) { return h ? h->M : fail(DGP_EINVAL, "null handle"); }
 
+int dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
+  if (!h || batch <= 0) return fail(DGP_EINVAL, "null handle or non-positive batch");
+  const DgpShape sh = dgp_host::choose_shape(h, batch);
+  if (lpt) *lpt = sh.lpt;
+  if (c) *c = sh.c;
+  return DGP_OK;
+}
+
 int dgp_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                 const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void* stream) {
   dgp::GnParams p;

@@ -104,6 +104,10 @@ void dgp_destroy(DgpHandle* h);
 /* M of plan_layer.py:43-45 (rows of the dense system; the normaliser of err) for this handle. */
 int  dgp_num_factor_rows(const DgpHandle* h);
 
+/* Launch shape the library will use for a batch of `batch` trajectories: lanes per trajectory and consecutive states per
+ * lane (reporting / tuning aid; the environment variable DGP_FORCE_SHAPE="LPT,C" read by dgp_create pins it). */
+int  dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lanes_per_trajectory, int32_t* states_per_lane);
+
 /* One batched Gauss-Newton step == PlanLayer.forward (plan_layer.py:87-99):
  * factor evaluation (gp_factor.py:100-110, prior_factor.py:15-18, obstacle_factor.py:35-40 ->
  * obstacle_cost.py:29-38 -> sdf_utils.py:38-107, custom_factors/), assembly of the block-tridiagonal

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Read the rocpd databases written by pmc_traffic.sh and print per-kernel average counter values per dispatch; derive the
+HBM traffic of the GN kernel with the calibration copy's correction factors and write profiles/traffic.json."""
+import glob, json, os, sqlite3, sys
+d = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/pmc'
+vals = {}
+for f in sorted(glob.glob(os.path.join(d, '*_results.db'))):
+  cur = sqlite3.connect(f).cursor()
+  try:
+    rows = cur.execute("select k.name, p.name, count(*), avg(e.value) from pmc_events e join kernels k on k.dispatch_id = e.dispatch_id "
+                       "join pmc_info p on p.id = e.pmc_id group by k.name, p.name").fetchall()
+  except sqlite3.Error as ex:
+    print('# %s: %s' % (f, ex)); continue
+  for kname, cname, cnt, avg in rows:
+    short = 'gn_kernel' if 'gn_kernel' in kname else ('copy' if ('copy' in kname.lower() or 'Memcpy' in kname or 'elementwise' in kname) else None)
+    if short: vals.setdefault(short, {}).setdefault(cname, []).append((cnt, avg, kname[:90]))
+  for r in cur.execute("select name, count(*), avg(duration) from kernels where name like '%gn_kernel%' group by name"):
+    print('# %s: %s x%d avg %.1f ns' % (os.path.basename(f), r[0][:80], r[1], r[2]))
+for short, cs in vals.items():
+  for c, lst in sorted(cs.items()):
+    for cnt, avg, kn in lst: print('%-10s %-22s dispatches=%-4d avg=%.1f   [%s]' % (short, c, cnt, avg, kn))
+try:
+  known = 64 * 1024 * 1024 * 4            # calibration copy: bytes read == bytes written
+  cf = max(v[1] for v in vals['copy']['FETCH_SIZE']); cw = max(v[1] for v in vals['copy']['WRITE_SIZE'])
+  kf = known / (cf * 1024.0); kw = known / (cw * 1024.0)
+  gf = vals['gn_kernel']['FETCH_SIZE'][0][1]; gw = vals['gn_kernel']['WRITE_SIZE'][0][1]
+  out = {'fetch_size_kb_raw': gf, 'write_size_kb_raw': gw, 'fetch_correction': kf, 'write_correction': kw,
+         'hbm_bytes_per_launch': gf * 1024.0 * kf + gw * 1024.0 * kw,
+         'note': 'FETCH_SIZE/WRITE_SIZE (KB) of gn_kernel per dispatch, each scaled by known_bytes/reported_bytes of a 256 MiB '
+                 'float4 copy measured in the same rocprofv3 pass (MI355X_MICROARCH.md: gfx950 FETCH_SIZE under-reports wide streams 2x)'}
+  print(json.dumps(out))
+  if len(sys.argv) > 2: json.dump(out, open(sys.argv[2], 'w'), indent=1)
+except (KeyError, ValueError) as ex:
+  print('# traffic not derivable:', ex)

@@ -106,6 +106,14 @@ int emul_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create
 void emul_destroy(DgpHandle* h) { delete h; }
 int emul_num_factor_rows(const DgpHandle* h) { return h ? h->M : DGP_EINVAL; }
 
+int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
+  if (!h || batch <= 0) return DGP_EINVAL;
+  const DgpShape sh = dgp_host::choose_shape(h, batch);
+  if (lpt) *lpt = sh.lpt;
+  if (c) *c = sh.c;
+  return DGP_OK;
+}
+
 int emul_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                  const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void*) {
   dgp::GnParams p;
