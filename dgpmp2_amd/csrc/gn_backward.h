@@ -34,8 +34,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
   const bool traj_ok = b < p.B;
-  const int src_m = (j >= 1) ? lane - 1 : lane;
-  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  const Nbr<LPT, 1, Ctx> nb(cx, j);
   const int g0 = j * C;
 
   double x[C][D], gbar[C][D], lam[C][D];
@@ -62,8 +61,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   double x_prev[D], x_next[D], lam_prev[D], lam_next[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) {
-    x_prev[a] = cx.fetch(x[C - 1][a], src_m); x_next[a] = cx.fetch(x[0][a], src_p);
-    lam_prev[a] = cx.fetch(lam[C - 1][a], src_m); lam_next[a] = cx.fetch(lam[0][a], src_p);
+    x_prev[a] = nb.lo(x[C - 1][a]); x_next[a] = nb.hi(x[0][a]);
+    lam_prev[a] = nb.lo(lam[C - 1][a]); lam_next[a] = nb.hi(lam[0][a]);
   }
   const double dt = p.dt;
   Sym<D> Qf;

@@ -20,6 +20,21 @@ struct DevCtx {
     hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
     return __hiloint2double(hi, lo);
   }
+  // value of lane (l - S) / (l + S) inside the 16-lane DPP row; lanes without such a neighbour read 0 (bound_ctrl)
+  template <int S>
+  __device__ __forceinline__ double row_from_lower(double v) const {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x110 + S, 0xf, 0xf, true);      // row_shr:S
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x110 + S, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
+  template <int S>
+  __device__ __forceinline__ double row_from_upper(double v) const {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + S, 0xf, 0xf, true);      // row_shl:S
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + S, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
   __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }
   __device__ __forceinline__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
   __device__ __forceinline__ void atomic_add(double* p, double v) const { atomicAdd(p, v); }

@@ -567,113 +567,142 @@ template <int D> DGP_HD void sub_A_B(Mat<D>& O, const Mat<D>& A, const Mat<D>& B
 //     D_i' = D_i - T2 U_{i-s} - T U_i^T ;  r_i' = r_i - T2 r_{i-s} - T r_{i+s} ;  U_i' = -T U_{i+s}
 //   (the lower coupling stays the transpose of the upper one, so only U is carried).
 // ---------------------------------------------------------------------------------------------------
+// Cross-lane access helper.  With 16 lanes per trajectory every exchange stays inside one 16-lane DPP row, so the
+// neighbour at distance S is read with a DPP row shift (a plain VALU move: no LDS round trip, no s_waitcnt); wider
+// groups go through ds_bpermute.  Lanes without a neighbour receive 0 (DPP bound_ctrl) or their own value (bpermute);
+// both are harmless because the coupling block that multiplies the fetched data is zero there.
+template <int LPT, int S, typename Ctx>
+struct Nbr {
+  Ctx& cx;
+  int src_lo, src_hi;
+  DGP_HD Nbr(Ctx& c, int j) : cx(c) {
+    const int lane = c.lane();
+    src_lo = (j >= S) ? lane - S : lane;
+    src_hi = (j + S < LPT) ? lane + S : lane;
+  }
+  DGP_HD double lo(double v) const {          // value held by lane j - S
+    if constexpr (LPT == 16) return cx.template row_from_lower<S>(v);
+    else return cx.fetch(v, src_lo);
+  }
+  DGP_HD double hi(double v) const {          // value held by lane j + S
+    if constexpr (LPT == 16) return cx.template row_from_upper<S>(v);
+    else return cx.fetch(v, src_hi);
+  }
+};
+
+// one PCR round at stride S
+template <int D, int LPT, int S, typename Ctx>
+DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], bool& ok) {
+  constexpr bool last = (2 * S >= LPT);
+  const Nbr<LPT, S, Ctx> nb(cx, i);
+  Sym<D> Di;
+  sym_inverse<D>(Dm, Di, ok);
+  const bool has_l = (i >= S);
+  double rn[D];
+  // ---- left neighbour
+  {
+    Sym<D> DiL;
+    Mat<D> UL;
+    double rL[D];
+#pragma unroll
+    for (int k = 0; k < D * (D + 1) / 2; ++k) DiL.v[k] = nb.lo(Di.v[k]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      rL[a] = nb.lo(r[a]);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const double u = nb.lo(U.v[a][c]);
+        UL.v[a][c] = has_l ? u : 0.0;
+      }
+    }
+    // T2 = UL^T DiL
+    double T2[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += UL.v[k][a] * DiL(k, c);
+        T2[a][c] = t;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double t = r[a];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= T2[a][k] * rL[k];
+      rn[a] = t;
+#pragma unroll
+      for (int c = a; c < D; ++c) {
+        double w = Dm(a, c);
+#pragma unroll
+        for (int k = 0; k < D; ++k) w -= T2[a][k] * UL.v[k][c];
+        Dm(a, c) = w;
+      }
+    }
+  }
+  // ---- right neighbour
+  {
+    Sym<D> DiR;
+    double rR[D];
+#pragma unroll
+    for (int k = 0; k < D * (D + 1) / 2; ++k) DiR.v[k] = nb.hi(Di.v[k]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) rR[a] = nb.hi(r[a]);
+    // T = U DiR
+    double T[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += U.v[a][k] * DiR(k, c);
+        T[a][c] = t;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double t = rn[a];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= T[a][k] * rR[k];
+      rn[a] = t;
+#pragma unroll
+      for (int c = a; c < D; ++c) {
+        double w = Dm(a, c);
+#pragma unroll
+        for (int k = 0; k < D; ++k) w -= T[a][k] * U.v[c][k];
+        Dm(a, c) = w;
+      }
+    }
+    if (!last) {
+      Mat<D> UR;
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) UR.v[a][c] = nb.hi(U.v[a][c]);
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) t -= T[a][k] * UR.v[k][c];
+          U.v[a][c] = t;
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) r[a] = rn[a];
+}
+
 template <int D, int LPT, typename Ctx>
 DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], double (&x)[D], bool& ok) {
-  const int lane = cx.lane();
-#pragma unroll 1
-  for (int s = 1; s < LPT; s <<= 1) {
-    Sym<D> Di;
-    sym_inverse<D>(Dm, Di, ok);
-    const bool has_l = (i >= s);
-    const bool last = (2 * s >= LPT);
-    const int src_l = has_l ? lane - s : lane;
-    const int src_r = (i + s < LPT) ? lane + s : lane;      // no right neighbour => own U is already 0
-    double rn[D];
-    // ---- left neighbour
-    {
-      Sym<D> DiL;
-      Mat<D> UL;
-      double rL[D];
-#pragma unroll
-      for (int k = 0; k < D * (D + 1) / 2; ++k) DiL.v[k] = cx.fetch(Di.v[k], src_l);
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        rL[a] = cx.fetch(r[a], src_l);
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          const double u = cx.fetch(U.v[a][c], src_l);
-          UL.v[a][c] = has_l ? u : 0.0;
-        }
-      }
-      // T2 = UL^T DiL
-      double T2[D][D];
-#pragma unroll
-      for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          double t = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) t += UL.v[k][a] * DiL(k, c);
-          T2[a][c] = t;
-        }
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double t = r[a];
-#pragma unroll
-        for (int k = 0; k < D; ++k) t -= T2[a][k] * rL[k];
-        rn[a] = t;
-#pragma unroll
-        for (int c = a; c < D; ++c) {
-          double w = Dm(a, c);
-#pragma unroll
-          for (int k = 0; k < D; ++k) w -= T2[a][k] * UL.v[k][c];
-          Dm(a, c) = w;
-        }
-      }
-    }
-    // ---- right neighbour
-    {
-      Sym<D> DiR;
-      double rR[D];
-#pragma unroll
-      for (int k = 0; k < D * (D + 1) / 2; ++k) DiR.v[k] = cx.fetch(Di.v[k], src_r);
-#pragma unroll
-      for (int a = 0; a < D; ++a) rR[a] = cx.fetch(r[a], src_r);
-      // T = U DiR
-      double T[D][D];
-#pragma unroll
-      for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          double t = 0.0;
-#pragma unroll
-          for (int k = 0; k < D; ++k) t += U.v[a][k] * DiR(k, c);
-          T[a][c] = t;
-        }
-#pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double t = rn[a];
-#pragma unroll
-        for (int k = 0; k < D; ++k) t -= T[a][k] * rR[k];
-        rn[a] = t;
-#pragma unroll
-        for (int c = a; c < D; ++c) {
-          double w = Dm(a, c);
-#pragma unroll
-          for (int k = 0; k < D; ++k) w -= T[a][k] * U.v[c][k];
-          Dm(a, c) = w;
-        }
-      }
-      if (!last) {
-        Mat<D> UR;
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int c = 0; c < D; ++c) UR.v[a][c] = cx.fetch(U.v[a][c], src_r);
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int c = 0; c < D; ++c) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) t -= T[a][k] * UR.v[k][c];
-            U.v[a][c] = t;
-          }
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < D; ++a) r[a] = rn[a];
-  }
+  if constexpr (LPT > 1) pcr_round<D, LPT, 1>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 2) pcr_round<D, LPT, 2>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 4) pcr_round<D, LPT, 4>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 8) pcr_round<D, LPT, 8>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 16) pcr_round<D, LPT, 16>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 32) pcr_round<D, LPT, 32>(cx, i, Dm, U, r, ok);
   sym_solve<D>(Dm, r, x, ok);
 }
 
@@ -714,14 +743,12 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
   constexpr int D = 2 * DOF;
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
-  const int lane = cx.lane();
   const int n = p.n;
-  const int src_m = (j >= 1) ? lane - 1 : lane;
-  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  const Nbr<LPT, 1, Ctx> nb(cx, j);
   // neighbouring states across the lane boundary
   double x_prev[D], x_next[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) { x_prev[a] = cx.fetch(x[C - 1][a], src_m); x_next[a] = cx.fetch(x[0][a], src_p); }
+  for (int a = 0; a < D; ++a) { x_prev[a] = nb.lo(x[C - 1][a]); x_next[a] = nb.hi(x[0][a]); }
 
   Sym<D> Sinv[CI];
   Mat<D> G[CI], V[CI], W[CI];
@@ -811,9 +838,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     Mat<D> Vn, Wn; double Pn[D];
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      Pn[a] = cx.fetch(P[0][a], src_p);
+      Pn[a] = nb.hi(P[0][a]);
 #pragma unroll
-      for (int c = 0; c < D; ++c) { Vn.v[a][c] = cx.fetch(V[0].v[a][c], src_p); Wn.v[a][c] = cx.fetch(W[0].v[a][c], src_p); }
+      for (int c = 0; c < D; ++c) { Vn.v[a][c] = nb.hi(V[0].v[a][c]); Wn.v[a][c] = nb.hi(W[0].v[a][c]); }
     }
     // (Us == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
     sub_A_B_sym<D>(Ds, Us, Vn);                           // D_s -= U_s V'_0
@@ -830,7 +857,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   if (C > 1) {
     double xps[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) xps[a] = cx.fetch(xs[a], src_m);      // V == 0 where there is no previous separator
+    for (int a = 0; a < D; ++a) xps[a] = nb.lo(xs[a]);                // V == 0 where there is no previous separator
 #pragma unroll
     for (int k = 0; k < C - 1; ++k) {
       double t[D];
@@ -848,11 +875,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 template <int DOF, int LPT, int C, typename IO, typename Ctx>
 DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF], ErrAcc& acc) {
   constexpr int D = 2 * DOF;
-  const int lane = cx.lane();
-  const int src_p = (j + 1 < LPT) ? lane + 1 : lane;
+  const Nbr<LPT, 1, Ctx> nb(cx, j);
   double x_next[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) x_next[a] = cx.fetch(x[0][a], src_p);
+  for (int a = 0; a < D; ++a) x_next[a] = nb.hi(x[0][a]);
   Sym<D> Qm = {}, Q = {}, Dk; Mat<D> Uk; double rk[D];
 #pragma unroll
   for (int k = 0; k < C; ++k) {

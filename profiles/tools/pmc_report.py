@@ -7,12 +7,11 @@ vals = {}
 for f in sorted(glob.glob(os.path.join(d, '*_results.db'))):
   cur = sqlite3.connect(f).cursor()
   try:
-    rows = cur.execute("select k.name, p.name, count(*), avg(e.value) from pmc_events e join kernels k on k.dispatch_id = e.dispatch_id "
-                       "join pmc_info p on p.id = e.pmc_id group by k.name, p.name").fetchall()
+    rows = cur.execute("select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name").fetchall()
   except sqlite3.Error as ex:
     print('# %s: %s' % (f, ex)); continue
   for kname, cname, cnt, avg in rows:
-    short = 'gn_kernel' if 'gn_kernel' in kname else ('copy' if ('copy' in kname.lower() or 'Memcpy' in kname or 'elementwise' in kname) else None)
+    short = 'gn_kernel' if 'gn_kernel' in kname else ('copy' if 'copyBuffer' in kname else None)
     if short: vals.setdefault(short, {}).setdefault(cname, []).append((cnt, avg, kname[:90]))
   for r in cur.execute("select name, count(*), avg(duration) from kernels where name like '%gn_kernel%' group by name"):
     print('# %s: %s x%d avg %.1f ns' % (os.path.basename(f), r[0][:80], r[1], r[2]))

@@ -43,6 +43,23 @@ struct HostCtx {
     pthread_barrier_wait(&ws->bar);
     return r;
   }
+  // DPP row shifts of the device context: neighbour inside the 16-lane row, 0 where there is none
+  template <int S>
+  double row_from_lower(double v) {
+    ws->slot[lane_] = v;
+    pthread_barrier_wait(&ws->bar);
+    double r = ((lane_ & 15) >= S) ? ws->slot[lane_ - S] : 0.0;
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
+  template <int S>
+  double row_from_upper(double v) {
+    ws->slot[lane_] = v;
+    pthread_barrier_wait(&ws->bar);
+    double r = ((lane_ & 15) + S < 16) ? ws->slot[lane_ + S] : 0.0;
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
   bool any(bool pred) {
     ws->islot[lane_] = pred ? 1 : 0;
     pthread_barrier_wait(&ws->bar);
