@@ -84,6 +84,21 @@ struct Sym {                 // symmetric DxD, packed upper triangle
 template <int D>
 struct Mat { double v[D][D]; };
 
+// 1/v for a pivot: on the device v_rcp_f64 refined by two Newton steps (full double accuracy for normal, finite v;
+// the IEEE division expansion's scaling / fix-up of denormals and overflow is not needed for SPD pivots).
+DGP_HD double pivot_rcp(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(v);
+  double e = __builtin_fma(-v, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-v, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  return r;
+#else
+  return 1.0 / v;
+#endif
+}
+
 // A^-1 of an SPD matrix through LDL^T; ok=false when a pivot is <= 0 or NaN.
 template <int D>
 DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
@@ -97,7 +112,7 @@ DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * dd[k];
     dd[j] = v;
     ok = ok && (v > 0.0);
-    dinv[j] = 1.0 / v;
+    dinv[j] = pivot_rcp(v);
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double w = A(i, j);
@@ -144,7 +159,7 @@ DGP_HD void sym_solve(const Sym<D>& A, const double (&b)[D], double (&x)[D], boo
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * dd[k];
     dd[j] = v;
     ok = ok && (v > 0.0);
-    dinv[j] = 1.0 / v;
+    dinv[j] = pivot_rcp(v);
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
       double w = A(i, j);
@@ -287,6 +302,34 @@ DGP_HD void fixed_Qinv(const GnParams& p, Sym<2 * DOF>& Q) {
     }
 }
 
+// Blocks one GP factor (g -> g+1) contributes: Q^-1, Phi^T Q^-1 and Phi^T Q^-1 Phi.  With static covariances they are the
+// same for every factor and are built once per lane.
+template <int DOF>
+struct GpBlk {
+  Sym<2 * DOF> Q;
+  double PQ[2 * DOF][2 * DOF];     // Phi^T Q : rows pos = Q[pos,:], rows vel = dt*Q[pos,:] + Q[vel,:]
+  Sym<2 * DOF> PQP;                // Phi^T Q Phi
+};
+
+template <int DOF>
+DGP_HD void build_gp_blk(double dt, GpBlk<DOF>& g) {
+  constexpr int D = 2 * DOF;
+#pragma unroll
+  for (int a = 0; a < DOF; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      g.PQ[a][c] = g.Q(a, c);
+      g.PQ[DOF + a][c] = dt * g.Q(a, c) + g.Q(DOF + a, c);
+    }
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < DOF; ++c) {
+      if (c >= a) g.PQP(a, c) = g.PQ[a][c];
+      if (DOF + c >= a) g.PQP(a, DOF + c) = dt * g.PQ[a][c] + g.PQ[a][DOF + c];
+    }
+}
+
 template <int D>
 DGP_HD double quad(const Sym<D>& Q, const double (&e)[D]) {      // e^T Q e
   double s = 0.0;
@@ -303,8 +346,9 @@ DGP_HD double quad(const Sym<D>& Q, const double (&e)[D]) {      // e^T Q e
 // ---------------------------------------------------------------------------------------------------
 // factor evaluation for ONE support state (row g of the block-tridiagonal system)
 //   -> diagonal block Dm, coupling U to row g+1, eta r, and the partial error sums.
-// Qm is Q^-1 of the GP factor (g-1 -> g) (ignored for g == 0); Q returns Q^-1 of the factor (g -> g+1) so that
-// the caller can hand it to the next row instead of loading it twice.
+// `own` holds the blocks of the GP factor (g -> g+1), Qm is Q^-1 of the factor (g-1 -> g) (ignored for g == 0);
+// (oc, ohx, ohy) is the obstacle factor of this state, evaluated beforehand (all SDF lookups of a lane are issued
+// together, ahead of the elimination sweep, so that their memory latency overlaps).
 // ---------------------------------------------------------------------------------------------------
 struct ErrAcc {
   double e, eext;          // partial sums of err / err_ext (un-normalised)
@@ -313,8 +357,9 @@ struct ErrAcc {
 
 template <int DOF, typename IO, bool ASSEMBLE>
 DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
-                       const double (&xp)[2 * DOF], const Sym<2 * DOF>& Qm, Sym<2 * DOF>& Q, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U,
-                       double (&r)[2 * DOF], ErrAcc& acc) {
+                       const double (&xp)[2 * DOF], const GpBlk<DOF>& own, const Sym<2 * DOF>& Qm, const Sym<2 * DOF>& Qfix,
+                       double ow, double oc, double ohx, double ohy, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U, double (&r)[2 * DOF],
+                       ErrAcc& acc) {
   constexpr int D = 2 * DOF;
   const int n = p.n;
   if (ASSEMBLE) {
@@ -350,49 +395,28 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
   // ---- GP factor (g -> g+1), owned by row g: e = x_{g+1} - Phi x_g (gp_factor.py:105)
   const double dt = p.dt;
   if (g < n - 1) {
-    load_Qinv<DOF, IO>(p, b, g, Q);
     double e[D];
 #pragma unroll
     for (int a = 0; a < DOF; ++a) {
       e[a] = xp[a] - (x[a] + dt * x[DOF + a]);
       e[DOF + a] = xp[DOF + a] - x[DOF + a];
     }
-    const double q = quad<D>(Q, e);
+    const double q = quad<D>(own.Q, e);
     acc.e += 0.5 * q;
     double s2 = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) s2 += e[a] * e[a];
     acc.ugp += 0.5 * s2;
-    if (p.qc_mode == QC_STATIC) {
-      acc.eext += 0.5 * q;
-    } else {
-      Sym<D> Qf;
-      fixed_Qinv<DOF>(p, Qf);
-      acc.eext += 0.5 * quad<D>(Qf, e);                    // plan_layer.py:318-321
-    }
+    acc.eext += (p.qc_mode == QC_STATIC) ? 0.5 * q : 0.5 * quad<D>(Qfix, e);      // plan_layer.py:318-321
     if (ASSEMBLE) {
-      // PQ = Phi^T Q : rows pos = Q[pos,:], rows vel = dt*Q[pos,:] + Q[vel,:]
-      double PQ[D][D];
-#pragma unroll
-      for (int a = 0; a < DOF; ++a)
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          PQ[a][c] = Q(a, c);
-          PQ[DOF + a][c] = dt * Q(a, c) + Q(DOF + a, c);
-        }
-      // Dm += PQ Phi : cols pos = PQ[:,pos], cols vel = dt*PQ[:,pos] + PQ[:,vel]   (upper triangle only)
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-#pragma unroll
-        for (int c = 0; c < DOF; ++c) {
-          if (c >= a) Dm(a, c) += PQ[a][c];
-          if (DOF + c >= a) Dm(a, DOF + c) += dt * PQ[a][c] + PQ[a][DOF + c];
-        }
         double t = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-          U.v[a][c] = -PQ[a][c];                           // block (g,g+1) = H1^T Q^-1 H2 = -Phi^T Q^-1
-          t += PQ[a][c] * e[c];
+          if (c >= a) Dm(a, c) += own.PQP(a, c);           // H1^T Q^-1 H1 = Phi^T Q^-1 Phi
+          U.v[a][c] = -own.PQ[a][c];                       // block (g,g+1) = H1^T Q^-1 H2 = -Phi^T Q^-1
+          t += own.PQ[a][c] * e[c];
         }
         r[a] += t;                                         // H1^T Q^-1 e
       }
@@ -419,17 +443,12 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
   }
   // ---- obstacle factor (obstacle_factor.py:35-40): sphere centre = x[0:2], H = H_e H_fk, H_fk = I_d[0:2,:]
   {
-    const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
-    const double w = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
-    const IO* grid = (const IO*)p.sdf + b * p.sdf_bstride;
-    double c, hx, hy;
-    obstacle_eval<IO>(p, grid, x[0], x[1], eps, c, hx, hy);
-    acc.e += 0.5 * w * c * c;
-    acc.eext += 0.5 * p.obs_w_fix * c * c;                 // plan_layer.py:329-332 (fixed weight, current eps)
-    acc.uobs += 0.5 * c * c;
+    acc.e += 0.5 * ow * oc * oc;
+    acc.eext += 0.5 * p.obs_w_fix * oc * oc;               // plan_layer.py:329-332 (fixed weight, current eps)
+    acc.uobs += 0.5 * oc * oc;
     if (ASSEMBLE) {
-      Dm(0, 0) += w * hx * hx; Dm(0, 1) += w * hx * hy; Dm(1, 1) += w * hy * hy;
-      r[0] += w * hx * c; r[1] += w * hy * c;
+      Dm(0, 0) += ow * ohx * ohx; Dm(0, 1) += ow * ohx * ohy; Dm(1, 1) += ow * ohy * ohy;
+      r[0] += ow * ohx * oc; r[1] += ow * ohy * oc;
     }
   }
   // ---- velocity-limit factor (velocity_limit_factor.py:17-29): '>=' (not '>'), H = -sign(v) e_{dof+a}
@@ -462,6 +481,33 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
       }
     }
   }
+}
+
+// Per-lane inputs that do not depend on the elimination: obstacle factors of the lane's C states (all SDF loads issued
+// together) and the GP blocks (built once for static covariances).
+template <int DOF, int C, typename IO>
+struct LaneFactors {
+  double ow[C], oc[C], ohx[C], ohy[C];
+  GpBlk<DOF> stat;           // blocks of the static Q^-1 (also the FIXED Q^-1 of err_ext)
+};
+
+template <int DOF, int C, typename IO>
+DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<DOF, C, IO>& f) {
+  const int n = p.n;
+  const IO* grid = (const IO*)p.sdf + (traj_ok ? b : 0) * p.sdf_bstride;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = g0 + k;
+    const bool valid = traj_ok && g < n;
+    f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0;
+    if (valid) {
+      const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
+      f.ow[k] = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
+      obstacle_eval<IO>(p, grid, x[k][0], x[k][1], eps, f.oc[k], f.ohx[k], f.ohy[k]);
+    }
+  }
+  fixed_Qinv<DOF>(p, f.stat.Q);
+  build_gp_blk<DOF>(p.dt, f.stat);
 }
 
 // small dense helpers on dxd blocks -----------------------------------------------------------------
@@ -753,10 +799,14 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   Sym<D> Sinv[CI];
   Mat<D> G[CI], V[CI], W[CI];
   double P[CI][D];
-  Sym<D> Qm = {}, Q = {};
-  Mat<D> Uprev = {};     // U of the previous row (k-1)
   const int g0 = j * C;
-  if (traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
+  LaneFactors<DOF, C, IO> lf;
+  lane_prefetch<DOF, C, IO>(p, b, g0, traj_ok, x, lf);
+  const bool stat = (p.qc_mode == QC_STATIC);
+  GpBlk<DOF> blk = lf.stat;      // blocks of the current row's own GP factor (per-state modes: rebuilt per row)
+  Sym<D> Qm = lf.stat.Q;         // Q^-1 of the factor (g-1 -> g)
+  Mat<D> Uprev = {};             // U of the previous row (k-1)
+  if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
 
   // ---- a. forward sweep over the interior rows
 #pragma unroll
@@ -764,7 +814,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
     Sym<D> Dk; Mat<D> Uk; double rk[D];
-    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Qm, Q, Dk, Uk, rk, acc);
+    if (!stat && valid && g < n - 1) { load_Qinv<DOF, IO>(p, b, g, blk.Q); build_gp_blk<DOF>(p.dt, blk); }
+    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], blk, Qm, lf.stat.Q,
+                              lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
@@ -791,7 +843,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     sym_inverse<D>(Dk, Sinv[k], ok);
     sym_times_mat<D>(Sinv[k], Uk, G[k]);                  // G_k = S_k^-1 U_k
     Uprev = Uk;
-    Qm = Q;
+    if (!stat) Qm = blk.Q;
   }
   // ---- b. back substitution: P, V, W in place
   if (C > 1) {
@@ -825,7 +877,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   {
     const int g = g0 + C - 1;
     const bool valid = traj_ok && g < n;
-    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Qm, Q, Ds, Us, rs, acc);
+    if (!stat && valid && g < n - 1) { load_Qinv<DOF, IO>(p, b, g, blk.Q); build_gp_blk<DOF>(p.dt, blk); }
+    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, blk, Qm, lf.stat.Q,
+                              lf.ow[C - 1], lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rs[a] = valid ? rhs[C - 1][a] : 0.0;
@@ -879,11 +933,18 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
   double x_next[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) x_next[a] = nb.hi(x[0][a]);
-  Sym<D> Qm = {}, Q = {}, Dk; Mat<D> Uk; double rk[D];
+  LaneFactors<DOF, C, IO> lf;
+  lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
+  const bool stat = (p.qc_mode == QC_STATIC);
+  GpBlk<DOF> blk = lf.stat;
+  Sym<D> Dk; Mat<D> Uk; double rk[D];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int g = j * C + k;
-    eval_state<DOF, IO, false>(p, b, g, traj_ok && g < p.n, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, Qm, Q, Dk, Uk, rk, acc);
+    const bool valid = traj_ok && g < p.n;
+    if (!stat && valid && g < p.n - 1) load_Qinv<DOF, IO>(p, b, g, blk.Q);
+    eval_state<DOF, IO, false>(p, b, g, valid, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, blk, lf.stat.Q, lf.stat.Q,
+                               lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
   }
 }
 
