@@ -99,9 +99,10 @@ DGP_HD double pivot_rcp(double v) {
 #endif
 }
 
-// A^-1 of an SPD matrix through LDL^T; ok=false when a pivot is <= 0 or NaN.
+// A^-1 of an SPD matrix through LDL^T; ok=false when a pivot is <= 0 or NaN.  (Generic fallback; the kernels use the
+// block forms below, whose dependency chains are much shorter.)
 template <int D>
-DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
+DGP_HD void sym_inverse_ldlt(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
   double L[D][D];      // unit lower (strict part used)
   double dinv[D];
   double dd[D];
@@ -144,6 +145,88 @@ DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
       for (int k = j + 1; k < D; ++k) w += Mi[k][i] * dinv[k] * Mi[k][j];
       Ai(i, j) = w;
     }
+  }
+}
+
+// Inverse of an SPD 2x2 / 3x3 block given as scalars (adjugate / determinant); ok tracks the leading minors.
+DGP_HD void inv2(double a, double b, double c, double& ia, double& ib, double& ic, bool& ok) {      // [[a,b],[b,c]]
+  const double det = a * c - b * b;
+  ok = ok && (a > 0.0) && (det > 0.0);
+  const double r = pivot_rcp(det);
+  ia = c * r; ib = -b * r; ic = a * r;
+}
+DGP_HD void inv3(const double (&m)[6], double (&o)[6], bool& ok) {      // packed upper: m00 m01 m02 m11 m12 m22
+  const double c00 = m[3] * m[5] - m[4] * m[4];
+  const double c01 = m[2] * m[4] - m[1] * m[5];
+  const double c02 = m[1] * m[4] - m[2] * m[3];
+  const double c11 = m[0] * m[5] - m[2] * m[2];
+  const double c12 = m[1] * m[2] - m[0] * m[4];
+  const double c22 = m[0] * m[3] - m[1] * m[1];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  ok = ok && (m[0] > 0.0) && (c22 > 0.0) && (det > 0.0);
+  const double r = pivot_rcp(det);
+  o[0] = c00 * r; o[1] = c01 * r; o[2] = c02 * r; o[3] = c11 * r; o[4] = c12 * r; o[5] = c22 * r;
+}
+
+// A^-1 of an SPD dxd matrix by 2x2 block elimination with (d/2)x(d/2) blocks:
+//   A = [[P, Q],[Q^T, R]],  S = R - Q^T P^-1 Q,  A^-1 = [[P^-1 + Y S^-1 Y^T, -Y S^-1],[., S^-1]],  Y = P^-1 Q.
+// Two reciprocals and a dependency depth of ~12 operations instead of d sequential pivots; ok=false if not SPD.
+template <int D>
+DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
+  if constexpr (D == 4) {
+    double p0, p1, p2;
+    inv2(A(0, 0), A(0, 1), A(1, 1), p0, p1, p2, ok);
+    // Y = P^-1 Q (2x2), Q = A[0:2, 2:4]
+    const double y00 = p0 * A(0, 2) + p1 * A(1, 2), y01 = p0 * A(0, 3) + p1 * A(1, 3);
+    const double y10 = p1 * A(0, 2) + p2 * A(1, 2), y11 = p1 * A(0, 3) + p2 * A(1, 3);
+    // S = R - Q^T Y (symmetric)
+    const double s00 = A(2, 2) - (A(0, 2) * y00 + A(1, 2) * y10);
+    const double s01 = A(2, 3) - (A(0, 2) * y01 + A(1, 2) * y11);
+    const double s11 = A(3, 3) - (A(0, 3) * y01 + A(1, 3) * y11);
+    double t0, t1, t2;
+    inv2(s00, s01, s11, t0, t1, t2, ok);
+    // Z = Y S^-1
+    const double z00 = y00 * t0 + y01 * t1, z01 = y00 * t1 + y01 * t2;
+    const double z10 = y10 * t0 + y11 * t1, z11 = y10 * t1 + y11 * t2;
+    Ai(2, 2) = t0; Ai(2, 3) = t1; Ai(3, 3) = t2;
+    Ai(0, 2) = -z00; Ai(0, 3) = -z01; Ai(1, 2) = -z10; Ai(1, 3) = -z11;
+    Ai(0, 0) = p0 + (z00 * y00 + z01 * y01);
+    Ai(0, 1) = p1 + (z00 * y10 + z01 * y11);
+    Ai(1, 1) = p2 + (z10 * y10 + z11 * y11);
+  } else if constexpr (D == 6) {
+    double Pm[6] = {A(0, 0), A(0, 1), A(0, 2), A(1, 1), A(1, 2), A(2, 2)}, Pi[6];
+    inv3(Pm, Pi, ok);
+    auto P = [&](int i, int j) { return Pi[Sym<3>::idx(i, j)]; };
+    double Y[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Y[i][j] = P(i, 0) * A(0, 3 + j) + P(i, 1) * A(1, 3 + j) + P(i, 2) * A(2, 3 + j);
+    double Sm[6], Si[6];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j)
+        Sm[Sym<3>::idx(i, j)] = A(3 + i, 3 + j) - (A(0, 3 + i) * Y[0][j] + A(1, 3 + i) * Y[1][j] + A(2, 3 + i) * Y[2][j]);
+    inv3(Sm, Si, ok);
+    auto S = [&](int i, int j) { return Si[Sym<3>::idx(i, j)]; };
+    double Z[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Z[i][j] = Y[i][0] * S(0, j) + Y[i][1] * S(1, j) + Y[i][2] * S(2, j);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        Ai(i, 3 + j) = -Z[i][j];
+        if (j >= i) {
+          Ai(3 + i, 3 + j) = S(i, j);
+          Ai(i, j) = P(i, j) + (Z[i][0] * Y[j][0] + Z[i][1] * Y[j][1] + Z[i][2] * Y[j][2]);
+        }
+      }
+  } else {
+    sym_inverse_ldlt<D>(A, Ai, ok);
   }
 }
 
@@ -658,7 +741,7 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], boo
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         const double u = nb.lo(U.v[a][c]);
-        UL.v[a][c] = has_l ? u : 0.0;
+        UL.v[a][c] = (LPT == 16 || has_l) ? u : 0.0;     // the DPP row shift already yields 0 where there is no left neighbour
       }
     }
     // T2 = UL^T DiL
