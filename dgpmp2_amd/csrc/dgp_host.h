@@ -50,7 +50,10 @@ inline DgpShape choose_shape(const DgpHandle* h, int B) {
   const int n = h->cfg.num_states;
   DgpShape best{64, 4};
   double best_cost = 1e300;
-  for (int c = 1; c <= 4; c *= 2)
+  // d = 6 blocks: four states per lane do not fit the 512-register budget (measured: C=4 spills ~1200 dwords and is 1.6x
+  // slower than C=2 at B=4096), so C is capped at 2 whenever that still covers n
+  const int c_max = (h->cfg.dof == 3 && 64 * 2 >= n) ? 2 : 4;
+  for (int c = 1; c <= c_max; c *= 2)
     for (int lpt = 16; lpt <= 64; lpt *= 2) {
       if (lpt * c < n) continue;
       int rounds = 0;
