@@ -149,12 +149,15 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   return DGP_OK;
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 inline int fill_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                      const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, dgp::GnParams& p) {
   int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
   if (rc != DGP_OK) return rc;
   if (!dtheta) return fail(DGP_EINVAL, "dtheta must be non-null");
   p.dtheta = dtheta; p.err = err; p.err_ext = err_ext; p.info = info;
+  p.vec_io = (aligned16(th) && aligned16(dtheta)) ? 1 : 0;
   return DGP_OK;
 }
 
@@ -167,6 +170,7 @@ inline int fill_solve(const DgpHandle* h, int32_t batch, const void* th_init, co
   if (max_iters < 1) return fail(DGP_EINVAL, "max_iters must be >= 1, got %d", max_iters);
   p.th_out = th_out; p.iters = iters; p.err_hist = err_hist; p.errext_hist = errext_hist; p.err_final = err_final;
   p.info = info; p.max_iters = max_iters; p.tol_delta = tol_delta;
+  p.vec_io = (aligned16(th_init) && aligned16(th_out)) ? 1 : 0;
   return DGP_OK;
 }
 
@@ -175,6 +179,7 @@ inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const vo
   int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
   if (rc != DGP_OK) return rc;
   p.err = err; p.err_ext = err_ext; p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
+  p.vec_io = aligned16(th) ? 1 : 0;
   return DGP_OK;
 }
 
@@ -189,6 +194,7 @@ inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   if (g_qc_inv && p.qc_mode == DGP_QC_STATIC) return fail(DGP_EINVAL, "g_qc_inv given but qc_mode is DGP_QC_STATIC");
   g.dtheta = dtheta; g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
   g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
+  p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
 }
 

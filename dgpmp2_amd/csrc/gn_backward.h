@@ -37,16 +37,17 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   const Nbr<LPT, 1, Ctx> nb(cx, j);
   const int g0 = j * C;
 
+  const bool vec = p.vec_io != 0;
   double x[C][D], gbar[C][D], lam[C][D];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      x[k][a] = valid ? ld<IO>(p.th, (b * n + g) * D + a) : 0.0;
-      gbar[k][a] = (valid && gp.g_dtheta) ? ld<IO>(gp.g_dtheta, (b * n + g) * D + a) : 0.0;
-      lam[k][a] = 0.0;
+    for (int a = 0; a < D; ++a) { x[k][a] = 0.0; gbar[k][a] = 0.0; lam[k][a] = 0.0; }
+    if (valid) {
+      ld_row<IO, D>(p.th, b * n + g, vec, x[k]);
+      if (gp.g_dtheta) ld_row<IO, D>(gp.g_dtheta, b * n + g, vec, gbar[k]);
     }
   }
   // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
@@ -78,12 +79,12 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     const double* lk = lam[k];
     const double* lm = (k == 0) ? lam_prev : lam[k > 0 ? k - 1 : 0];
     const double* lp = (k == C - 1) ? lam_next : lam[k < C - 1 ? k + 1 : 0];
-    double dth[D], dth_m[D], dth_p[D];
+    double dth[D], dth_p[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      dth[a] = gp.g_dtheta ? ld<IO>(gp.dtheta, (b * n + g) * D + a) : 0.0;
-      dth_m[a] = (gp.g_dtheta && g > 0) ? ld<IO>(gp.dtheta, (b * n + g - 1) * D + a) : 0.0;
-      dth_p[a] = (gp.g_dtheta && g < n - 1) ? ld<IO>(gp.dtheta, (b * n + g + 1) * D + a) : 0.0;
+    for (int a = 0; a < D; ++a) { dth[a] = 0.0; dth_p[a] = 0.0; }
+    if (gp.g_dtheta) {
+      ld_row<IO, D>(gp.dtheta, b * n + g, vec, dth);
+      if (g < n - 1) ld_row<IO, D>(gp.dtheta, b * n + g + 1, vec, dth_p);
     }
     double gx[D];
 #pragma unroll
@@ -247,10 +248,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       gx[DOF] += a2 * cs + ae * (-sn);                             // d/dvx: h2 -> cos, e -> -sin
       gx[DOF + 1] += a2 * (-sn) + ae * cs;                         // d/dvy: h2 -> -sin, e -> cos
     }
-    if (gp.g_th) {
-#pragma unroll
-      for (int a = 0; a < D; ++a) st<IO>(gp.g_th, (b * n + g) * D + a, gx[a]);
-    }
+    if (gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gx);
   }
 }
 

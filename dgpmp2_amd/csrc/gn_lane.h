@@ -44,7 +44,7 @@ struct GnParams {
   int32_t qc_mode;
   uint32_t flags;
   int32_t max_iters;
-  int32_t pad_;
+  int32_t vec_io;            // 1: th / dtheta / th_out / gradient rows are 16-byte aligned -> vector row accesses
   const void *th, *start, *goal, *sdf, *qc, *obs_w, *eps;
   void *dtheta, *err, *err_ext;
   int32_t* info;
@@ -273,6 +273,48 @@ DGP_HD void sym_solve(const Sym<D>& A, const double (&b)[D], double (&x)[D], boo
 // ---------------------------------------------------------------------------------------------------
 template <typename IO> DGP_HD double ld(const void* p, int64_t i) { return (double)((const IO*)p)[i]; }
 template <typename IO> DGP_HD void st(void* p, int64_t i, double v) { ((IO*)p)[i] = (IO)v; }
+
+// One state row (D consecutive elements) as 16-byte (8-byte for f32, D = 6) vector accesses when the host found every
+// row pointer suitably aligned (GnParams::vec_io), scalar accesses otherwise.
+template <typename IO, int D> struct RowVec;
+template <> struct RowVec<float, 4> { typedef float T __attribute__((vector_size(16))); enum { N = 1, W = 4 }; };
+template <> struct RowVec<float, 6> { typedef float T __attribute__((vector_size(8))); enum { N = 3, W = 2 }; };
+template <> struct RowVec<double, 4> { typedef double T __attribute__((vector_size(16))); enum { N = 2, W = 2 }; };
+template <> struct RowVec<double, 6> { typedef double T __attribute__((vector_size(16))); enum { N = 3, W = 2 }; };
+
+template <typename IO, int D>
+DGP_HD void ld_row(const void* p, int64_t row, bool vec, double (&x)[D]) {
+  if (vec) {
+    typedef typename RowVec<IO, D>::T V;
+    const V* q = (const V*)((const IO*)p + row * D);
+#pragma unroll
+    for (int k = 0; k < RowVec<IO, D>::N; ++k) {
+      const V v = q[k];
+#pragma unroll
+      for (int a = 0; a < RowVec<IO, D>::W; ++a) x[k * RowVec<IO, D>::W + a] = (double)v[a];
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < D; ++a) x[a] = ld<IO>(p, row * D + a);
+  }
+}
+template <typename IO, int D>
+DGP_HD void st_row(void* p, int64_t row, bool vec, const double (&x)[D]) {
+  if (vec) {
+    typedef typename RowVec<IO, D>::T V;
+    V* q = (V*)((IO*)p + row * D);
+#pragma unroll
+    for (int k = 0; k < RowVec<IO, D>::N; ++k) {
+      V v;
+#pragma unroll
+      for (int a = 0; a < RowVec<IO, D>::W; ++a) v[a] = (IO)x[k * RowVec<IO, D>::W + a];
+      q[k] = v;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < D; ++a) st<IO>(p, row * D + a, x[a]);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // bilinear SDF lookup + hinge, bit-for-bit the reference's fp64 op order (no FMA contraction here, so
@@ -1044,12 +1086,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int n = p.n;
   const bool traj_ok = b < p.B;
 
+  const bool vec = p.vec_io != 0;
   double x[C][D];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int g = j * C + k;
 #pragma unroll
-    for (int a = 0; a < D; ++a) x[k][a] = (traj_ok && g < n) ? ld<IO>(p.th, (b * n + g) * D + a) : 0.0;
+    for (int a = 0; a < D; ++a) x[k][a] = 0.0;
+    if (traj_ok && g < n) ld_row<IO, D>(p.th, b * n + g, vec, x[k]);
   }
 
   if (MODE == MODE_EVAL) {
@@ -1083,10 +1127,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 #pragma unroll
       for (int k = 0; k < C; ++k) {
         const int g = j * C + k;
-        if (traj_ok && g < n) {
-#pragma unroll
-          for (int a = 0; a < D; ++a) st<IO>(p.dtheta, (b * n + g) * D + a, dx[k][a]);
-        }
+        if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
       }
       if (traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, e / p.M);
@@ -1120,10 +1161,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int g = j * C + k;
-      if (traj_ok && g < n) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) st<IO>(p.th_out, (b * n + g) * D + a, x[k][a]);
-      }
+      if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, x[k]);
     }
     if (traj_ok && j == 0 && p.iters) p.iters[b] = my_iters;
     if (p.err_final) {

@@ -16,6 +16,17 @@ a = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=dev).normal_()
 b = torch.empty_like(a)
 for _ in range(3): b.copy_(a)
 torch.cuda.synchronize()
+# calibration in the kernel's own access pattern: 16 dword loads + 16 dword stores per lane, 64 B lane stride, 256 MiB each way
+import subprocess
+here = os.path.dirname(os.path.abspath(__file__))
+so = '/tmp/libdgp_calib.so'
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', os.path.join(here, 'calib.hip'), '-o', so])
+cal = ctypes.CDLL(so)
+cal.calib_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+for _ in range(3):
+  rc = cal.calib_launch(a.data_ptr(), b.data_ptr(), a.numel() // 16, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+  assert rc == 0
+torch.cuda.synchronize()
 B, n = B_PER_GPU, N_STATES
 th0, start, goal, sdf = make_inputs(B, n, GRID, dev)
 s = _capi.Solver(solver_config(n, DOF, torch.float32))

@@ -56,6 +56,7 @@ class Backend(object):
       self.torch = torch
       self.api = _capi.get_api()
     self._keep = []
+    self.misalign = False      # True: hand the C-ABI buffers that start one element past a 16-byte boundary (scalar row access path)
 
   # -- memory ------------------------------------------------------------------------------------
   def _np_dtype(self, io): return np.float64 if io == 'f64' else np.float32
@@ -65,9 +66,15 @@ class Backend(object):
     dt = dtype if dtype is not None else self._np_dtype(io)
     a = np.ascontiguousarray(np.asarray(a), dtype=dt)
     if self.kind == 'emul':
+      if self.misalign and a.size:
+        buf = np.empty(a.size + 1, dtype=dt); v = buf[1:]; v[:] = a.ravel(); a = v.reshape(a.shape)
+        assert a.ctypes.data % 16 != 0
       self._keep.append(a)
       return a, a.ctypes.data
     t = self.torch.from_numpy(a).to('cuda:0')
+    if self.misalign and t.numel():
+      buf = self.torch.empty(t.numel() + 1, dtype=t.dtype, device=t.device); v = buf[1:]; v.copy_(t.reshape(-1)); t = v.view(t.shape)
+      assert t.data_ptr() % 16 != 0
     self._keep.append(t)
     return t, t.data_ptr()
 

@@ -302,5 +302,26 @@ def case_backward_fd(be, golden, io):
   check(p, g['th'][:2], g['start'][:2], g['goal'][:2], sdf, qc=Qf, q_full=True, nprobe=10)     # q_full
 
 
+def case_unaligned_buffers(be, golden, io):
+  """Buffers that are only element-aligned (e.g. a slice of a larger tensor): the kernels fall back from 16-byte vector row
+  accesses to scalar ones; forward and backward results must not change."""
+  g = golden('g5_grads')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  th, st, go, sdf = rnd(g['th'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io)
+  d0, e0, x0, _ = be.step(p, th, st, go, sdf, io=io)
+  r0 = be.backward(p, th, st, go, sdf, d0, rnd(g['gbar'], io), None, io=io)
+  be.misalign = True
+  try:
+    d1, e1, x1, _ = be.step(p, th, st, go, sdf, io=io)
+    r1 = be.backward(p, th, st, go, sdf, d0, rnd(g['gbar'], io), None, io=io)
+  finally:
+    be.misalign = False
+  assert np.array_equal(d0, d1) and np.array_equal(e0, e1) and np.array_equal(x0, x1)
+  assert np.array_equal(r0['th'], r1['th']) and np.array_equal(r0['start'], r1['start'])
+  assert rel_err(r1['sdf'], r0['sdf']) < 1e-12          # atomics: summation order may differ
+
+
 ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, case_c1, case_small_ragged, case_edges,
-             case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd, case_backward_golden, case_backward_fd]
+             case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd, case_backward_golden, case_backward_fd, case_unaligned_buffers]

@@ -28,6 +28,8 @@ def test_emul_not_spd(be, golden): PC.case_not_spd(be, golden, 'f64')
 def test_emul_backward_golden(be, golden): PC.case_backward_golden(be, golden, 'f64')
 def test_emul_backward_golden_f32(be, golden): PC.case_backward_golden(be, golden, 'f32')
 def test_emul_backward_fd(be, golden): PC.case_backward_fd(be, golden, 'f64')
+def test_emul_unaligned(be, golden): PC.case_unaligned_buffers(be, golden, 'f64')
+def test_emul_unaligned_f32(be, golden): PC.case_unaligned_buffers(be, golden, 'f32')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)
