@@ -378,37 +378,26 @@ DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y,
 // Q^-1 of one GP factor (gp_factor.py:65-73 / plan_layer.py:90)
 template <int DOF, typename IO>
 DGP_HD void load_Qinv(const GnParams& p, int64_t b, int f, Sym<2 * DOF>& Q) {
+  // NB every entry of Q is assigned exactly once, in straight-line code: writing the aggregate on two control-flow paths
+  // (an early-return branch per mode) leaves part of it in scratch memory (measured: 49 scratch accesses per lane).
   constexpr int D = 2 * DOF;
-  if (p.qc_mode == QC_QFULL) {
-    const int64_t base = (b * (p.n - 1) + f) * (D * D);
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int j = i; j < D; ++j) Q(i, j) = ld<IO>(p.qc, base + i * D + j);
-    return;
-  }
-  double C[DOF][DOF];
-  if (p.qc_mode == QC_PERSTATE) {
-    const int64_t base = (b * (p.n - 1) + f) * (DOF * DOF);
-#pragma unroll
-    for (int i = 0; i < DOF; ++i)
-#pragma unroll
-      for (int j = 0; j < DOF; ++j) C[i][j] = ld<IO>(p.qc, base + i * DOF + j);
-  } else {
-#pragma unroll
-    for (int i = 0; i < DOF; ++i)
-#pragma unroll
-      for (int j = 0; j < DOF; ++j) C[i][j] = p.qc_fix[i * DOF + j];
-  }
+  const bool per = (p.qc_mode == QC_PERSTATE);
+  const bool full = (p.qc_mode == QC_QFULL);
+  const int64_t base = per ? (b * (p.n - 1) + f) * (DOF * DOF) : 0;
+  const int64_t fbase = full ? (b * (p.n - 1) + f) * (D * D) : 0;
+  double c[DOF][DOF];
 #pragma unroll
   for (int i = 0; i < DOF; ++i)
 #pragma unroll
-    for (int j = 0; j < DOF; ++j) {
-      if (j >= i) {
-        Q(i, j) = p.qa * C[i][j];
-        Q(DOF + i, DOF + j) = p.qc_ * C[i][j];
-      }
-      Q(i, DOF + j) = p.qb * C[i][j];      // upper-right block (all entries are in the packed upper triangle)
+    for (int j = 0; j < DOF; ++j) c[i][j] = per ? ld<IO>(p.qc, base + i * DOF + j) : p.qc_fix[i * DOF + j];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      const double coef = (j < DOF) ? p.qa : ((i >= DOF) ? p.qc_ : p.qb);      // blocks [[qa C, qb C],[qb C, qc C]]
+      double v = coef * c[i % DOF][j % DOF];
+      if (full) v = ld<IO>(p.qc, fbase + i * D + j);
+      Q(i, j) = v;
     }
 }
 
@@ -424,34 +413,6 @@ DGP_HD void fixed_Qinv(const GnParams& p, Sym<2 * DOF>& Q) {
         Q(DOF + i, DOF + j) = p.qc_ * c;
       }
       Q(i, DOF + j) = p.qb * c;
-    }
-}
-
-// Blocks one GP factor (g -> g+1) contributes: Q^-1, Phi^T Q^-1 and Phi^T Q^-1 Phi.  With static covariances they are the
-// same for every factor and are built once per lane.
-template <int DOF>
-struct GpBlk {
-  Sym<2 * DOF> Q;
-  double PQ[2 * DOF][2 * DOF];     // Phi^T Q : rows pos = Q[pos,:], rows vel = dt*Q[pos,:] + Q[vel,:]
-  Sym<2 * DOF> PQP;                // Phi^T Q Phi
-};
-
-template <int DOF>
-DGP_HD void build_gp_blk(double dt, GpBlk<DOF>& g) {
-  constexpr int D = 2 * DOF;
-#pragma unroll
-  for (int a = 0; a < DOF; ++a)
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      g.PQ[a][c] = g.Q(a, c);
-      g.PQ[DOF + a][c] = dt * g.Q(a, c) + g.Q(DOF + a, c);
-    }
-#pragma unroll
-  for (int a = 0; a < D; ++a)
-#pragma unroll
-    for (int c = 0; c < DOF; ++c) {
-      if (c >= a) g.PQP(a, c) = g.PQ[a][c];
-      if (DOF + c >= a) g.PQP(a, DOF + c) = dt * g.PQ[a][c] + g.PQ[a][DOF + c];
     }
 }
 
@@ -471,7 +432,7 @@ DGP_HD double quad(const Sym<D>& Q, const double (&e)[D]) {      // e^T Q e
 // ---------------------------------------------------------------------------------------------------
 // factor evaluation for ONE support state (row g of the block-tridiagonal system)
 //   -> diagonal block Dm, coupling U to row g+1, eta r, and the partial error sums.
-// `own` holds the blocks of the GP factor (g -> g+1), Qm is Q^-1 of the factor (g-1 -> g) (ignored for g == 0);
+// Qown is Q^-1 of the GP factor (g -> g+1), Qm is Q^-1 of the factor (g-1 -> g) (ignored for g == 0);
 // (oc, ohx, ohy) is the obstacle factor of this state, evaluated beforehand (all SDF lookups of a lane are issued
 // together, ahead of the elimination sweep, so that their memory latency overlaps).
 // ---------------------------------------------------------------------------------------------------
@@ -482,9 +443,8 @@ struct ErrAcc {
 
 template <int DOF, typename IO, bool ASSEMBLE>
 DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
-                       const double (&xp)[2 * DOF], const GpBlk<DOF>& own, const Sym<2 * DOF>& Qm, const Sym<2 * DOF>& Qfix,
-                       double ow, double oc, double ohx, double ohy, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U, double (&r)[2 * DOF],
-                       ErrAcc& acc) {
+                       const double (&xp)[2 * DOF], const Sym<2 * DOF>& Qown, const Sym<2 * DOF>& Qm, double ow, double oc,
+                       double ohx, double ohy, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U, double (&r)[2 * DOF], ErrAcc& acc) {
   constexpr int D = 2 * DOF;
   const int n = p.n;
   if (ASSEMBLE) {
@@ -526,24 +486,40 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
       e[a] = xp[a] - (x[a] + dt * x[DOF + a]);
       e[DOF + a] = xp[DOF + a] - x[DOF + a];
     }
-    const double q = quad<D>(own.Q, e);
+    const double q = quad<D>(Qown, e);
     acc.e += 0.5 * q;
     double s2 = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) s2 += e[a] * e[a];
     acc.ugp += 0.5 * s2;
-    acc.eext += (p.qc_mode == QC_STATIC) ? 0.5 * q : 0.5 * quad<D>(Qfix, e);      // plan_layer.py:318-321
+    if (p.qc_mode == QC_STATIC) {
+      acc.eext += 0.5 * q;
+    } else {
+      Sym<D> Qf;
+      fixed_Qinv<DOF>(p, Qf);
+      acc.eext += 0.5 * quad<D>(Qf, e);                    // plan_layer.py:318-321 (fixed GP weight)
+    }
     if (ASSEMBLE) {
+      // U = -Phi^T Q : rows pos = Q[pos,:], rows vel = dt*Q[pos,:] + Q[vel,:]     (block (g,g+1) = H1^T Q^-1 H2)
+#pragma unroll
+      for (int a = 0; a < DOF; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          U.v[a][c] = -Qown(a, c);
+          U.v[DOF + a][c] = -(dt * Qown(a, c) + Qown(DOF + a, c));
+        }
+      // Dm += Phi^T Q Phi = -U Phi : cols pos = -U[:,pos], cols vel = -(dt*U[:,pos] + U[:,vel]);   eta += Phi^T Q e = -U e
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-          if (c >= a) Dm(a, c) += own.PQP(a, c);           // H1^T Q^-1 H1 = Phi^T Q^-1 Phi
-          U.v[a][c] = -own.PQ[a][c];                       // block (g,g+1) = H1^T Q^-1 H2 = -Phi^T Q^-1
-          t += own.PQ[a][c] * e[c];
+        for (int c = 0; c < DOF; ++c) {
+          if (c >= a) Dm(a, c) -= U.v[a][c];
+          if (DOF + c >= a) Dm(a, DOF + c) -= dt * U.v[a][c] + U.v[a][DOF + c];
         }
-        r[a] += t;                                         // H1^T Q^-1 e
+#pragma unroll
+        for (int c = 0; c < D; ++c) t += U.v[a][c] * e[c];
+        r[a] -= t;
       }
     }
   }
@@ -608,12 +584,11 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
   }
 }
 
-// Per-lane inputs that do not depend on the elimination: obstacle factors of the lane's C states (all SDF loads issued
-// together) and the GP blocks (built once for static covariances).
+// Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
+// issued together).
 template <int DOF, int C, typename IO>
 struct LaneFactors {
   double ow[C], oc[C], ohx[C], ohy[C];
-  GpBlk<DOF> stat;           // blocks of the static Q^-1 (also the FIXED Q^-1 of err_ext)
 };
 
 template <int DOF, int C, typename IO>
@@ -631,8 +606,6 @@ DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, co
       obstacle_eval<IO>(p, grid, x[k][0], x[k][1], eps, f.oc[k], f.ohx[k], f.ohy[k]);
     }
   }
-  fixed_Qinv<DOF>(p, f.stat.Q);
-  build_gp_blk<DOF>(p.dt, f.stat);
 }
 
 // small dense helpers on dxd blocks -----------------------------------------------------------------
@@ -928,8 +901,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   LaneFactors<DOF, C, IO> lf;
   lane_prefetch<DOF, C, IO>(p, b, g0, traj_ok, x, lf);
   const bool stat = (p.qc_mode == QC_STATIC);
-  GpBlk<DOF> blk = lf.stat;      // blocks of the current row's own GP factor (per-state modes: rebuilt per row)
-  Sym<D> Qm = lf.stat.Q;         // Q^-1 of the factor (g-1 -> g)
+  Sym<D> Qown, Qm;               // Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
+  fixed_Qinv<DOF>(p, Qown);      // static covariances: built once; per-state modes: reloaded per row
+  fixed_Qinv<DOF>(p, Qm);
   Mat<D> Uprev = {};             // U of the previous row (k-1)
   if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
 
@@ -939,9 +913,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
     Sym<D> Dk; Mat<D> Uk; double rk[D];
-    if (!stat && valid && g < n - 1) { load_Qinv<DOF, IO>(p, b, g, blk.Q); build_gp_blk<DOF>(p.dt, blk); }
-    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], blk, Qm, lf.stat.Q,
-                              lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
+    if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
+    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Qown, Qm, lf.ow[k], lf.oc[k],
+                              lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
@@ -968,7 +942,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     sym_inverse<D>(Dk, Sinv[k], ok);
     sym_times_mat<D>(Sinv[k], Uk, G[k]);                  // G_k = S_k^-1 U_k
     Uprev = Uk;
-    if (!stat) Qm = blk.Q;
+    if (!stat) Qm = Qown;
   }
   // ---- b. back substitution: P, V, W in place
   if (C > 1) {
@@ -1002,9 +976,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   {
     const int g = g0 + C - 1;
     const bool valid = traj_ok && g < n;
-    if (!stat && valid && g < n - 1) { load_Qinv<DOF, IO>(p, b, g, blk.Q); build_gp_blk<DOF>(p.dt, blk); }
-    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, blk, Qm, lf.stat.Q,
-                              lf.ow[C - 1], lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
+    if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
+    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Qown, Qm, lf.ow[C - 1],
+                              lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rs[a] = valid ? rhs[C - 1][a] : 0.0;
@@ -1061,15 +1035,16 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
   LaneFactors<DOF, C, IO> lf;
   lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
   const bool stat = (p.qc_mode == QC_STATIC);
-  GpBlk<DOF> blk = lf.stat;
+  Sym<D> Qown;
+  fixed_Qinv<DOF>(p, Qown);
   Sym<D> Dk; Mat<D> Uk; double rk[D];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int g = j * C + k;
     const bool valid = traj_ok && g < p.n;
-    if (!stat && valid && g < p.n - 1) load_Qinv<DOF, IO>(p, b, g, blk.Q);
-    eval_state<DOF, IO, false>(p, b, g, valid, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, blk, lf.stat.Q, lf.stat.Q,
-                               lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
+    if (!stat && valid && g < p.n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
+    eval_state<DOF, IO, false>(p, b, g, valid, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, Qown, Qown, lf.ow[k],
+                               lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
   }
 }
 

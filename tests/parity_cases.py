@@ -320,7 +320,7 @@ def case_unaligned_buffers(be, golden, io):
     be.misalign = False
   assert np.array_equal(d0, d1) and np.array_equal(e0, e1) and np.array_equal(x0, x1)
   assert np.array_equal(r0['th'], r1['th']) and np.array_equal(r0['start'], r1['start'])
-  assert rel_err(r1['sdf'], r0['sdf']) < 1e-12          # atomics: summation order may differ
+  assert rel_err(r1['sdf'], r0['sdf']) < (1e-12 if io == 'f64' else 1e-5)          # atomics: summation order may differ
 
 
 ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, case_c1, case_small_ragged, case_edges,
