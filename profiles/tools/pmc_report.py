@@ -25,12 +25,12 @@ try:
         (wide_f, known / (max(v[1] for v in vals['copy']['WRITE_SIZE']) * 1024.0)))
   cf = max(v[1] for v in vals['calib']['FETCH_SIZE']); cw = max(v[1] for v in vals['calib']['WRITE_SIZE'])
   kf = known / (cf * 1024.0); kw = known / (cw * 1024.0)
-  print('# dword-granular calibration kernel (the GN kernel own pattern): FETCH_SIZE correction %.3f, WRITE_SIZE correction %.3f' % (kf, kw))
+  print('# calibration kernel in the GN kernel's own row access pattern: FETCH_SIZE correction %.3f, WRITE_SIZE correction %.3f' % (kf, kw))
   gf = vals['gn_kernel']['FETCH_SIZE'][0][1]; gw = vals['gn_kernel']['WRITE_SIZE'][0][1]
   out = {'fetch_size_kb_raw': gf, 'write_size_kb_raw': gw, 'fetch_correction': kf, 'write_correction': kw,
          'hbm_bytes_per_launch': gf * 1024.0 * kf + gw * 1024.0 * kw,
          'note': 'FETCH_SIZE/WRITE_SIZE (KB) of gn_kernel per dispatch, each scaled by known_bytes/reported_bytes of a 256 MiB '
-                 'calibration kernel with the GN kernel\'s own access pattern (16 dword loads/stores per lane, 64 B lane stride), '
+                 'calibration kernel with the GN kernel\'s own access pattern (four float4 loads + four float4 stores per lane, 64 B lane stride), '
                  'measured in the same rocprofv3 passes, as MI355X_MICROARCH.md prescribes for non-wide access widths'}
   print(json.dumps(out))
   if len(sys.argv) > 2: json.dump(out, open(sys.argv[2], 'w'), indent=1)
