@@ -45,7 +45,7 @@ class DiffGPMP2Planner(nn.Module):
     self.use_vel_limits = planner_params['use_vel_limits'] if 'use_vel_limits' in planner_params else False
     self.batch_size = batch_size
     nl = robot_model.nlinks
-    dd = torch.get_default_dtype()
+    dd = torch.float64      # the static covariances are exact copies of the config values (the reference runs under a float64 default)
     mk = lambda shape, v: (torch.zeros(*shape, dtype=dd, device=self.device) + torch.as_tensor(v, dtype=dd, device=self.device))
     self.fixed_conv = False
     self.learn_eps = False
