@@ -122,6 +122,8 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   return DGP_OK;
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 // Fill the per-call part of the kernel arguments; returns DGP_OK or an error code.
 inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                      const DgpCovs* covs, dgp::GnParams& p) {
@@ -140,6 +142,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   p.orig_px = (0. - h->cfg.x_lims[0] / p.res);
   p.orig_py = (0. - h->cfg.y_lims[0] / p.res);
   p.qc_mode = DGP_QC_STATIC; p.qc = nullptr; p.obs_w = nullptr; p.eps = nullptr;
+  p.vec_mu = (aligned16(start) && aligned16(goal)) ? 1 : 0;
   if (covs) {
     if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_QFULL) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
     if ((covs->qc_mode == DGP_QC_STATIC) != (covs->qc_inv == nullptr))
@@ -148,8 +151,6 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   }
   return DGP_OK;
 }
-
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int fill_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                      const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, dgp::GnParams& p) {

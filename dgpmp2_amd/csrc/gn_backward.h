@@ -38,23 +38,20 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   const int g0 = j * C;
 
   const bool vec = p.vec_io != 0;
-  double x[C][D], gbar[C][D], lam[C][D];
+  double x[C][D], gbar[C][D], lam[C][D], mu_s[D], mu_g[D];
+  load_lane_rows<DOF, C, IO>(p, p.th, b, g0, traj_ok, vec, x);
+  ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
+  ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
 #pragma unroll
-  for (int k = 0; k < C; ++k) {
-    const int g = g0 + k;
-    const bool valid = traj_ok && g < n;
+  for (int k = 0; k < C; ++k)
 #pragma unroll
-    for (int a = 0; a < D; ++a) { x[k][a] = 0.0; gbar[k][a] = 0.0; lam[k][a] = 0.0; }
-    if (valid) {
-      ld_row<IO, D>(p.th, b * n + g, vec, x[k]);
-      if (gp.g_dtheta) ld_row<IO, D>(gp.g_dtheta, b * n + g, vec, gbar[k]);
-    }
-  }
+    for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
+  if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.g_dtheta, b, g0, traj_ok, vec, gbar);
   // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
   if (gp.g_dtheta) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, true>(p, cx, b, j, traj_ok, x, gbar, lam, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, true>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok);
   }
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
 
@@ -93,12 +90,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- priors: e = mu - x, H = I, K = w I  ->  dL = w (lambda + ebar e)^T (dmu - dx)
     if (g == 0 || g == n - 1) {
       const bool is_start = (g == 0);
-      const void* mu = is_start ? p.start : p.goal;
       void* gmu = is_start ? gp.g_start : gp.g_goal;
       const double w = is_start ? p.w_s : p.w_g;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
-        const double ea = ld<IO>(mu, b * D + a) - xk[a];
+        const double ea = (is_start ? mu_s[a] : mu_g[a]) - xk[a];
         const double t = w * (lk[a] + ebar * ea);
         gx[a] -= t;
         if (gmu) st<IO>(gmu, b * D + a, t);
@@ -107,7 +103,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
     if (g < n - 1) {
       Sym<D> Q;
-      load_Qinv<DOF, IO>(p, b, g, Q);
+      fixed_Qinv<DOF>(p, Q);
+      if (p.qc_mode != QC_STATIC) load_Qinv<DOF, IO>(p, b, g, Q);
       double e[D], u[D], rho[D];
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {
@@ -166,7 +163,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g-1 -> g): this row's share is +(Q_{g-1} u_{g-1} + ebar Qfix e_{g-1})
     if (g > 0) {
       Sym<D> Q;
-      load_Qinv<DOF, IO>(p, b, g - 1, Q);
+      fixed_Qinv<DOF>(p, Q);
+      if (p.qc_mode != QC_STATIC) load_Qinv<DOF, IO>(p, b, g - 1, Q);
       double e[D], u[D];
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {

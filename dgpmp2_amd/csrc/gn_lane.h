@@ -45,6 +45,8 @@ struct GnParams {
   uint32_t flags;
   int32_t max_iters;
   int32_t vec_io;            // 1: th / dtheta / th_out / gradient rows are 16-byte aligned -> vector row accesses
+  int32_t vec_mu;            // 1: start / goal rows too
+  int32_t pad_;
   const void *th, *start, *goal, *sdf, *qc, *obs_w, *eps;
   void *dtheta, *err, *err_ext;
   int32_t* info;
@@ -316,12 +318,25 @@ DGP_HD void st_row(void* p, int64_t row, bool vec, const double (&x)[D]) {
   }
 }
 
+// The C state rows of a lane, loaded without branches: rows that do not exist read row 0 of the tensor and are zeroed.
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_rows(const GnParams& p, const void* src, int64_t b, int g0, bool traj_ok, bool vec, double (&x)[C][2 * DOF]) {
+  constexpr int D = 2 * DOF;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const bool valid = traj_ok && (g0 + k) < p.n;
+    ld_row<IO, D>(src, valid ? b * p.n + g0 + k : 0, vec, x[k]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) x[k][a] = valid ? x[k][a] : 0.0;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // bilinear SDF lookup + hinge, bit-for-bit the reference's fp64 op order (no FMA contraction here, so
 // the `dist <= eps + r` decision equals the CPU oracle's on identical inputs).
 //   utils/sdf_utils.py:57-94, gpmp2/obstacle/obstacle_cost.py:30,36-37
 // ---------------------------------------------------------------------------------------------------
-// Everything the backward needs from one bilinear lookup (same arithmetic as obstacle_eval below).
+// Everything the backward needs from one bilinear lookup (same arithmetic as obstacle_finish below).
 struct ObsTaps {
   int64_t i11, i21, i12, i22;      // element offsets of the four taps inside the grid
   double wja, wjb, wjc, wjd;       // (fy2-py), (py-fy1), (fx2-px), (px-fx1)
@@ -329,32 +344,41 @@ struct ObsTaps {
   bool act;
 };
 
-template <typename IO>
-DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y, double eps, double& cost, double& hx,
-                          double& hy, ObsTaps* taps = nullptr) {
+// Bilinear lookup, phase 1 (utils/sdf_utils.py:57-72): pixel coordinates and the four (clamped) tap offsets.
+struct ObsAddr {
+  double px, py;
+  int64_t x1, x2, y1, y2;
+};
+
+DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
 #pragma clang fp contract(off)
   const double res = p.res;
-  double px = p.orig_px + x / res;                        // :61
-  double py = p.orig_py - y / res;                        // :62
-  double fpx = floor(px), fpy = floor(py);
+  o.px = p.orig_px + x / res;                             // :61
+  o.py = p.orig_py - y / res;                             // :62
+  double fpx = floor(o.px), fpy = floor(o.py);
   // floor -> int64 -> clamp (:64-72); saturate first so that huge |px| cannot overflow the conversion
   const double big = 1.0e9;
   double cx = fpx < -big ? -big : (fpx > big ? big : fpx);
   double cy = fpy < -big ? -big : (fpy > big ? big : fpy);
-  if (!(cx == cx)) cx = 0.0;                              // NaN coordinates: any in-range index (result is NaN anyway)
+  if (!(cx == cx)) cx = 0.0;                              // NaN coordinates: any in-range index (the result is NaN anyway)
   if (!(cy == cy)) cy = 0.0;
   int64_t x1 = (int64_t)cx, y1 = (int64_t)cy;
   int64_t x2 = x1 + 1, y2 = y1 + 1;                       // :65,67 (before clamping)
   const int64_t W = p.sdf_cols, H = p.sdf_rows;
-  x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
-  x2 = x2 < 0 ? 0 : (x2 > W - 1 ? W - 1 : x2);
-  y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
-  y2 = y2 < 0 ? 0 : (y2 > H - 1 ? H - 1 : y2);
-  double d11 = (double)grid[y1 * W + x1];                 // dx1y1 (:76)
-  double d21 = (double)grid[y1 * W + x2];                 // dx2y1
-  double d12 = (double)grid[y2 * W + x1];                 // dx1y2
-  double d22 = (double)grid[y2 * W + x2];                 // dx2y2
-  double fx1 = (double)x1, fx2 = (double)x2, fy1 = (double)y1, fy2 = (double)y2;
+  o.x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
+  o.x2 = x2 < 0 ? 0 : (x2 > W - 1 ? W - 1 : x2);
+  o.y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+  o.y2 = y2 < 0 ? 0 : (y2 > H - 1 ? H - 1 : y2);
+}
+
+// Phase 2 (utils/sdf_utils.py:81-94, obstacle_cost.py:30,36-37): weights, distance, gradient, hinge -- bit-for-bit the
+// reference's fp64 op order (no FMA contraction here, so the `dist <= eps + r` decision equals the CPU oracle's).
+DGP_HD void obstacle_finish(const GnParams& p, const ObsAddr& o, double d11, double d21, double d12, double d22, double eps,
+                            double& cost, double& hx, double& hy, ObsTaps* taps = nullptr) {
+#pragma clang fp contract(off)
+  const double res = p.res;
+  const double px = o.px, py = o.py;
+  double fx1 = (double)o.x1, fx2 = (double)o.x2, fy1 = (double)o.y1, fy2 = (double)o.y2;
   double wa = (fx2 - px) * (fy2 - py);                    // :81-84
   double wb = (px - fx1) * (fy2 - py);
   double wc = (fx2 - px) * (py - fy1);
@@ -368,36 +392,51 @@ DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y,
   hx = act ? (-1.0 * Jx) : 0.0;                           // :37
   hy = act ? (-1.0 * Jy) : 0.0;
   if (taps) {
-    taps->i11 = y1 * W + x1; taps->i21 = y1 * W + x2; taps->i12 = y2 * W + x1; taps->i22 = y2 * W + x2;
+    const int64_t W = p.sdf_cols;
+    taps->i11 = o.y1 * W + o.x1; taps->i21 = o.y1 * W + o.x2; taps->i12 = o.y2 * W + o.x1; taps->i22 = o.y2 * W + o.x2;
     taps->wja = fy2 - py; taps->wjb = py - fy1; taps->wjc = fx2 - px; taps->wjd = px - fx1;
     taps->cross = d22 - d12 - d21 + d11;
     taps->act = act;
   }
 }
 
+template <typename IO>
+DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y, double eps, double& cost, double& hx,
+                          double& hy, ObsTaps* taps = nullptr) {
+  ObsAddr o;
+  obstacle_addr(p, x, y, o);
+  const int64_t W = p.sdf_cols;
+  const double d11 = (double)grid[o.y1 * W + o.x1], d21 = (double)grid[o.y1 * W + o.x2];      // dx1y1, dx2y1 (:76-77)
+  const double d12 = (double)grid[o.y2 * W + o.x1], d22 = (double)grid[o.y2 * W + o.x2];      // dx1y2, dx2y2 (:78-79)
+  obstacle_finish(p, o, d11, d21, d12, d22, eps, cost, hx, hy, taps);
+}
+
 // Q^-1 of one GP factor (gp_factor.py:65-73 / plan_layer.py:90)
+// Per-state Q^-1 of GP factor f (only for the non-static modes: p.qc != null).  All loads are unconditional and issued
+// together (a wave-uniform address select instead of per-element branches, each of which would cost its own s_waitcnt);
+// every entry of Q is assigned exactly once, in straight-line code (an aggregate written on two control-flow paths ends
+// up partly in scratch memory).
 template <int DOF, typename IO>
 DGP_HD void load_Qinv(const GnParams& p, int64_t b, int f, Sym<2 * DOF>& Q) {
-  // NB every entry of Q is assigned exactly once, in straight-line code: writing the aggregate on two control-flow paths
-  // (an early-return branch per mode) leaves part of it in scratch memory (measured: 49 scratch accesses per lane).
   constexpr int D = 2 * DOF;
-  const bool per = (p.qc_mode == QC_PERSTATE);
   const bool full = (p.qc_mode == QC_QFULL);
-  const int64_t base = per ? (b * (p.n - 1) + f) * (DOF * DOF) : 0;
-  const int64_t fbase = full ? (b * (p.n - 1) + f) * (D * D) : 0;
+  const IO* src = (const IO*)p.qc + (b * (p.n - 1) + f) * (full ? D * D : DOF * DOF);
   double c[DOF][DOF];
 #pragma unroll
   for (int i = 0; i < DOF; ++i)
 #pragma unroll
-    for (int j = 0; j < DOF; ++j) c[i][j] = per ? ld<IO>(p.qc, base + i * DOF + j) : p.qc_fix[i * DOF + j];
+    for (int j = 0; j < DOF; ++j) c[i][j] = (double)src[i * DOF + j];          // per-state mode: C = Q_c^-1 (dof x dof)
+  double fq[D * (D + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) fq[Sym<D>::idx(i, j)] = (double)src[full ? i * D + j : 0];   // q_full mode: Q^-1 itself
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int j = i; j < D; ++j) {
       const double coef = (j < DOF) ? p.qa : ((i >= DOF) ? p.qc_ : p.qb);      // blocks [[qa C, qb C],[qb C, qc C]]
-      double v = coef * c[i % DOF][j % DOF];
-      if (full) v = ld<IO>(p.qc, fbase + i * D + j);
-      Q(i, j) = v;
+      Q(i, j) = full ? fq[Sym<D>::idx(i, j)] : coef * c[i % DOF][j % DOF];
     }
 }
 
@@ -433,8 +472,8 @@ DGP_HD double quad(const Sym<D>& Q, const double (&e)[D]) {      // e^T Q e
 // factor evaluation for ONE support state (row g of the block-tridiagonal system)
 //   -> diagonal block Dm, coupling U to row g+1, eta r, and the partial error sums.
 // Qown is Q^-1 of the GP factor (g -> g+1), Qm is Q^-1 of the factor (g-1 -> g) (ignored for g == 0);
-// (oc, ohx, ohy) is the obstacle factor of this state, evaluated beforehand (all SDF lookups of a lane are issued
-// together, ahead of the elimination sweep, so that their memory latency overlaps).
+// (oc, ohx, ohy) is the obstacle factor of this state and mu_s / mu_g the start / goal means of the trajectory, all loaded
+// beforehand (every load of a lane is issued up front, branch-free, so that the memory latencies overlap).
 // ---------------------------------------------------------------------------------------------------
 struct ErrAcc {
   double e, eext;          // partial sums of err / err_ext (un-normalised)
@@ -443,8 +482,9 @@ struct ErrAcc {
 
 template <int DOF, typename IO, bool ASSEMBLE>
 DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
-                       const double (&xp)[2 * DOF], const Sym<2 * DOF>& Qown, const Sym<2 * DOF>& Qm, double ow, double oc,
-                       double ohx, double ohy, Sym<2 * DOF>& Dm, Mat<2 * DOF>& U, double (&r)[2 * DOF], ErrAcc& acc) {
+                       const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
+                       const Sym<2 * DOF>& Qown, const Sym<2 * DOF>& Qm, double ow, double oc, double ohx, double ohy,
+                       Sym<2 * DOF>& Dm, Mat<2 * DOF>& U, double (&r)[2 * DOF], ErrAcc& acc) {
   constexpr int D = 2 * DOF;
   const int n = p.n;
   if (ASSEMBLE) {
@@ -466,12 +506,11 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
   // ---- start / goal priors: e = mu - x, H = +I, weight I/K^2 (prior_factor.py:15-18; plan_layer.py:64-68)
   if (g == 0 || g == n - 1) {
     const bool is_start = (g == 0);                        // n >= 2 (host-enforced): rows 0 and n-1 are distinct
-    const void* mu = is_start ? p.start : p.goal;
     const double w = is_start ? p.w_s : p.w_g;
     double s2 = 0.0;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      const double ea = ld<IO>(mu, b * D + a) - x[a];
+      const double ea = (is_start ? mu_s[a] : mu_g[a]) - x[a];
       s2 += ea * ea;
       if (ASSEMBLE) { Dm(a, a) += w; r[a] += w * ea; }
     }
@@ -591,20 +630,39 @@ struct LaneFactors {
   double ow[C], oc[C], ohx[C], ohy[C];
 };
 
+// All loads are UNCONDITIONAL (rows / trajectories that do not exist read element 0 of the same tensor and are masked
+// afterwards): a load inside a divergent `if (valid)` costs its own s_waitcnt, i.e. one exposed memory round trip each.
 template <int DOF, int C, typename IO>
 DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<DOF, C, IO>& f) {
   const int n = p.n;
+  const int64_t W = p.sdf_cols;
   const IO* grid = (const IO*)p.sdf + (traj_ok ? b : 0) * p.sdf_bstride;
+  double eps[C];
+  ObsAddr oa[C];
+  double d11[C], d21[C], d12[C], d22[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    const int g = g0 + k;
-    const bool valid = traj_ok && g < n;
-    f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0;
-    if (valid) {
-      const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
-      f.ow[k] = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
-      obstacle_eval<IO>(p, grid, x[k][0], x[k][1], eps, f.oc[k], f.ohx[k], f.ohy[k]);
-    }
+    eps[k] = p.eps_static; f.ow[k] = p.obs_w_fix;
+    obstacle_addr(p, x[k][0], x[k][1], oa[k]);
+  }
+  if (p.eps) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) eps[k] = ld<IO>(p.eps, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
+  }
+  if (p.obs_w) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) f.ow[k] = ld<IO>(p.obs_w, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    d11[k] = (double)grid[oa[k].y1 * W + oa[k].x1]; d21[k] = (double)grid[oa[k].y1 * W + oa[k].x2];
+    d12[k] = (double)grid[oa[k].y2 * W + oa[k].x1]; d22[k] = (double)grid[oa[k].y2 * W + oa[k].x2];
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const bool valid = traj_ok && (g0 + k) < n;
+    obstacle_finish(p, oa[k], d11[k], d21[k], d12[k], d22[k], eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
+    if (!valid) { f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0; }
   }
 }
 
@@ -884,7 +942,8 @@ DGP_HD int group_or(Ctx& cx, int v) {
 // ---------------------------------------------------------------------------------------------------
 template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, typename Ctx>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
-                            const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
+                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
+                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
   constexpr int D = 2 * DOF;
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
   const int n = p.n;
@@ -914,8 +973,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const bool valid = traj_ok && g < n;
     Sym<D> Dk; Mat<D> Uk; double rk[D];
     if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Qown, Qm, lf.ow[k], lf.oc[k],
-                              lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
+    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], mu_s, mu_g, Qown, Qm, lf.ow[k],
+                              lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
@@ -977,8 +1036,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const int g = g0 + C - 1;
     const bool valid = traj_ok && g < n;
     if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Qown, Qm, lf.ow[C - 1],
-                              lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
+    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, mu_s, mu_g, Qown, Qm,
+                              lf.ow[C - 1], lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rs[a] = valid ? rhs[C - 1][a] : 0.0;
@@ -1026,7 +1085,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 
 // errors only (no assembly): sums over the lane's C rows
 template <int DOF, int LPT, int C, typename IO, typename Ctx>
-DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF], ErrAcc& acc) {
+DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
+                         const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], ErrAcc& acc) {
   constexpr int D = 2 * DOF;
   const Nbr<LPT, 1, Ctx> nb(cx, j);
   double x_next[D];
@@ -1043,8 +1103,8 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
     const int g = j * C + k;
     const bool valid = traj_ok && g < p.n;
     if (!stat && valid && g < p.n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-    eval_state<DOF, IO, false>(p, b, g, valid, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, Qown, Qown, lf.ow[k],
-                               lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
+    eval_state<DOF, IO, false>(p, b, g, valid, x[k], x[k], (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next, mu_s, mu_g, Qown, Qown,
+                               lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
   }
 }
 
@@ -1062,18 +1122,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const bool traj_ok = b < p.B;
 
   const bool vec = p.vec_io != 0;
-  double x[C][D];
-#pragma unroll
-  for (int k = 0; k < C; ++k) {
-    const int g = j * C + k;
-#pragma unroll
-    for (int a = 0; a < D; ++a) x[k][a] = 0.0;
-    if (traj_ok && g < n) ld_row<IO, D>(p.th, b * n + g, vec, x[k]);
-  }
+  double x[C][D], mu_s[D], mu_g[D];
+  load_lane_rows<DOF, C, IO>(p, p.th, b, j * C, traj_ok, vec, x);
+  ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
+  ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
 
   if (MODE == MODE_EVAL) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
-    gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, acc);
+    gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
     const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
     const double usg = group_sum<LPT>(cx, acc.usg), ugp = group_sum<LPT>(cx, acc.ugp), uobs = group_sum<LPT>(cx, acc.uobs);
     if (traj_ok && j == 0) {
@@ -1095,7 +1151,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, false>(p, cx, b, j, traj_ok, x, x, dx, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, false>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
     const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
@@ -1141,7 +1197,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     if (traj_ok && j == 0 && p.iters) p.iters[b] = my_iters;
     if (p.err_final) {
       ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
-      gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, acc);
+      gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
       const double e = group_sum<LPT>(cx, acc.e);
       if (traj_ok && j == 0) st<IO>(p.err_final, b, e / p.M);
     }

@@ -25,7 +25,7 @@ try:
         (wide_f, known / (max(v[1] for v in vals['copy']['WRITE_SIZE']) * 1024.0)))
   cf = max(v[1] for v in vals['calib']['FETCH_SIZE']); cw = max(v[1] for v in vals['calib']['WRITE_SIZE'])
   kf = known / (cf * 1024.0); kw = known / (cw * 1024.0)
-  print('# calibration kernel in the GN kernel's own row access pattern: FETCH_SIZE correction %.3f, WRITE_SIZE correction %.3f' % (kf, kw))
+  print('# calibration kernel in the GN kernel own row access pattern: FETCH_SIZE correction %.3f, WRITE_SIZE correction %.3f' % (kf, kw))
   gf = vals['gn_kernel']['FETCH_SIZE'][0][1]; gw = vals['gn_kernel']['WRITE_SIZE'][0][1]
   out = {'fetch_size_kb_raw': gf, 'write_size_kb_raw': gw, 'fetch_correction': kf, 'write_correction': kw,
          'hbm_bytes_per_launch': gf * 1024.0 * kf + gw * 1024.0 * kw,
