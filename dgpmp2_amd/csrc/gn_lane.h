@@ -916,6 +916,21 @@ DGP_HD double group_sum(Ctx& cx, double v) {
   for (int m = LPT / 2; m >= 1; m >>= 1) v += cx.fetch(v, lane ^ m);
   return v;
 }
+// sum over the LPT lanes of one trajectory, valid in the FIRST lane of the group only (that is where err / err_ext are
+// written from).  With 16 lanes per trajectory it is four DPP row shifts + adds, no LDS round trips.
+template <int LPT, typename Ctx>
+DGP_HD double group_sum_to_first(Ctx& cx, double v) {
+  if constexpr (LPT == 16) {
+    v += cx.template row_from_upper<8>(v);
+    v += cx.template row_from_upper<4>(v);
+    v += cx.template row_from_upper<2>(v);
+    v += cx.template row_from_upper<1>(v);
+    return v;
+  } else {
+    return group_sum<LPT>(cx, v);
+  }
+}
+
 template <int LPT, typename Ctx>
 DGP_HD int group_or(Ctx& cx, int v) {
   const int lane = cx.lane();
@@ -1130,8 +1145,9 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   if (MODE == MODE_EVAL) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
-    const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
-    const double usg = group_sum<LPT>(cx, acc.usg), ugp = group_sum<LPT>(cx, acc.ugp), uobs = group_sum<LPT>(cx, acc.uobs);
+    const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
+    const double usg = group_sum_to_first<LPT>(cx, acc.usg), ugp = group_sum_to_first<LPT>(cx, acc.ugp);
+    const double uobs = group_sum_to_first<LPT>(cx, acc.uobs);
     if (traj_ok && j == 0) {
       if (p.err) st<IO>(p.err, b, e / p.M);
       if (p.err_ext) st<IO>(p.err_ext, b, ee / p.M);
@@ -1152,7 +1168,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     double dx[C][D];
     bool ok = true;
     gn_linear_solve<DOF, LPT, C, IO, false>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
-    const double e = group_sum<LPT>(cx, acc.e), ee = group_sum<LPT>(cx, acc.eext);
+    const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
 #pragma unroll
@@ -1198,7 +1214,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     if (p.err_final) {
       ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
       gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
-      const double e = group_sum<LPT>(cx, acc.e);
+      const double e = group_sum_to_first<LPT>(cx, acc.e);
       if (traj_ok && j == 0) st<IO>(p.err_final, b, e / p.M);
     }
   }

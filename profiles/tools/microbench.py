@@ -1,37 +1,54 @@
 #!/usr/bin/env python
-"""Kernel-level timing of dgp_gn_step / dgp_gn_solve at several shapes (HIP events), for tuning rounds.
-usage: python profiles/tools/microbench.py [--reps 200]"""
-import argparse, ctypes, json, os, sys, time
+"""Kernel-level timing (HIP events) of every C-ABI entry point on the benchmark workload: dgp_gn_step, dgp_gn_solve
+(10 fused GN iterations), dgp_eval_errors, dgp_gn_step_backward.   usage: python profiles/tools/microbench.py [--reps 100]"""
+import argparse, ctypes, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from bench import make_inputs, algorithmic_bytes_per_trajectory
+from bench import make_inputs
 from dgpmp2_amd import _capi
 from dgpmp2_amd.gpmp2.plan_layer import solver_config
 
 
-def time_step(B, n, G, dtype, reps, dof=2):
+def timed(f, reps):
+  for _ in range(5): f()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize(); e0.record()
+  for _ in range(reps): f()
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps * 1e3
+
+
+def run(B, n, G, dtype, reps, percov=False):
   dev = torch.device('cuda:0')
-  th0, start, goal, sdf = make_inputs(B, n, G, dev)
-  th0, start, goal, sdf = [t.to(dtype) for t in (th0, start, goal, sdf)]
-  s = _capi.Solver(solver_config(n, dof, dtype))
+  th0, start, goal, sdf = [t.to(dtype) for t in make_inputs(B, n, G, dev)]
+  s = _capi.Solver(solver_config(n, 2, dtype))
   sa = s.sdf_arg(sdf.data_ptr(), G, G, 0)
   st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-  dth = torch.empty_like(th0); err = torch.empty(B, device=dev, dtype=dtype); eex = torch.empty(B, device=dev, dtype=dtype)
-  f = lambda: s.gn_step(B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sa, None, dth.data_ptr(), err.data_ptr(), eex.data_ptr(), None, st)
-  for _ in range(10): f()
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  torch.cuda.synchronize(); t0 = time.perf_counter(); e0.record()
-  for _ in range(reps): f()
-  e1.record(); torch.cuda.synchronize(); wall = time.perf_counter() - t0
-  ms = e0.elapsed_time(e1) / reps
-  by = algorithmic_bytes_per_trajectory(n, 2 * dof, io_bytes=4 if dtype == torch.float32 else 8) * B
-  return dict(B=B, n=n, G=G, dtype=str(dtype), kernel_us=ms * 1e3, wall_us=wall / reps * 1e6, GBs=by / (ms * 1e-3) / 1e9)
+  dth = torch.empty_like(th0); err = torch.empty(B, device=dev, dtype=dtype); eex = torch.empty_like(err)
+  covs = None; keep = []
+  if percov:
+    qc = torch.eye(2, device=dev, dtype=dtype).expand(B, n - 1, 2, 2).contiguous(); ow = torch.full((B, n), 1e4, device=dev, dtype=dtype)
+    ep = torch.full((B, n), 0.4, device=dev, dtype=dtype); keep = [qc, ow, ep]
+    covs = s.covs_arg(_capi.DGP_QC_PERSTATE, qc.data_ptr(), ow.data_ptr(), ep.data_ptr())
+  P = lambda t: t.data_ptr()
+  out = dict(B=B, n=n, io=str(dtype).split('.')[-1], covs='per-state tensors' if percov else 'static', shape=s.launch_shape(B))
+  out['gn_step_us'] = timed(lambda: s.gn_step(B, P(th0), P(start), P(goal), sa, covs, P(dth), P(err), P(eex), None, st), reps)
+  tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev); eh = torch.empty(B, 10, device=dev, dtype=dtype)
+  out['gn_solve_10iters_us'] = timed(lambda: s.gn_solve(B, P(th0), P(start), P(goal), sa, covs, 10, 0.0, P(tho), P(it), P(eh), None, P(err), None, st), max(5, reps // 10))
+  out['eval_errors_us'] = timed(lambda: s.eval_errors(B, P(th0), P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st), reps)
+  g = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
+  gs = torch.zeros_like(sdf); ge = torch.ones(B, device=dev, dtype=dtype)
+  gq = torch.empty_like(keep[0]) if percov else None; gw = torch.empty(B, n, device=dev, dtype=dtype) if percov else None
+  gp = torch.empty(B, n, device=dev, dtype=dtype) if percov else None
+  PP = lambda t: None if t is None else t.data_ptr()
+  out['gn_step_backward_us'] = timed(lambda: s.gn_step_backward(B, P(th0), P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo),
+                                                                P(gs), 0, PP(gq), PP(gw), PP(gp), st), reps)
+  return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}
 
 
 if __name__ == '__main__':
-  ap = argparse.ArgumentParser(); ap.add_argument('--reps', type=int, default=200); a = ap.parse_args()
+  ap = argparse.ArgumentParser(); ap.add_argument('--reps', type=int, default=100); a = ap.parse_args()
   import __graft_entry__; __graft_entry__.build()
-  for (B, n, G, dt) in [(4096, 64, 256, torch.float32), (4096, 64, 256, torch.float64), (32768, 64, 256, torch.float32),
-                        (1024, 64, 256, torch.float32), (4096, 32, 256, torch.float32), (4096, 16, 256, torch.float32)]:
-    print(json.dumps(time_step(B, n, G, dt, a.reps)))
+  for (B, n, dt, pc) in [(4096, 64, torch.float32, False), (4096, 64, torch.float32, True), (4096, 64, torch.float64, False), (32768, 64, torch.float32, False)]:
+    print(json.dumps(run(B, n, 256, dt, a.reps if B <= 4096 else 20, pc)), flush=True)

@@ -325,3 +325,29 @@ def case_unaligned_buffers(be, golden, io):
 
 ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, case_c1, case_small_ragged, case_edges,
              case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd, case_backward_golden, case_backward_fd, case_unaligned_buffers]
+
+
+def case_tiny_and_odd_sizes(be, golden, io):
+  """n = 2 (the minimum: start and goal only), n = 3, n = 5 with B = 1, and a batch that is not a multiple of the number of
+  trajectories per wavefront; NaN in one trajectory must not leak into its wave neighbours."""
+  rs = np.random.RandomState(21)
+  sdf = O.circles_sdf(48, O.C2_CIRCLES)[None, None]
+  for n, B in ((2, 1), (3, 2), (5, 7), (17, 3)):
+    p = P2d(n)
+    start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+    goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+    th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + rs.randn(B, n, 4) * 0.1
+    check_step(be, p, th, start, goal, sdf, io, tag='tiny n=%d B=%d' % (n, B))
+  n, B = 5, 7
+  p = P2d(n)
+  start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  goal = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)
+  th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  th_nan = th.copy(); th_nan[2, 1, 0] = np.nan
+  d0, _, _, _ = be.step(p, rnd(th, io), rnd(start, io), rnd(goal, io), rnd(sdf, io), io=io)
+  d1, _, _, _ = be.step(p, rnd(th_nan, io), rnd(start, io), rnd(goal, io), rnd(sdf, io), io=io)
+  keep = [b for b in range(B) if b != 2]
+  assert np.array_equal(d0[keep], d1[keep]) and np.all(np.isnan(d1[2]))
+
+
+ALL_CASES.append(case_tiny_and_odd_sizes)
