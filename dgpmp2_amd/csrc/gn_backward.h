@@ -65,6 +65,18 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   const double dt = p.dt;
   Sym<D> Qf;
   fixed_Qinv<DOF>(p, Qf);
+  // everything the per-row chain rule reads from memory, loaded up front and branch-free: dtheta rows, epsilons / weights,
+  // the four SDF taps of every state (one exposed memory round trip instead of one per divergent branch)
+  double dthr[C][D], dth_next[D];
+#pragma unroll
+  for (int k = 0; k < C; ++k)
+#pragma unroll
+    for (int a = 0; a < D; ++a) dthr[k][a] = 0.0;
+  if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.dtheta, b, g0, traj_ok, vec, dthr);
+#pragma unroll
+  for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
+  LaneTaps<C> taps;
+  lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
 
 #pragma unroll
   for (int k = 0; k < C; ++k) {
@@ -76,13 +88,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     const double* lk = lam[k];
     const double* lm = (k == 0) ? lam_prev : lam[k > 0 ? k - 1 : 0];
     const double* lp = (k == C - 1) ? lam_next : lam[k < C - 1 ? k + 1 : 0];
-    double dth[D], dth_p[D];
-#pragma unroll
-    for (int a = 0; a < D; ++a) { dth[a] = 0.0; dth_p[a] = 0.0; }
-    if (gp.g_dtheta) {
-      ld_row<IO, D>(gp.dtheta, b * n + g, vec, dth);
-      if (g < n - 1) ld_row<IO, D>(gp.dtheta, b * n + g + 1, vec, dth_p);
-    }
+    const double* dth = dthr[k];
+    const double* dth_p = (k == C - 1) ? dth_next : dthr[k < C - 1 ? k + 1 : 0];      // rows past n-1 are zero
     double gx[D];
 #pragma unroll
     for (int a = 0; a < D; ++a) gx[a] = 0.0;
@@ -183,12 +190,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
     // ---- obstacle factor: e = c, H = [hx, hy, 0..], K = omega
     {
-      const double eps = p.eps ? ld<IO>(p.eps, b * n + g) : p.eps_static;
-      const double w = p.obs_w ? ld<IO>(p.obs_w, b * n + g) : p.obs_w_fix;
-      const IO* grid = (const IO*)p.sdf + b * p.sdf_bstride;
+      const double w = taps.ow[k];
       double c, hx, hy;
       ObsTaps tp;
-      obstacle_eval<IO>(p, grid, xk[0], xk[1], eps, c, hx, hy, &tp);
+      obstacle_finish(p, taps.oa[k], taps.d11[k], taps.d21[k], taps.d12[k], taps.d22[k], taps.eps[k], c, hx, hy, &tp);
       double g_eps = 0.0, g_w = 0.0;
       if (tp.act) {
         const double u = hx * lk[0] + hy * lk[1];

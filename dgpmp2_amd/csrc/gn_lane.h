@@ -632,36 +632,46 @@ struct LaneFactors {
 
 // All loads are UNCONDITIONAL (rows / trajectories that do not exist read element 0 of the same tensor and are masked
 // afterwards): a load inside a divergent `if (valid)` costs its own s_waitcnt, i.e. one exposed memory round trip each.
+template <int C>
+struct LaneTaps {
+  ObsAddr oa[C];
+  double d11[C], d21[C], d12[C], d22[C], eps[C], ow[C];
+};
+
 template <int DOF, int C, typename IO>
-DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<DOF, C, IO>& f) {
+DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneTaps<C>& t) {
   const int n = p.n;
   const int64_t W = p.sdf_cols;
   const IO* grid = (const IO*)p.sdf + (traj_ok ? b : 0) * p.sdf_bstride;
-  double eps[C];
-  ObsAddr oa[C];
-  double d11[C], d21[C], d12[C], d22[C];
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    eps[k] = p.eps_static; f.ow[k] = p.obs_w_fix;
-    obstacle_addr(p, x[k][0], x[k][1], oa[k]);
+    t.eps[k] = p.eps_static; t.ow[k] = p.obs_w_fix;
+    obstacle_addr(p, x[k][0], x[k][1], t.oa[k]);
   }
   if (p.eps) {
 #pragma unroll
-    for (int k = 0; k < C; ++k) eps[k] = ld<IO>(p.eps, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
+    for (int k = 0; k < C; ++k) t.eps[k] = ld<IO>(p.eps, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
   }
   if (p.obs_w) {
 #pragma unroll
-    for (int k = 0; k < C; ++k) f.ow[k] = ld<IO>(p.obs_w, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
+    for (int k = 0; k < C; ++k) t.ow[k] = ld<IO>(p.obs_w, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
   }
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    d11[k] = (double)grid[oa[k].y1 * W + oa[k].x1]; d21[k] = (double)grid[oa[k].y1 * W + oa[k].x2];
-    d12[k] = (double)grid[oa[k].y2 * W + oa[k].x1]; d22[k] = (double)grid[oa[k].y2 * W + oa[k].x2];
+    t.d11[k] = (double)grid[t.oa[k].y1 * W + t.oa[k].x1]; t.d21[k] = (double)grid[t.oa[k].y1 * W + t.oa[k].x2];
+    t.d12[k] = (double)grid[t.oa[k].y2 * W + t.oa[k].x1]; t.d22[k] = (double)grid[t.oa[k].y2 * W + t.oa[k].x2];
   }
+}
+
+template <int DOF, int C, typename IO>
+DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<DOF, C, IO>& f) {
+  LaneTaps<C> t;
+  lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, t);
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    const bool valid = traj_ok && (g0 + k) < n;
-    obstacle_finish(p, oa[k], d11[k], d21[k], d12[k], d22[k], eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
+    const bool valid = traj_ok && (g0 + k) < p.n;
+    obstacle_finish(p, t.oa[k], t.d11[k], t.d21[k], t.d12[k], t.d22[k], t.eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
+    f.ow[k] = t.ow[k];
     if (!valid) { f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0; }
   }
 }
