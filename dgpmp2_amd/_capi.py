@@ -19,7 +19,7 @@ DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
 DGP_ABI_VERSION = 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')
+LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
 
 
 class DgpConfig(C.Structure):

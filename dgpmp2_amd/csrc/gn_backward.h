@@ -16,8 +16,6 @@
 
 namespace dgp {
 
-static const bool kBackwardImplemented = true;
-
 struct GnGradParams {
   const void *dtheta;                 // dtheta of the forward pass (B,n,d)
   const void *g_dtheta, *g_err_ext;   // cotangents; either may be null (= 0)

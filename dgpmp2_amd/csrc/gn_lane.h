@@ -1,8 +1,9 @@
 // gn_lane.h -- the per-lane program of the fused Gauss-Newton kernel.
 //
-// Mapping (MI355X, wave64): one trajectory occupies LPT consecutive lanes of a wavefront (LPT = 8..64) and every
+// Mapping (MI355X, wave64): one trajectory occupies LPT consecutive lanes of a wavefront (LPT = 16, 32 or 64) and every
 // lane OWNS C consecutive support states (n <= LPT*C).  Every lane
-//   1. loads its C states, gets the two states across its lane boundaries with cross-lane moves,
+//   1. loads its C states and everything else it reads from memory (start/goal, covariances, SDF taps) up front and
+//      branch-free, gets the two states across its lane boundaries with cross-lane moves (DPP row shifts for LPT = 16),
 //   2. evaluates the factors touching its states and writes their block rows of the block-tridiagonal normal
 //      equations (D sym dxd, U dxd, eta) straight into registers,
 //   3. eliminates its C-1 interior rows locally (block Thomas with a left spike), which leaves ONE row per lane,
@@ -625,8 +626,8 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
 
 // Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
 // issued together).
-template <int DOF, int C, typename IO>
-struct LaneFactors {
+template <int C>
+struct LaneFactors {          // obstacle factor of each of the lane's C states: weight, hinge cost, H = [ohx, ohy, 0..]
   double ow[C], oc[C], ohx[C], ohy[C];
 };
 
@@ -664,7 +665,7 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
 }
 
 template <int DOF, int C, typename IO>
-DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<DOF, C, IO>& f) {
+DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<C>& f) {
   LaneTaps<C> t;
   lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, t);
 #pragma unroll
@@ -982,7 +983,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   Mat<D> G[CI], V[CI], W[CI];
   double P[CI][D];
   const int g0 = j * C;
-  LaneFactors<DOF, C, IO> lf;
+  LaneFactors<C> lf;
   lane_prefetch<DOF, C, IO>(p, b, g0, traj_ok, x, lf);
   const bool stat = (p.qc_mode == QC_STATIC);
   Sym<D> Qown, Qm;               // Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
@@ -1117,7 +1118,7 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
   double x_next[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) x_next[a] = nb.hi(x[0][a]);
-  LaneFactors<DOF, C, IO> lf;
+  LaneFactors<C> lf;
   lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
   const bool stat = (p.qc_mode == QC_STATIC);
   Sym<D> Qown;
