@@ -74,7 +74,7 @@ class CApi(object):
     self.eval_errors.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp]
     self.gn_step_backward = f('gn_step_backward'); self.gn_step_backward.restype = C.c_int
     self.gn_step_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, i64,
-                                      vp, vp, vp, vp]
+                                      i32, vp, vp, vp, vp]
     v = self.abi_version()
     if v != DGP_ABI_VERSION:
       raise ImportError('%s: ABI version %d, binding expects %d' % (path, v, DGP_ABI_VERSION))
@@ -165,7 +165,7 @@ class Solver(object):
                                         C.byref(covs) if covs is not None else None, err, err_ext, unw_sg, unw_gp, unw_obs, stream))
 
   def gn_step_backward(self, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th=None, g_start=None, g_goal=None,
-                       g_sdf=None, g_sdf_batch_stride=0, g_qc_inv=None, g_obs_w=None, g_eps=None, stream=None):
+                       g_sdf=None, g_sdf_batch_stride=0, g_qc_inv=None, g_obs_w=None, g_eps=None, stream=None, g_sdf_copies=1):
     self.api.check(self.api.gn_step_backward(self.handle, batch, th, start, goal, C.byref(sdf),
                                              C.byref(covs) if covs is not None else None, dtheta, g_dtheta, g_err_ext, g_th, g_start,
-                                             g_goal, g_sdf, int(g_sdf_batch_stride), g_qc_inv, g_obs_w, g_eps, stream))
+                                             g_goal, g_sdf, int(g_sdf_batch_stride), int(g_sdf_copies), g_qc_inv, g_obs_w, g_eps, stream))

@@ -186,15 +186,17 @@ inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const vo
 
 inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                          const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
-                         void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w,
-                         void* g_eps, dgp::GnParams& p, dgp::GnGradParams& g) {
+                         void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv,
+                         void* g_obs_w, void* g_eps, dgp::GnParams& p, dgp::GnGradParams& g) {
   int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
   if (rc != DGP_OK) return rc;
   if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
+  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
+  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   if (g_dtheta && !dtheta) return fail(DGP_EINVAL, "dtheta (the forward output) is needed with a g_dtheta cotangent");
   if (g_qc_inv && p.qc_mode == DGP_QC_STATIC) return fail(DGP_EINVAL, "g_qc_inv given but qc_mode is DGP_QC_STATIC");
   g.dtheta = dtheta; g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
-  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
+  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
   p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
 }

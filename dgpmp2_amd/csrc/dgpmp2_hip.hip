@@ -68,12 +68,12 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const voi
 
 int dgp_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                          const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
-                         void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w,
-                         void* g_eps, void* stream) {
+                         void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv,
+                         void* g_obs_w, void* g_eps, void* stream) {
   dgp::GnParams p;
   dgp::GnGradParams g;
   int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
-                                   g_sdf_batch_stride, g_qc_inv, g_obs_w, g_eps, p, g);
+                                   g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
   if (rc != DGP_OK) return rc;
   hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step_backward launch failed: %s", hipGetErrorString(e));

@@ -21,6 +21,7 @@ struct GnGradParams {
   const void *g_dtheta, *g_err_ext;   // cotangents; either may be null (= 0)
   void *g_th, *g_start, *g_goal, *g_sdf, *g_qc, *g_obs_w, *g_eps;
   int64_t g_sdf_bstride;
+  int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
 };
 
 template <int DOF, int LPT, int C, typename IO, typename Ctx>
@@ -207,11 +208,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         g_w = u * rho;
         if (gp.g_sdf) {
           IO* gs = (IO*)gp.g_sdf + b * gp.g_sdf_bstride;
+          const bool local = gp.g_sdf_copies > 1;
+          if (local) gs += (int64_t)(cx.xcc_id() % gp.g_sdf_copies) * ((int64_t)p.sdf_rows * p.sdf_cols);
           const double wa = tp.wjc * tp.wja, wb = tp.wjd * tp.wja, wc = tp.wjc * tp.wjb, wd = tp.wjd * tp.wjb;
-          cx.atomic_add(gs + tp.i11, (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa));
-          cx.atomic_add(gs + tp.i21, (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb));
-          cx.atomic_add(gs + tp.i12, (IO)(al * (-tp.wjb * ir) + be * (-tp.wjc * ir) - ga * wc));
-          cx.atomic_add(gs + tp.i22, (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd));
+          cx.atomic_add(gs + tp.i11, (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa), local);
+          cx.atomic_add(gs + tp.i21, (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb), local);
+          cx.atomic_add(gs + tp.i12, (IO)(al * (-tp.wjb * ir) + be * (-tp.wjc * ir) - ga * wc), local);
+          cx.atomic_add(gs + tp.i22, (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd), local);
         }
       }
       if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);

@@ -36,8 +36,16 @@ struct DevCtx {
     return __hiloint2double(hi, lo);
   }
   __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }
-  __device__ __forceinline__ void atomic_add(float* p, float v) const { atomicAdd(p, v); }
-  __device__ __forceinline__ void atomic_add(double* p, double v) const { atomicAdd(p, v); }
+  // XCD (accelerator complex die) this wavefront runs on, 0..7 on MI355X: HW_REG_XCC_ID (id 20), bits [3:0]
+  __device__ __forceinline__ int xcc_id() const { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }
+  // xcd_local: the target is only touched by wavefronts of THIS XCD during the kernel (a per-XCD partial buffer), so the
+  // read-modify-write may resolve in the XCD's own L2 (workgroup-scope atomic: no sc1, the line stays in L2) instead of at
+  // the memory side, where device-scope atomics from eight non-coherent L2s serialise.
+  template <typename T>
+  __device__ __forceinline__ void atomic_add(T* p, T v, bool xcd_local = false) const {
+    if (xcd_local) __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 };
 
 template <int DOF, int LPT, int C, typename IO, int MODE>

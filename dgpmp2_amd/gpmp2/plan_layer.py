@@ -48,6 +48,9 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
                            cost_sigma=cost_sigma, epsilon_dist=epsilon_dist, **kw)
 
 
+_SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2
+
+
 def _stream():
   return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -99,15 +102,19 @@ class _GNStep(torch.autograd.Function):
     g_th, g_st, g_go = mk(th, need[1]), mk(start, need[2]), mk(goal, need[3])
     shared = sdf.stride(0) == 0 or sdf.shape[0] == 1
     g_sdf = None
+    copies = _SDF_GRAD_COPIES if shared else 1     # shared grid: one partial grid per XCD (XCD-local atomics), summed below
     if need[4]:
-      g_sdf = torch.zeros((1 if shared else B, 1) + tuple(sdf.shape[-2:]), dtype=th.dtype, device=th.device)
+      g_sdf = torch.zeros((copies if shared else B, 1) + tuple(sdf.shape[-2:]), dtype=th.dtype, device=th.device)
     static_qc = covs.qc_mode == _capi.DGP_QC_STATIC
     g_qc = torch.empty(qc.shape, dtype=th.dtype, device=th.device) if (need[5] and not static_qc) else None
     g_ow = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[6] and covs.obs_w) else None
     g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[7] and covs.eps) else None
     p = lambda t: None if t is None else t.data_ptr()
     solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
-                            p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream())
+                            p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream(),
+                            g_sdf_copies=copies)
+    if g_sdf is not None and shared:
+      g_sdf = g_sdf.sum(0, keepdim=True)
     if g_sdf is not None and shared and sdf.shape[0] != 1:
       # the kernel already accumulated all B trajectories into the one shared grid; autograd's expand-backward will sum
       # the B slices of whatever is returned here, so hand it B equal shares

@@ -148,13 +148,17 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch,
  * g_err_ext = dL/d(err_ext) (B) (either cotangent may be NULL = 0; dtheta may be NULL iff g_dtheta is),
  * re-assembles the system, solves the adjoint system Lambda lambda = g_dtheta and writes dL/d{th,start,goal}
  * (same shapes), dL/d(qc_inv) (shape of the qc_mode), dL/d(obs_w), dL/d(eps) (B,n), and ACCUMULATES dL/d(sdf)
- * into g_sdf with atomics (layout given by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped. */
+ * into g_sdf with atomics (layout given by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped.
+ * g_sdf_copies: 1, or (shared grid, g_sdf_batch_stride == 0, only) the number of PARTIAL grids laid out back to back
+ * in g_sdf: every XCD of the GPU accumulates into copy (xcc_id % g_sdf_copies) with XCD-local L2 atomics instead of
+ * device-scope ones (the per-XCD L2s are not coherent with each other), and the caller sums the copies afterwards.
+ * 8 copies remove the cross-XCD contention of a shared grid (2.5x faster backward at batch 4096). */
 int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          const void* th, const void* start, const void* goal,
                          const DgpSdf* sdf, const DgpCovs* covs,
                          const void* dtheta, const void* g_dtheta, const void* g_err_ext,
                          void* g_th, void* g_start, void* g_goal,
-                         void* g_sdf, int64_t g_sdf_batch_stride,
+                         void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                          void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);
 
 #ifdef __cplusplus

@@ -68,8 +68,9 @@ struct HostCtx {
     pthread_barrier_wait(&ws->bar);
     return r != 0;
   }
+  int xcc_id() const { return wave_ & 7; }          // the emulator spreads "wavefronts" over 8 pretend XCDs
   template <typename T>
-  void atomic_add(T* p, T v) {
+  void atomic_add(T* p, T v, bool = false) {
     pthread_mutex_lock(&g_atomic_mutex); *p += v; pthread_mutex_unlock(&g_atomic_mutex);
   }
 };
@@ -162,12 +163,12 @@ int emul_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const vo
 
 int emul_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                           const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
-                          void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, void* g_qc_inv, void* g_obs_w,
-                          void* g_eps, void*) {
+                          void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv,
+                          void* g_obs_w, void* g_eps, void*) {
   dgp::GnParams p;
   dgp::GnGradParams g;
   int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
-                                   g_sdf_batch_stride, g_qc_inv, g_obs_w, g_eps, p, g);
+                                   g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
   if (rc != DGP_OK) return rc;
   run(h, p, &g, 3);
   return DGP_OK;

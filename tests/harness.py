@@ -145,7 +145,8 @@ class Backend(object):
     solver.eval_errors(B, th_p, st_p, go_p, sdf_arg, covs, *[o[1] for o in outs], stream=self.stream())
     return tuple(self.to_np(o[0]) for o in outs)
 
-  def backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+  def backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, qc=None, ow=None, eps=None, q_full=False, io='f64',
+               sdf_copies=1):
     """-> dict of gradients: th, start, goal, sdf, qc, ow, eps (numpy fp64)"""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
     n = th.shape[1]
@@ -156,12 +157,12 @@ class Backend(object):
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
     sdf = np.asarray(sdf)
-    gsdf, gsdf_p = self.empty(sdf.shape, io, fill=0.0)
+    gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
     gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
     stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
     solver.gn_step_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, ge_p, gth_p, gst_p, ggo_p, gsdf_p, stride, gqc_p, gow_p,
-                            gep_p, self.stream())
+                            gep_p, self.stream(), g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc),
                 ow=self.to_np(gow), eps=self.to_np(gep))

@@ -327,6 +327,28 @@ ALL_CASES = [case_c2mini_static, case_c2mini_covs, case_c2mini_per_sample_sdf, c
              case_c3_vel, case_c4_xyh, case_eval_errors, case_solve, case_not_spd, case_backward_golden, case_backward_fd, case_unaligned_buffers]
 
 
+def case_shared_sdf_gradient_partial_copies(be, golden, io):
+  """Shared SDF: the gradient accumulated into 8 per-XCD partial grids (XCD-local L2 atomics) and summed equals the
+  single-grid device-scope accumulation."""
+  g = golden('g5_grads')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  rs = np.random.RandomState(4)
+  reps = 40 if be.kind == 'hip' else 1          # on the GPU use enough trajectories to populate every XCD
+  th = np.concatenate([g['th'] + rs.randn(B, n, 4) * 0.05 for _ in range(reps)], 0)
+  st = np.concatenate([g['start']] * reps, 0); go = np.concatenate([g['goal']] * reps, 0)
+  gbar = rs.randn(*th.shape)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  th, st, go, sdf, gbar = rnd(th, io), rnd(st, io), rnd(go, io), rnd(sdf, io), rnd(gbar, io)
+  dth, _, _, _ = be.step(p, th, st, go, sdf, io=io)
+  r1 = be.backward(p, th, st, go, sdf, dth, gbar, None, io=io)
+  r8 = be.backward(p, th, st, go, sdf, dth, gbar, None, io=io, sdf_copies=8)
+  assert r8['sdf'].shape[0] == 8
+  if be.kind == 'hip' and reps > 8: assert (np.abs(r8['sdf']).reshape(8, -1).max(1) > 0).sum() >= 2      # really spread over XCDs
+  assert rel_err(r8['sdf'].sum(0, keepdims=True), r1['sdf']) < (1e-11 if io == 'f64' else 2e-5)
+  assert np.array_equal(r8['th'], r1['th'])
+
+
 def case_tiny_and_odd_sizes(be, golden, io):
   """n = 2 (the minimum: start and goal only), n = 3, n = 5 with B = 1, and a batch that is not a multiple of the number of
   trajectories per wavefront; NaN in one trajectory must not leak into its wave neighbours."""
@@ -351,3 +373,4 @@ def case_tiny_and_odd_sizes(be, golden, io):
 
 
 ALL_CASES.append(case_tiny_and_odd_sizes)
+ALL_CASES.append(case_shared_sdf_gradient_partial_copies)
