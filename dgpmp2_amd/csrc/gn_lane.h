@@ -348,7 +348,7 @@ struct ObsTaps {
 // Bilinear lookup, phase 1 (utils/sdf_utils.py:57-72): pixel coordinates and the four (clamped) tap offsets.
 struct ObsAddr {
   double px, py;
-  int64_t x1, x2, y1, y2;
+  int32_t x1, x2, y1, y2;          // clamped to [0, W-1] / [0, H-1]: 32 bits are plenty (and int32 -> fp64 is one instruction)
 };
 
 DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
@@ -358,14 +358,14 @@ DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
   o.py = p.orig_py - y / res;                             // :62
   double fpx = floor(o.px), fpy = floor(o.py);
   // floor -> int64 -> clamp (:64-72); saturate first so that huge |px| cannot overflow the conversion
-  const double big = 1.0e9;
+  const double big = 1.0e9;                               // |floor| <= 1e9 fits int32 and int32 + 1 does not overflow
   double cx = fpx < -big ? -big : (fpx > big ? big : fpx);
   double cy = fpy < -big ? -big : (fpy > big ? big : fpy);
   if (!(cx == cx)) cx = 0.0;                              // NaN coordinates: any in-range index (the result is NaN anyway)
   if (!(cy == cy)) cy = 0.0;
-  int64_t x1 = (int64_t)cx, y1 = (int64_t)cy;
-  int64_t x2 = x1 + 1, y2 = y1 + 1;                       // :65,67 (before clamping)
-  const int64_t W = p.sdf_cols, H = p.sdf_rows;
+  int32_t x1 = (int32_t)cx, y1 = (int32_t)cy;
+  int32_t x2 = x1 + 1, y2 = y1 + 1;                       // :65,67 (before clamping)
+  const int32_t W = p.sdf_cols, H = p.sdf_rows;
   o.x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
   o.x2 = x2 < 0 ? 0 : (x2 > W - 1 ? W - 1 : x2);
   o.y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
@@ -394,7 +394,8 @@ DGP_HD void obstacle_finish(const GnParams& p, const ObsAddr& o, double d11, dou
   hy = act ? (-1.0 * Jy) : 0.0;
   if (taps) {
     const int64_t W = p.sdf_cols;
-    taps->i11 = o.y1 * W + o.x1; taps->i21 = o.y1 * W + o.x2; taps->i12 = o.y2 * W + o.x1; taps->i22 = o.y2 * W + o.x2;
+    taps->i11 = (int64_t)o.y1 * W + o.x1; taps->i21 = (int64_t)o.y1 * W + o.x2;
+    taps->i12 = (int64_t)o.y2 * W + o.x1; taps->i22 = (int64_t)o.y2 * W + o.x2;
     taps->wja = fy2 - py; taps->wjb = py - fy1; taps->wjc = fx2 - px; taps->wjd = px - fx1;
     taps->cross = d22 - d12 - d21 + d11;
     taps->act = act;
@@ -407,8 +408,8 @@ DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y,
   ObsAddr o;
   obstacle_addr(p, x, y, o);
   const int64_t W = p.sdf_cols;
-  const double d11 = (double)grid[o.y1 * W + o.x1], d21 = (double)grid[o.y1 * W + o.x2];      // dx1y1, dx2y1 (:76-77)
-  const double d12 = (double)grid[o.y2 * W + o.x1], d22 = (double)grid[o.y2 * W + o.x2];      // dx1y2, dx2y2 (:78-79)
+  const double d11 = (double)grid[(int64_t)o.y1 * W + o.x1], d21 = (double)grid[(int64_t)o.y1 * W + o.x2];      // dx1y1, dx2y1 (:76-77)
+  const double d12 = (double)grid[(int64_t)o.y2 * W + o.x1], d22 = (double)grid[(int64_t)o.y2 * W + o.x2];      // dx1y2, dx2y2 (:78-79)
   obstacle_finish(p, o, d11, d21, d12, d22, eps, cost, hx, hy, taps);
 }
 
@@ -659,8 +660,10 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
   }
 #pragma unroll
   for (int k = 0; k < C; ++k) {
-    t.d11[k] = (double)grid[t.oa[k].y1 * W + t.oa[k].x1]; t.d21[k] = (double)grid[t.oa[k].y1 * W + t.oa[k].x2];
-    t.d12[k] = (double)grid[t.oa[k].y2 * W + t.oa[k].x1]; t.d22[k] = (double)grid[t.oa[k].y2 * W + t.oa[k].x2];
+    // grids have fewer than 2^31 elements (host-checked): 32-bit element offsets
+    const int32_t r1 = t.oa[k].y1 * (int32_t)W, r2 = t.oa[k].y2 * (int32_t)W;
+    t.d11[k] = (double)grid[r1 + t.oa[k].x1]; t.d21[k] = (double)grid[r1 + t.oa[k].x2];
+    t.d12[k] = (double)grid[r2 + t.oa[k].x1]; t.d22[k] = (double)grid[r2 + t.oa[k].x2];
   }
 }
 
@@ -989,7 +992,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   Sym<D> Qown, Qm;               // Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
   fixed_Qinv<DOF>(p, Qown);      // static covariances: built once; per-state modes: reloaded per row
   fixed_Qinv<DOF>(p, Qm);
-  Mat<D> Uprev = {};             // U of the previous row (k-1)
+  Mat<D> Urow[2] = {};           // U of the current / previous interior row, alternating (no copies)
   if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
 
   // ---- a. forward sweep over the interior rows
@@ -997,7 +1000,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   for (int k = 0; k < C - 1; ++k) {
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
-    Sym<D> Dk; Mat<D> Uk; double rk[D];
+    Sym<D> Dk; double rk[D];
+    Mat<D>& Uk = Urow[k & 1];
+    const Mat<D>& Uprev = Urow[(k & 1) ^ 1];
     if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
     eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], mu_s, mu_g, Qown, Qm, lf.ow[k],
                               lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
@@ -1026,7 +1031,6 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     }
     sym_inverse<D>(Dk, Sinv[k], ok);
     sym_times_mat<D>(Sinv[k], Uk, G[k]);                  // G_k = S_k^-1 U_k
-    Uprev = Uk;
     if (!stat) Qm = Qown;
   }
   // ---- b. back substitution: P, V, W in place
@@ -1070,6 +1074,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     }
   }
   if (C > 1) {
+    const Mat<D>& Uprev = Urow[(C > 1 ? C - 2 : 0) & 1];  // U of the last interior row
     sub_At_B_sym<D>(Ds, Uprev, W[C > 1 ? C - 2 : 0]);     // D_s -= U_{C-2}^T W_{C-2}
     sub_At_v<D>(rs, Uprev, P[C > 1 ? C - 2 : 0]);         // r_s -= U_{C-2}^T P_{C-2}
     // first interior row of the next lane
