@@ -23,6 +23,29 @@ from .plan_layer import PlanLayer, _f, _stream
 from ..utils.planner_utils import check_convergence
 
 
+class _PerSampleHistory(object):
+  """List-like view of a (B, max_iters) history array: item b is the python list of sample b's first iters[b] entries --
+  what the reference accumulates sample by sample (diff_gpmp2_planner.py:140-141,163-164) -- built lazily, because
+  materialising 4096 python lists costs more than the whole fused solve."""
+
+  def __init__(self, hist, iters):
+    self._h, self._k = hist, iters
+
+  def __len__(self):
+    return len(self._k)
+
+  def __getitem__(self, b):
+    if isinstance(b, slice):
+      return [self[i] for i in range(*b.indices(len(self)))]
+    return self._h[b, :self._k[b]].tolist()
+
+  def __iter__(self):
+    return (self[b] for b in range(len(self)))
+
+  def __repr__(self):
+    return 'PerSampleHistory(%d samples)' % len(self)
+
+
 class DiffGPMP2Planner(nn.Module):
   def __init__(self, gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params=None, batch_size=1,
                use_cuda=False, learn_module_conv=None, learn_module_fcn=None):
@@ -47,6 +70,7 @@ class DiffGPMP2Planner(nn.Module):
     nl = robot_model.nlinks
     dd = torch.float64      # the static covariances are exact copies of the config values (the reference runs under a float64 default)
     mk = lambda shape, v: (torch.zeros(*shape, dtype=dd, device=self.device) + torch.as_tensor(v, dtype=dd, device=self.device))
+    self._static_views = {}
     self.fixed_conv = False
     self.learn_eps = False
     self.dynamics_mode = None
@@ -80,12 +104,16 @@ class DiffGPMP2Planner(nn.Module):
                                 self.batch_size, self.use_cuda)
 
   # -- helpers ------------------------------------------------------------------------------------------
-  @staticmethod
-  def _static_view(t, B, like):
+  def _static_view(self, t, B, like):
     """(…)-shaped static covariance -> (B,…) expand()ed view in the dtype of `like`, tagged so that PlanLayer passes the
-    handle's constants instead of streaming B copies (the reference materialises them with .repeat, :202-205)."""
-    v = t.to(like.dtype).unsqueeze(0).expand(B, *t.shape)
-    v._dgp_static = True
+    handle's constants instead of streaming B copies (the reference materialises them with .repeat, :202-205).  Cached per
+    (tensor, batch, dtype): building three views costs more host time than the kernel runs."""
+    key = (id(t), B, like.dtype)
+    v = self._static_views.get(key)
+    if v is None:
+      v = t.to(like.dtype).unsqueeze(0).expand(B, *t.shape)
+      v._dgp_static = True
+      self._static_views[key] = v
     return v
 
   def _predict(self, th_in, conv_out, hiddenb, im_in=None):
@@ -163,12 +191,9 @@ class DiffGPMP2Planner(nn.Module):
     pl.last_info = info
     pl._last = (st, go, None, None, None)
     jb = iters.cpu().tolist()                       # synchronises
-    eh_c, eeh_c, ef_c = eh.cpu(), eeh.cpu(), ef.cpu()
+    eh_c, eeh_c, ef_c = eh.cpu().numpy(), eeh.cpu().numpy(), ef.cpu().numpy()
     t = time.time() - start_t
-    err_per_iterb = [eh_c[b, :jb[b]].tolist() for b in range(B)]
-    err_ext_per_iterb = [eeh_c[b, :jb[b]].tolist() for b in range(B)]
-    err_initb = [e[0] for e in err_per_iterb]
-    return th_out, None, err_initb, ef_c.tolist(), err_per_iterb, err_ext_per_iterb, jb, [t] * B
+    return (th_out, None, eh_c[:, 0].tolist(), ef_c.tolist(), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), jb, [t] * B)
 
   def _forward_stepwise(self, th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t):
     """Differentiable / learned / time-limited variant: chained batched step() calls with a per-trajectory freeze once
@@ -199,12 +224,10 @@ class DiffGPMP2Planner(nn.Module):
         print('Plan time over')
         break
     err_final = self.plan_layer.error_batch(th.detach(), sdfb).reshape(B).cpu().tolist()
-    E = torch.stack(errs, 1).cpu(); EE = torch.stack(errs_ext, 1).cpu(); jl = jb.cpu().tolist()
+    E = torch.stack(errs, 1).cpu().numpy(); EE = torch.stack(errs_ext, 1).cpu().numpy(); jl = jb.cpu().tolist()
     t = time.time() - start_t
-    err_per_iterb = [E[b, :jl[b]].tolist() for b in range(B)]
-    err_ext_per_iterb = [EE[b, :jl[b]].tolist() for b in range(B)]
     hidden_newb = hidden if hiddenb is not None else None
-    return th, hidden_newb, [e[0] for e in err_per_iterb], err_final, err_per_iterb, err_ext_per_iterb, jl, [t] * B
+    return th, hidden_newb, E[:, 0].tolist(), err_final, _PerSampleHistory(E, jl), _PerSampleHistory(EE, jl), jl, [t] * B
 
   def error_batch(self, thb, sdfb):
     return self.plan_layer.error_batch(thb, sdfb)

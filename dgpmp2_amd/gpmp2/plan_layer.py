@@ -48,6 +48,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
                            cost_sigma=cost_sigma, epsilon_dist=epsilon_dist, **kw)
 
 
+_ALL_STATIC_COVS = _capi.DgpCovs(_capi.DGP_QC_STATIC, None, None, None)
 _SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2
 
 
@@ -197,6 +198,8 @@ class PlanLayer(nn.Module):
 
   def _covs_arg(self, solver, qc, ow, eps, dtype, B, static=(False, False, False)):
     """Covariance tensors -> DgpCovs.  A static entry selects the constants of the handle (no per-state tensor is streamed)."""
+    if static == (True, True, True):
+      return _ALL_STATIC_COVS, ()
     n, dof, d = self.num_traj_states, self.dof, self.state_dim
     keep = []
 
