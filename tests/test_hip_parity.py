@@ -77,3 +77,25 @@ def test_hip_c2_ten_iterations_reduce_error(be):
     assert rel_err(err, eh[:, k]) < 1e-12
     cur = cur + dth
   assert rel_err(cur, tho) < 1e-12
+
+
+@pytest.mark.parametrize('B,n', [(65537, 64), (1, 64), (3, 256), (1000, 101), (257, 7)])
+def test_hip_odd_batches_and_lengths_vs_c_oracle(be, B, n):
+  """Ragged grids (batch not a multiple of the trajectories per wavefront), the longest supported trajectory (n = 256:
+  64 lanes x 4 states), the reference's default n = 101, against oracle/gn_blocktri.c on every trajectory."""
+  from oracle import blocktri as BT
+  p = PC.P2d(n)
+  th, start, goal, sdf = _c2_inputs(B, n, 128, seed=B + n, perturb=0.03)
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, io='f64')
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, nthreads=4)
+  assert not info.any() and not c_info.any() and np.all(np.isfinite(dth))
+  per_traj = np.abs(dth - c_dth).reshape(B, -1).max(1) / np.abs(c_dth).reshape(B, -1).max(1)
+  assert per_traj.max() < 1e-9, per_traj.max()
+  assert rel_err(err, c_err) < 1e-11 and rel_err(eex, c_eex) < 1e-11
+
+
+def test_hip_rejects_too_long_trajectory(be):
+  from dgpmp2_amd import _capi
+  with pytest.raises(_capi.DgpError) as e:
+    _capi.Solver(harness.config_from_oracle(PC.P2d(257), 'f64'))
+  assert e.value.code == _capi.DGP_EUNSUPPORTED
