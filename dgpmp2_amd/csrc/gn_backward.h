@@ -29,7 +29,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;
   const int lane = cx.lane();
-  const int j = lane & (LPT - 1);
+  const int j = lane_to_row<LPT>(lane & (LPT - 1));
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
   const bool traj_ok = b < p.B;

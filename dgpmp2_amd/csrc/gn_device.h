@@ -48,8 +48,16 @@ struct DevCtx {
   }
 };
 
+// Wavefronts per SIMD the register allocator must leave room for.  One wavefront per SIMD issues at most one VALU
+// instruction every 4 cycles whatever its width; two co-resident ones fill each other's dependency stalls.  Forcing room
+// for two costs ~40 spilled registers on the d = 4, C <= 2 kernels, which pays only where a launch has more wavefronts
+// than the chip has SIMDs, i.e. for the shapes with 32 or 64 lanes per trajectory (measured at B = 4096, n = 64:
+// (32,2) 33.6 -> 23.0 us, (64,1) 47.9 -> 44.3 us; but (16,2) at n = 32, one wavefront per SIMD, 10.9 -> 12.2 us).
+template <int DOF, int LPT, int C, int MODE>
+struct WavesPerSimd { static constexpr int value = (DOF == 2 && C <= 2 && LPT >= 32 && MODE != dgp::MODE_SOLVE) ? 2 : 1; };
+
 template <int DOF, int LPT, int C, typename IO, int MODE>
-__global__ void __launch_bounds__(64) gn_kernel(const dgp::GnParams p) {
+__global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   DevCtx cx;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE>(p, cx);
 }

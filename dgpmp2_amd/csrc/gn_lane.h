@@ -783,25 +783,42 @@ template <int D> DGP_HD void sub_A_B(Mat<D>& O, const Mat<D>& A, const Mat<D>& B
 //     D_i' = D_i - T2 U_{i-s} - T U_i^T ;  r_i' = r_i - T2 r_{i-s} - T r_{i+s} ;  U_i' = -T U_{i+s}
 //   (the lower coupling stays the transpose of the upper one, so only U is carried).
 // ---------------------------------------------------------------------------------------------------
-// Cross-lane access helper.  With 16 lanes per trajectory every exchange stays inside one 16-lane DPP row, so the
-// neighbour at distance S is read with a DPP row shift (a plain VALU move: no LDS round trip, no s_waitcnt); wider
-// groups go through ds_bpermute.  Lanes without a neighbour receive 0 (DPP bound_ctrl) or their own value (bpermute);
-// both are harmless because the coupling block that multiplies the fetched data is zero there.
+// Position of a lane inside its trajectory's lane group <-> index j of the block row it owns in the LPT-row system.
+// LPT = 16 / 64: identity.  LPT = 32 (two 16-lane DPP rows per trajectory): rows are interleaved by parity,
+//   lane = (j & 1) * 16 + (j >> 1),
+// so that rows j and j +- s sit in the SAME DPP row, |s|/2 lanes apart, for every PCR stride s >= 2; only the stride-1
+// exchanges cross the DPP rows (and go through ds_bpermute).
+template <int LPT> DGP_HD int lane_to_row(int within) {
+  if constexpr (LPT == 32) return ((within & 15) << 1) | (within >> 4);
+  else return within;
+}
+template <int LPT> DGP_HD int row_to_lane(int j) {
+  if constexpr (LPT == 32) return ((j & 1) << 4) | (j >> 1);
+  else return j;
+}
+
+// Cross-lane access helper: value held by the lane that owns row j - S (lo) / j + S (hi) of the same trajectory.
+// Whenever both rows live in one 16-lane DPP row the neighbour is read with a DPP row shift (a plain VALU move: no LDS
+// round trip, no s_waitcnt); otherwise through ds_bpermute.  Rows without such a neighbour receive 0 (DPP bound_ctrl) or
+// their own value (bpermute); both are harmless because the coupling block that multiplies the fetched data is zero there.
 template <int LPT, int S, typename Ctx>
 struct Nbr {
+  static constexpr bool kDpp = (LPT == 16) || (LPT == 32 && S >= 2);     // DPP path: missing neighbours read as 0
+  static constexpr int kShift = (LPT == 32) ? S / 2 : S;                  // lane distance inside the DPP row
   Ctx& cx;
   int src_lo, src_hi;
   DGP_HD Nbr(Ctx& c, int j) : cx(c) {
     const int lane = c.lane();
-    src_lo = (j >= S) ? lane - S : lane;
-    src_hi = (j + S < LPT) ? lane + S : lane;
+    const int base = lane & ~(LPT - 1);
+    src_lo = (j >= S) ? base + row_to_lane<LPT>(j - S) : lane;
+    src_hi = (j + S < LPT) ? base + row_to_lane<LPT>(j + S) : lane;
   }
-  DGP_HD double lo(double v) const {          // value held by lane j - S
-    if constexpr (LPT == 16) return cx.template row_from_lower<S>(v);
+  DGP_HD double lo(double v) const {
+    if constexpr (kDpp) return cx.template row_from_lower<(kShift > 0 ? kShift : 1)>(v);
     else return cx.fetch(v, src_lo);
   }
-  DGP_HD double hi(double v) const {          // value held by lane j + S
-    if constexpr (LPT == 16) return cx.template row_from_upper<S>(v);
+  DGP_HD double hi(double v) const {
+    if constexpr (kDpp) return cx.template row_from_upper<(kShift > 0 ? kShift : 1)>(v);
     else return cx.fetch(v, src_hi);
   }
 };
@@ -828,7 +845,7 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], boo
 #pragma unroll
       for (int c = 0; c < D; ++c) {
         const double u = nb.lo(U.v[a][c]);
-        UL.v[a][c] = (LPT == 16 || has_l) ? u : 0.0;     // the DPP row shift already yields 0 where there is no left neighbour
+        UL.v[a][c] = (Nbr<LPT, S, Ctx>::kDpp || has_l) ? u : 0.0;     // a DPP row shift already yields 0 where there is no left neighbour
       }
     }
     // T2 = UL^T DiL
@@ -1147,7 +1164,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;                 // trajectories per wavefront
   const int lane = cx.lane();
-  const int j = lane & (LPT - 1);               // lane index inside the trajectory
+  const int j = lane_to_row<LPT>(lane & (LPT - 1));      // block row of the LPT-row system owned by this lane
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
   const bool traj_ok = b < p.B;
