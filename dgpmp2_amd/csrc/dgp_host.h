@@ -67,6 +67,31 @@ inline DgpShape choose_shape(const DgpHandle* h, int B) {
   return best;
 }
 
+// The constant blocks of a GP factor under the configured (static) Q_c_inv: Q^-1 exactly as dgp::fixed_Qinv builds it,
+// U = -Phi^T Q^-1 (block (i,i+1) of Lambda) and Phi^T Q^-1 Phi (the factor's share of block (i,i)); Phi = [[I, dt I],[0, I]].
+inline void fill_static_blocks(dgp::GnParams& p, int dof) {
+  const int d = 2 * dof;
+  double Q[6][6], U[6][6];
+  for (int i = 0; i < dof; ++i)
+    for (int j = 0; j < dof; ++j) {
+      const double c = p.qc_fix[i * dof + j];
+      if (j >= i) { Q[i][j] = Q[j][i] = p.qa * c; Q[dof + i][dof + j] = Q[dof + j][dof + i] = p.qc_ * c; }
+      Q[i][dof + j] = Q[dof + j][i] = p.qb * c;
+    }
+  for (int a = 0; a < dof; ++a)
+    for (int c = 0; c < d; ++c) { U[a][c] = -Q[a][c]; U[dof + a][c] = -(p.dt * Q[a][c] + Q[dof + a][c]); }
+  auto sidx = [d](int i, int j) { return i * d - (i * (i - 1)) / 2 + (j - i); };      // Sym<d>::idx for i <= j
+  for (int a = 0; a < d; ++a)
+    for (int c = 0; c < d; ++c) {
+      p.u_fix[a * d + c] = U[a][c];
+      if (c >= a) {
+        p.q_fix[sidx(a, c)] = Q[a][c];
+        // Phi^T Q Phi = -U Phi : columns pos = -U[:,pos], columns vel = -(dt U[:,pos] + U[:,vel])
+        p.a_fix[sidx(a, c)] = (c < dof) ? -U[a][c] : -(p.dt * U[a][c - dof] + U[a][c]);
+      }
+    }
+}
+
 inline int create(const DgpConfig* cfg, DgpHandle** out) {
   if (!cfg || !out) return fail(DGP_EINVAL, "null argument");
   *out = nullptr;
@@ -118,6 +143,7 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   p.w_v = (cfg->flags & DGP_FLAG_VEL_LIMITS) ? 1.0 / pow(cfg->K_v, 2.0) : 0.0;
   p.vmax[0] = cfg->v_x; p.vmax[1] = cfg->v_y;
   p.M = (double)h->M;
+  fill_static_blocks(p, dof);
   *out = h;
   return DGP_OK;
 }

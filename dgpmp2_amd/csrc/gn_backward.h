@@ -24,7 +24,7 @@ struct GnGradParams {
   int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
 };
 
-template <int DOF, int LPT, int C, typename IO, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool QSTAT, typename Ctx>
 DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;
@@ -50,7 +50,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   if (gp.g_dtheta) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, true>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, true, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok);
   }
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
 

@@ -56,16 +56,17 @@ struct DevCtx {
 template <int DOF, int LPT, int C, int MODE>
 struct WavesPerSimd { static constexpr int value = (DOF == 2 && C <= 2 && LPT >= 32 && MODE != dgp::MODE_SOLVE) ? 2 : 1; };
 
-template <int DOF, int LPT, int C, typename IO, int MODE>
+// QSTAT: static covariances (p.qc_mode == QC_STATIC) -- the constant GP blocks are scalar operands (see gn_lane.h).
+template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   DevCtx cx;
-  dgp::gn_lane_program<DOF, LPT, C, IO, MODE>(p, cx);
+  dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QSTAT>(p, cx);
 }
 
-template <int DOF, int LPT, int C, typename IO>
+template <int DOF, int LPT, int C, typename IO, bool QSTAT>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   DevCtx cx;
-  dgp::gn_backward_lane_program<DOF, LPT, C, IO>(p, g, cx);
+  dgp::gn_backward_lane_program<DOF, LPT, C, IO, QSTAT>(p, g, cx);
 }
 
 // every (LPT, C) of dgp_host::shape_supported
@@ -78,18 +79,30 @@ template <int DOF, typename IO>
 hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const int tpw = 64 / sh.lpt;
   const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
+  const bool qstat = (p.qc_mode == dgp::QC_STATIC);
+#define DGP_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, p)
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
     switch (mode) {                                                                                                        \
-      case dgp::MODE_STEP: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP>), grid, block, 0, s, p); break;   \
-      case dgp::MODE_SOLVE: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE>), grid, block, 0, s, p); break; \
-      case dgp::MODE_EVAL: hipLaunchKernelGGL((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL>), grid, block, 0, s, p); break;   \
-      default: hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO>), grid, block, 0, s, p, *g); break;                  \
+      case dgp::MODE_STEP:                                                                                                 \
+        if (qstat) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, true>));                                          \
+        else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, false>));                                               \
+        break;                                                                                                             \
+      case dgp::MODE_SOLVE:                                                                                                \
+        if (qstat) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, true>));                                         \
+        else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, false>));                                              \
+        break;                                                                                                             \
+      case dgp::MODE_EVAL: DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, false>)); break;                          \
+      default:                                                                                                             \
+        if (qstat) hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, true>), grid, block, 0, s, p, *g);               \
+        else hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, false>), grid, block, 0, s, p, *g);                    \
+        break;                                                                                                             \
     }                                                                                                                      \
     return hipGetLastError();                                                                                              \
   }
   DGP_FOR_EACH_SHAPE(DGP_CASE)
 #undef DGP_CASE
+#undef DGP_LAUNCH
   return hipErrorInvalidValue;
 }
 

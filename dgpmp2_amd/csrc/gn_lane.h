@@ -69,6 +69,12 @@ struct GnParams {
   double w_d, w_v, vmax[2];  // 1/K_d^2, 1/K_v^2, (v_x, v_y)
   double M;                  // plan_layer.py:43-45
   double tol_delta;
+  // Static covariances (qc_mode == QC_STATIC): the three constant blocks every GP factor contributes, precomputed on the
+  // host from (dt, Q_c_inv) so that the kernels read them as scalar (SGPR) operands instead of holding them in vector
+  // registers.  d = 2 dof; symmetric blocks packed like Sym<d>, u_fix row-major d x d.
+  double q_fix[21];          // Q^-1                                   (gp_factor.py:65-73)
+  double a_fix[21];          // Phi^T Q^-1 Phi                         (block (i,i) share of factor i -> i+1)
+  double u_fix[36];          // U = -Phi^T Q^-1                        (block (i,i+1))
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -482,6 +488,52 @@ struct ErrAcc {
   double usg, ugp, uobs;   // unweighted partials (plan_layer.py:374-388)
 };
 
+// The factors that touch ONE state only (obstacle, velocity limits, non-holonomic), for a VALID row.
+template <int DOF, bool ASSEMBLE>
+DGP_HD void eval_state_local(const GnParams& p, const double (&x)[2 * DOF], double ow, double oc, double ohx, double ohy,
+                             Sym<2 * DOF>& Dm, double (&r)[2 * DOF], ErrAcc& acc) {
+  // ---- obstacle factor (obstacle_factor.py:35-40): sphere centre = x[0:2], H = H_e H_fk, H_fk = I_d[0:2,:]
+  {
+    acc.e += 0.5 * ow * oc * oc;
+    acc.eext += 0.5 * p.obs_w_fix * oc * oc;               // plan_layer.py:329-332 (fixed weight, current eps)
+    acc.uobs += 0.5 * oc * oc;
+    if (ASSEMBLE) {
+      Dm(0, 0) += ow * ohx * ohx; Dm(0, 1) += ow * ohx * ohy; Dm(1, 1) += ow * ohy * ohy;
+      r[0] += ow * ohx * oc; r[1] += ow * ohy * oc;
+    }
+  }
+  // ---- velocity-limit factor (velocity_limit_factor.py:17-29): '>=' (not '>'), H = -sign(v) e_{dof+a}
+  if (p.flags & FLAG_VEL_LIMITS) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const double v = x[DOF + a];
+      const double av = fabs(v);
+      const bool act = av >= p.vmax[a];
+      const double c = act ? (av - p.vmax[a]) : 0.0;
+      const double sg = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+      const double h = act ? -sg : 0.0;
+      acc.e += 0.5 * p.w_v * c * c; acc.eext += 0.5 * p.w_v * c * c;
+      if (ASSEMBLE) { Dm(DOF + a, DOF + a) += p.w_v * h * h; r[DOF + a] += p.w_v * h * c; }
+    }
+  }
+  // ---- non-holonomic factor (nonholonomic_factor.py:16-30), state [x,y,th,vx,vy,w]; H as the reference writes it
+  if constexpr (DOF == 3) if (p.flags & FLAG_NONHOLONOMIC) {
+    const double th = x[2], vx = x[DOF], vy = x[DOF + 1];
+    const double sn = sin(th), cs = cos(th);
+    const double e = vy * cs - vx * sn;
+    const double h[3] = {-vy * sn + vx * cs, -sn, cs};    // columns 2,3,4
+    acc.e += 0.5 * p.w_d * e * e; acc.eext += 0.5 * p.w_d * e * e;
+    if (ASSEMBLE) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = a; c < 3; ++c) Dm(2 + a, 2 + c) += p.w_d * h[a] * h[c];
+        r[2 + a] += p.w_d * h[a] * e;
+      }
+    }
+  }
+}
+
 template <int DOF, typename IO, bool ASSEMBLE>
 DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
                        const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
@@ -583,46 +635,69 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
       r[a] -= t;
     }
   }
-  // ---- obstacle factor (obstacle_factor.py:35-40): sphere centre = x[0:2], H = H_e H_fk, H_fk = I_d[0:2,:]
-  {
-    acc.e += 0.5 * ow * oc * oc;
-    acc.eext += 0.5 * p.obs_w_fix * oc * oc;               // plan_layer.py:329-332 (fixed weight, current eps)
-    acc.uobs += 0.5 * oc * oc;
-    if (ASSEMBLE) {
-      Dm(0, 0) += ow * ohx * ohx; Dm(0, 1) += ow * ohx * ohy; Dm(1, 1) += ow * ohy * ohy;
-      r[0] += ow * ohx * oc; r[1] += ow * ohy * oc;
-    }
-  }
-  // ---- velocity-limit factor (velocity_limit_factor.py:17-29): '>=' (not '>'), H = -sign(v) e_{dof+a}
-  if (p.flags & FLAG_VEL_LIMITS) {
+  eval_state_local<DOF, ASSEMBLE>(p, x, ow, oc, ohx, ohy, Dm, r, acc);
+}
+
+// Static covariances (qc_mode == QC_STATIC, the reference's default planner): the same row, assembled branch-free from
+// the host-precomputed blocks p.q_fix / p.a_fix / p.u_fix.  Every GP term is weighted by a 0/1 lane mask instead of being
+// guarded by a branch (each wavefront holds first and last rows, so both sides of such a branch run anyway), and the
+// constant blocks are scalar operands of the FMAs.  The coupling block itself is NOT written: U_g = m_next * p.u_fix.
+//   m_next = 1 iff row g is valid and g < n-1;   m_prev = 1 iff row g is valid and g > 0
+template <int DOF>
+DGP_HD void eval_state_static(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
+                              const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
+                              double ow, double oc, double ohx, double ohy, Sym<2 * DOF>& Dm, double (&r)[2 * DOF],
+                              double& m_next, ErrAcc& acc) {
+  constexpr int D = 2 * DOF;
+  const int n = p.n;
+  const double dt = p.dt;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  m_next = mN;
+  // ---- start / goal priors (prior_factor.py:15-18; plan_layer.py:64-68)
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  double s2 = 0.0;
+  double ep[D];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const double v = x[DOF + a];
-      const double av = fabs(v);
-      const bool act = av >= p.vmax[a];
-      const double c = act ? (av - p.vmax[a]) : 0.0;
-      const double sg = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
-      const double h = act ? -sg : 0.0;
-      acc.e += 0.5 * p.w_v * c * c; acc.eext += 0.5 * p.w_v * c * c;
-      if (ASSEMBLE) { Dm(DOF + a, DOF + a) += p.w_v * h * h; r[DOF + a] += p.w_v * h * c; }
-    }
+  for (int a = 0; a < D; ++a) {
+    ep[a] = (is_start ? mu_s[a] : mu_g[a]) - x[a];
+    s2 += ep[a] * ep[a];
   }
-  // ---- non-holonomic factor (nonholonomic_factor.py:16-30), state [x,y,th,vx,vy,w]; H as the reference writes it
-  if constexpr (DOF == 3) if (p.flags & FLAG_NONHOLONOMIC) {
-    const double th = x[2], vx = x[DOF], vy = x[DOF + 1];
-    const double sn = sin(th), cs = cos(th);
-    const double e = vy * cs - vx * sn;
-    const double h[3] = {-vy * sn + vx * cs, -sn, cs};    // columns 2,3,4
-    acc.e += 0.5 * p.w_d * e * e; acc.eext += 0.5 * p.w_d * e * e;
-    if (ASSEMBLE) {
+  acc.e += 0.5 * w * s2; acc.eext += 0.5 * w * s2; acc.usg += (is_start || is_goal) ? 0.5 * s2 : 0.0;
+  // ---- GP factors (g -> g+1) and (g-1 -> g): e = x_{g+1} - Phi x_g (gp_factor.py:105)
+  double eo[D], em[D];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int c = a; c < 3; ++c) Dm(2 + a, 2 + c) += p.w_d * h[a] * h[c];
-        r[2 + a] += p.w_d * h[a] * e;
-      }
-    }
+  for (int a = 0; a < DOF; ++a) {
+    eo[a] = xp[a] - (x[a] + dt * x[DOF + a]);
+    eo[DOF + a] = xp[DOF + a] - x[DOF + a];
+    em[a] = x[a] - (xm[a] + dt * xm[DOF + a]);
+    em[DOF + a] = x[DOF + a] - xm[DOF + a];
   }
+  double q = 0.0, so = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) t += p.q_fix[Sym<D>::idx(a, c)] * eo[c];
+    q += eo[a] * t;
+    so += eo[a] * eo[a];
+  }
+  acc.e += mN * (0.5 * q); acc.eext += mN * (0.5 * q); acc.ugp += mN * (0.5 * so);
+  const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double tu = 0.0, tq = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      tu += p.u_fix[a * D + c] * eo[c];                    // (U e_own)_a :  eta += Phi^T Q e = -U e
+      tq += p.q_fix[Sym<D>::idx(a, c)] * em[c];            // (Q e_prev)_a:  eta -= Q e_prev
+    }
+    r[a] = w * ep[a] - mN * tu - mP * tq;
+#pragma unroll
+    for (int c = a; c < D; ++c)
+      Dm(a, c) = ((a == c) ? dbase + w : 0.0) + mN * p.a_fix[Sym<D>::idx(a, c)] + mP * p.q_fix[Sym<D>::idx(a, c)];
+  }
+  eval_state_local<DOF, true>(p, x, ow, oc, ohx, ohy, Dm, r, acc);
 }
 
 // Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
@@ -771,6 +846,38 @@ template <int D> DGP_HD void sub_A_B(Mat<D>& O, const Mat<D>& A, const Mat<D>& B
       double t = O.v[a][c];
 #pragma unroll
       for (int k = 0; k < D; ++k) t -= A.v[a][k] * B.v[k][c];
+      O.v[a][c] = t;
+    }
+}
+
+template <int D> DGP_HD void add_A_B(Mat<D>& O, const Mat<D>& A, const Mat<D>& B) {               // O += A B
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = O.v[a][c];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += A.v[a][k] * B.v[k][c];
+      O.v[a][c] = t;
+    }
+}
+template <int D> DGP_HD void add_A_v(double (&o)[D], const Mat<D>& A, const double (&v)[D]) {     // o += A v
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = o[a];
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += A.v[a][k] * v[k];
+    o[a] = t;
+  }
+}
+template <int D> DGP_HD void A_B(const Mat<D>& A, const Mat<D>& B, Mat<D>& O) {                   // O = A B
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += A.v[a][k] * B.v[k][c];
       O.v[a][c] = t;
     }
 }
@@ -971,136 +1078,247 @@ DGP_HD int group_or(Ctx& cx, int v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The coupling blocks U_k (block (k, k+1)) of the rows a lane owns, in two representations:
+//   generic (QSTAT = false): one d x d block per row, already zero where row k has no successor;
+//   static  (QSTAT = true) : U_k = m_k * p.u_fix with a 0/1 mask per row -- nothing but the masks is kept in vector
+//                            registers, the block itself is a scalar operand.
+// ---------------------------------------------------------------------------------------------------
+template <int D, int N, bool QSTAT> struct Coupling;
+template <int D, int N> struct Coupling<D, N, false> { Mat<D> u[N]; };
+template <int D, int N> struct Coupling<D, N, true> { double m[N]; };
+
+// G = S^-1 U_k
+template <int D, int N>
+DGP_HD void coup_SinvU(const GnParams&, const Coupling<D, N, false>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
+  sym_times_mat<D>(Si, cp.u[k], G);
+}
+template <int D, int N>
+DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
+  Sym<D> Sm;
+#pragma unroll
+  for (int i = 0; i < D * (D + 1) / 2; ++i) Sm.v[i] = cp.m[k] * Si.v[i];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) t += Sm(a, q) * p.u_fix[q * D + c];
+      G.v[a][c] = t;
+    }
+}
+// S -= U_k^T B (symmetric result).  Static form: B is G_k = S_k^-1 U_k, which already carries the mask.
+template <int D, int N>
+DGP_HD void coup_sub_UtB_sym(const GnParams&, const Coupling<D, N, false>& cp, int k, Sym<D>& S, const Mat<D>& B) {
+  sub_At_B_sym<D>(S, cp.u[k], B);
+}
+template <int D, int N>
+DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int, Sym<D>& S, const Mat<D>& B) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double t = S(a, c);
+#pragma unroll
+      for (int q = 0; q < D; ++q) t -= p.u_fix[q * D + a] * B.v[q][c];
+      S(a, c) = t;
+    }
+}
+// o -= U_k^T v
+template <int D, int N>
+DGP_HD void coup_sub_Ut_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
+  sub_At_v<D>(o, cp.u[k], v);
+}
+template <int D, int N>
+DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) t += p.u_fix[q * D + a] * v[q];
+    o[a] -= cp.m[k] * t;
+  }
+}
+// o -= U_k v
+template <int D, int N>
+DGP_HD void coup_sub_U_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
+  sub_A_v<D>(o, cp.u[k], v);
+}
+template <int D, int N>
+DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) t += p.u_fix[a * D + q] * v[q];
+    o[a] -= cp.m[k] * t;
+  }
+}
+// the block itself, in vector registers (the separator row's coupling is PCR state)
+template <int D, int N>
+DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Mat<D>& U) { U = cp.u[k]; }
+template <int D, int N>
+DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, Mat<D>& U) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) U.v[a][c] = cp.m[k] * p.u_fix[a * D + c];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // One Gauss-Newton linear solve for the C rows owned by this lane (rows j*C .. j*C+C-1 of trajectory b).
 //
 //  a. forward block elimination of the lane's C-1 INTERIOR rows (all but its last), carrying the right-hand side
 //     and the "left spike" (the coupling of row 0 to the previous lane's last row):
-//         S_0 = D_0,  S_k = D_k - U_{k-1}^T S_{k-1}^-1 U_{k-1},   G_k = S_k^-1 U_k
+//         S_0 = D_0,  S_k = D_k - U_{k-1}^T G_{k-1},   G_k = S_k^-1 U_k
 //         z_k = r_k - G_{k-1}^T z_{k-1},   Zl_0 = L_0 = U_{-1}^T,   Zl_k = -G_{k-1}^T Zl_{k-1}
-//  b. back substitution, giving the interior unknowns as an affine function of the two neighbouring SEPARATOR
-//     unknowns (x_ps = last row of the previous lane, x_s = last row of this lane):
-//         x_k = P_k - V_k x_ps - W_k x_s
-//  c. the lane's separator row, with x_{C-2} (own interior) and x'_0 (first interior row of the NEXT lane, whose
-//     P'_0, V'_0, W'_0 are fetched across lanes) substituted, is one row of a block-tridiagonal system over the LPT
-//     lanes -> block PCR (log2 LPT rounds) gives x_s;
-//  d. x_ps is fetched from the previous lane and the interior rows follow from b.
+//     i.e.  x_k = S_k^-1 (z_k - Zl_k x_ps) - G_k x_{k+1}     (x_ps = last row of the previous lane).
+//  b. STREAMED with a.: the first interior unknown as an affine function of the two neighbouring SEPARATOR unknowns
+//         x_0 = P_0 - V_0 x_ps - W_0 x_s,     (x_s = last row of this lane)
+//         P_0 = sum_k Pi_k S_k^-1 z_k,  V_0 = sum_k Pi_k S_k^-1 Zl_k,  W_0 = Pi_{C-2} G_{C-2},  Pi_0 = I, Pi_{k+1} = -Pi_k G_k
+//     so that only running products stay live, not G_k / Zl_k of every row;
+//  c. the lane's separator row, with x_{C-2} (own interior; its relation is the last line of a.) and x'_0 (first
+//     interior row of the NEXT lane, whose P'_0, V'_0, W'_0 are fetched across lanes) substituted, is one row of a
+//     block-tridiagonal system over the LPT lanes -> block PCR (log2 LPT rounds) gives x_s;
+//  d. x_ps is fetched from the previous lane and the interior rows follow from a VECTOR forward / back substitution
+//     with the kept S_k^-1, z_k:   w_0 = L_0 x_ps,  w_k = -U_{k-1}^T S_{k-1}^-1 w_{k-1},
+//                                  x_k = S_k^-1 (z_k - w_k - U_k x_{k+1}),  x_{C-1} = x_s
+//     (no d x d blocks survive the PCR rounds -- that is what keeps the kernel inside the vector register file).
 // With C == 1 there are no interior rows and this is plain block PCR on the original system.
+// QSTAT: static covariances, rows assembled by eval_state_static, U_k = m_k * p.u_fix (see Coupling).
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
                             double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
   constexpr int D = 2 * DOF;
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
+  constexpr int KL = (C > 1) ? C - 2 : 0;       // last interior row
   const int n = p.n;
   const Nbr<LPT, 1, Ctx> nb(cx, j);
   // neighbouring states across the lane boundary
   double x_prev[D], x_next[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) { x_prev[a] = nb.lo(x[C - 1][a]); x_next[a] = nb.hi(x[0][a]); }
+  for (int a = 0; a < D; ++a) { x_prev[a] = nb.lo(x[C - 1][a]); x_next[a] = nb.hi(x[0][a]);  }
 
-  Sym<D> Sinv[CI];
-  Mat<D> G[CI], V[CI], W[CI];
-  double P[CI][D];
   const int g0 = j * C;
   LaneFactors<C> lf;
   lane_prefetch<DOF, C, IO>(p, b, g0, traj_ok, x, lf);
   const bool stat = (p.qc_mode == QC_STATIC);
-  Sym<D> Qown, Qm;               // Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
-  fixed_Qinv<DOF>(p, Qown);      // static covariances: built once; per-state modes: reloaded per row
-  fixed_Qinv<DOF>(p, Qm);
-  Mat<D> Urow[2] = {};           // U of the current / previous interior row, alternating (no copies)
-  if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
+  Sym<D> Qown, Qm;               // generic path: Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
+  if (!QSTAT) {
+    fixed_Qinv<DOF>(p, Qown);    // static covariances on the generic path: built once; per-state modes: reloaded per row
+    fixed_Qinv<DOF>(p, Qm);
+    if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
+  }
 
-  // ---- a. forward sweep over the interior rows
-#pragma unroll
-  for (int k = 0; k < C - 1; ++k) {
+  // kept for the interior recovery (d.)
+  Sym<D> Sinv[CI];
+  double z[CI][D];
+  Coupling<D, C, QSTAT> cp;      // U_k of all C rows
+  Mat<D> L0;                     // generic path: left spike seed L_0; static path: L_0 = m_prev0 * p.u_fix^T
+  double m_prev0 = 0.0;
+  // running quantities of the streamed elimination
+  Mat<D> G, Zl, Pi, V0, W0;
+  double P0[D], Pl[D];
+
+  // assemble one row (D_k, r_k; U_k goes into cp)
+  auto assemble = [&](int k, const double (&xm)[D], const double (&xp)[D], Sym<D>& Dk, double (&rk)[D]) {
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
-    Sym<D> Dk; double rk[D];
-    Mat<D>& Uk = Urow[k & 1];
-    const Mat<D>& Uprev = Urow[(k & 1) ^ 1];
-    if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-    eval_state<DOF, IO, true>(p, b, g, valid, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], mu_s, mu_g, Qown, Qm, lf.ow[k],
-                              lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, Uk, rk, acc);
+    if constexpr (QSTAT) {
+      eval_state_static<DOF>(p, g, valid, x[k], xm, xp, mu_s, mu_g, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, cp.m[k], acc);
+    } else {
+      if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
+      eval_state<DOF, IO, true>(p, b, g, valid, x[k], xm, xp, mu_s, mu_g, Qown, Qm, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k],
+                                Dk, cp.u[k], rk, acc);
+    }
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
     }
+  };
+
+  // ---- a. + b. forward sweep over the interior rows
+#pragma unroll
+  for (int k = 0; k < C - 1; ++k) {
+    Sym<D> Dk; double rk[D];
+    assemble(k, (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Dk, rk);
     if (k == 0) {
       // left spike Zl_0 = L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
-      const bool has_prev = valid && g > 0;
+      const bool has_prev = traj_ok && g0 > 0 && g0 < n;
+      if constexpr (QSTAT) {
+        m_prev0 = has_prev ? 1.0 : 0.0;
 #pragma unroll
-      for (int a = 0; a < D; ++a)
+        for (int a = 0; a < D; ++a)
 #pragma unroll
-        for (int c = 0; c < DOF; ++c) {
-          V[0].v[a][c] = has_prev ? -Qm(a, c) : 0.0;
-          V[0].v[a][DOF + c] = has_prev ? -(p.dt * Qm(a, c) + Qm(a, DOF + c)) : 0.0;
-        }
+          for (int c = 0; c < D; ++c) Zl.v[a][c] = m_prev0 * p.u_fix[c * D + a];
+      } else {
 #pragma unroll
-      for (int a = 0; a < D; ++a) P[0][a] = rk[a];
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int c = 0; c < DOF; ++c) {
+            L0.v[a][c] = has_prev ? -Qm(a, c) : 0.0;
+            L0.v[a][DOF + c] = has_prev ? -(p.dt * Qm(a, c) + Qm(a, DOF + c)) : 0.0;
+          }
+        Zl = L0;
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a) z[0][a] = rk[a];
     } else {
-      sub_At_B_sym<D>(Dk, Uprev, G[k - 1]);               // S_k = D_k - U_{k-1}^T G_{k-1}
+      coup_sub_UtB_sym<D, C>(p, cp, k - 1, Dk, G);          // S_k = D_k - U_{k-1}^T G_{k-1}
 #pragma unroll
-      for (int a = 0; a < D; ++a) P[k][a] = rk[a];
-      sub_At_v<D>(P[k], G[k - 1], P[k - 1]);              // z_k = r_k - G_{k-1}^T z_{k-1}
-      neg_At_B<D>(G[k - 1], V[k - 1], V[k]);              // Zl_k = -G_{k-1}^T Zl_{k-1}
+      for (int a = 0; a < D; ++a) z[k][a] = rk[a];
+      sub_At_v<D>(z[k], G, z[k > 0 ? k - 1 : 0]);          // z_k = r_k - G_{k-1}^T z_{k-1}
+      Mat<D> T;
+      neg_At_B<D>(G, Zl, T);                               // Zl_k = -G_{k-1}^T Zl_{k-1}
+      Zl = T;
     }
     sym_inverse<D>(Dk, Sinv[k], ok);
-    sym_times_mat<D>(Sinv[k], Uk, G[k]);                  // G_k = S_k^-1 U_k
-    if (!stat) Qm = Qown;
-  }
-  // ---- b. back substitution: P, V, W in place
-  if (C > 1) {
-    {
-      constexpr int k = (C > 1) ? C - 2 : 0;
-      double t[D];
-      sym_times_vec<D>(Sinv[k], P[k], t);
+    double y[D];
+    Mat<D> Y;
+    sym_times_vec<D>(Sinv[k], z[k], y);                    // y_k = S_k^-1 z_k
+    sym_times_mat<D>(Sinv[k], Zl, Y);                      // Y_k = S_k^-1 Zl_k
+    coup_SinvU<D, C>(p, cp, k, Sinv[k], G);                // G_k = S_k^-1 U_k
+    if (k == 0) {
 #pragma unroll
-      for (int a = 0; a < D; ++a) P[k][a] = t[a];
+      for (int a = 0; a < D; ++a) P0[a] = y[a];
+      V0 = Y;
+      if (k == KL) {
+        W0 = G;                                            // C == 2: W_0 = G_0
+      } else {
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+          for (int c = 0; c < D; ++c) Pi.v[a][c] = -G.v[a][c];       // Pi_1 = -G_0
+      }
+    } else {
+      add_A_v<D>(P0, Pi, y);                               // P_0 += Pi_k y_k
+      add_A_B<D>(V0, Pi, Y);                               // V_0 += Pi_k Y_k
       Mat<D> T;
-      sym_times_mat<D>(Sinv[k], V[k], T);
-      V[k] = T;
-      W[k] = G[k];
+      if (k == KL) { A_B<D>(Pi, G, T); W0 = T; }           // W_0 = Pi_{C-2} G_{C-2}
+      else { neg_A_B<D>(Pi, G, T); Pi = T; }               // Pi_{k+1} = -Pi_k G_k
     }
+    if (k == KL) {
 #pragma unroll
-    for (int k = C - 3; k >= 0; --k) {
-      double t[D];
-      sym_times_vec<D>(Sinv[k], P[k], t);
-      sub_A_v<D>(t, G[k], P[k + 1]);
-#pragma unroll
-      for (int a = 0; a < D; ++a) P[k][a] = t[a];
-      Mat<D> T;
-      sym_times_mat<D>(Sinv[k], V[k], T);
-      sub_A_B<D>(T, G[k], V[k + 1]);
-      V[k] = T;
-      neg_A_B<D>(G[k], W[k + 1], W[k]);
+      for (int a = 0; a < D; ++a) Pl[a] = y[a];            // P_{C-2} = y_{C-2}  (x_{C-2} = y - Y x_ps - G x_s)
     }
+    if (!QSTAT && !stat) Qm = Qown;
   }
   // ---- c. separator row -> reduced system row
   Sym<D> Ds; Mat<D> Us; double rs[D];
-  {
-    const int g = g0 + C - 1;
-    const bool valid = traj_ok && g < n;
-    if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-    eval_state<DOF, IO, true>(p, b, g, valid, x[C - 1], (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, mu_s, mu_g, Qown, Qm,
-                              lf.ow[C - 1], lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, Us, rs, acc);
-    if (RHS_OVERRIDE) {
-#pragma unroll
-      for (int a = 0; a < D; ++a) rs[a] = valid ? rhs[C - 1][a] : 0.0;
-    }
-  }
+  assemble(C - 1, (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Ds, rs);
+  coup_get<D, C>(p, cp, C - 1, Us);
   if (C > 1) {
-    const Mat<D>& Uprev = Urow[(C > 1 ? C - 2 : 0) & 1];  // U of the last interior row
-    sub_At_B_sym<D>(Ds, Uprev, W[C > 1 ? C - 2 : 0]);     // D_s -= U_{C-2}^T W_{C-2}
-    sub_At_v<D>(rs, Uprev, P[C > 1 ? C - 2 : 0]);         // r_s -= U_{C-2}^T P_{C-2}
+    coup_sub_UtB_sym<D, C>(p, cp, KL, Ds, G);             // D_s -= U_{C-2}^T W_{C-2},  W_{C-2} = G_{C-2}
+    coup_sub_Ut_v<D, C>(p, cp, KL, rs, Pl);               // r_s -= U_{C-2}^T P_{C-2}
     // first interior row of the next lane
     Mat<D> Vn, Wn; double Pn[D];
 #pragma unroll
     for (int a = 0; a < D; ++a) {
-      Pn[a] = nb.hi(P[0][a]);
+      Pn[a] = nb.hi(P0[a]);
 #pragma unroll
-      for (int c = 0; c < D; ++c) { Vn.v[a][c] = nb.hi(V[0].v[a][c]); Wn.v[a][c] = nb.hi(W[0].v[a][c]); }
+      for (int c = 0; c < D; ++c) { Vn.v[a][c] = nb.hi(V0.v[a][c]); Wn.v[a][c] = nb.hi(W0.v[a][c]); }
     }
     // (Us == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
     sub_A_B_sym<D>(Ds, Us, Vn);                           // D_s -= U_s V'_0
@@ -1117,16 +1335,43 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   if (C > 1) {
     double xps[D];
 #pragma unroll
-    for (int a = 0; a < D; ++a) xps[a] = nb.lo(xs[a]);                // V == 0 where there is no previous separator
+    for (int a = 0; a < D; ++a) xps[a] = nb.lo(xs[a]);                // L_0 == 0 where there is no previous separator
+    double w[D], q[CI][D];
+    // w_0 = L_0 x_ps
+    if constexpr (QSTAT) {
 #pragma unroll
-    for (int k = 0; k < C - 1; ++k) {
+      for (int a = 0; a < D; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) t += p.u_fix[c * D + a] * xps[c];
+        w[a] = m_prev0 * t;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a) w[a] = 0.0;
+      add_A_v<D>(w, L0, xps);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) q[0][a] = z[0][a] - w[a];
+#pragma unroll
+    for (int k = 1; k < C - 1; ++k) {
       double t[D];
+      sym_times_vec<D>(Sinv[k - 1], w, t);
 #pragma unroll
-      for (int a = 0; a < D; ++a) t[a] = P[k][a];
-      sub_A_v<D>(t, V[k], xps);
-      sub_A_v<D>(t, W[k], xs);
+      for (int a = 0; a < D; ++a) w[a] = 0.0;
+      coup_sub_Ut_v<D, C>(p, cp, k - 1, w, t);                         // w_k = -U_{k-1}^T (S_{k-1}^-1 w_{k-1})
 #pragma unroll
-      for (int a = 0; a < D; ++a) dx[k][a] = t[a];
+      for (int a = 0; a < D; ++a) q[k][a] = z[k][a] - w[a];
+    }
+    double xn[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) xn[a] = xs[a];
+#pragma unroll
+    for (int k = C - 2; k >= 0; --k) {
+      coup_sub_U_v<D, C>(p, cp, k, q[k], xn);                          // q_k - U_k x_{k+1}
+      sym_times_vec<D>(Sinv[k], q[k], xn);
+#pragma unroll
+      for (int a = 0; a < D; ++a) dx[k][a] = xn[a];
     }
   }
 }
@@ -1159,7 +1404,7 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
 // ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, int C, typename IO, int MODE, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT, typename Ctx>
 DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;                 // trajectories per wavefront
@@ -1200,7 +1445,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, false>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, false, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
     const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {

@@ -83,10 +83,20 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
   for (int l = 0; l < 64; ++l) {
     th.emplace_back([&, l]() {
       HostCtx cx{&ws, l, wave};
-      if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP>(p, cx);
-      else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE>(p, cx);
-      else if (mode == dgp::MODE_EVAL) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL>(p, cx);
-      else dgp::gn_backward_lane_program<DOF, LPT, C, IO>(p, *g, cx);
+      // same dispatch as dgp_dev::launch_typed: static covariances run the QSTAT specialisation
+      const bool qstat = (p.qc_mode == dgp::QC_STATIC);
+      if (mode == dgp::MODE_STEP) {
+        if (qstat) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, true>(p, cx);
+        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, false>(p, cx);
+      } else if (mode == dgp::MODE_SOLVE) {
+        if (qstat) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, true>(p, cx);
+        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, false>(p, cx);
+      } else if (mode == dgp::MODE_EVAL) {
+        dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL, false>(p, cx);
+      } else {
+        if (qstat) dgp::gn_backward_lane_program<DOF, LPT, C, IO, true>(p, *g, cx);
+        else dgp::gn_backward_lane_program<DOF, LPT, C, IO, false>(p, *g, cx);
+      }
     });
   }
   for (auto& t : th) t.join();
