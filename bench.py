@@ -140,8 +140,8 @@ def cpu_blocktri(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, steps=5):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=200)
-  ap.add_argument('--warmup', type=int, default=20)
+  ap.add_argument('--steps', type=int, default=20000)
+  ap.add_argument('--warmup', type=int, default=2000)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   args = ap.parse_args()
 

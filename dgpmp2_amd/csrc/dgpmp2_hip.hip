@@ -11,9 +11,12 @@ using dgp_host::fail;
 
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const DgpShape sh = dgp_host::choose_shape(h, p.B);
-  const bool f64 = h->cfg.io_dtype == DGP_F64;
-  if (h->cfg.dof == 2) return f64 ? dgp_launch_2_f64(sh, mode, p, g, s) : dgp_launch_2_f32(sh, mode, p, g, s);
-  return f64 ? dgp_launch_3_f64(sh, mode, p, g, s) : dgp_launch_3_f32(sh, mode, p, g, s);
+  // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
+  static const DgpLaunchFn table[2][2][dgp_dev::NUM_GROUPS] = {
+      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2}, {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2}},
+      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2}, {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2}}};
+  const int f64 = h->cfg.io_dtype == DGP_F64 ? 1 : 0;
+  return table[h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
 }
 
 }  // namespace

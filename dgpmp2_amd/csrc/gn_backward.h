@@ -74,7 +74,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.dtheta, b, g0, traj_ok, vec, dthr);
 #pragma unroll
   for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
-  LaneTaps<C> taps;
+  LaneTaps<C, IO> taps;
   lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
 
 #pragma unroll
@@ -192,7 +192,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       const double w = taps.ow[k];
       double c, hx, hy;
       ObsTaps tp;
-      obstacle_finish(p, taps.oa[k], taps.d11[k], taps.d21[k], taps.d12[k], taps.d22[k], taps.eps[k], c, hx, hy, &tp);
+      obstacle_finish(p, taps.oa[k], (double)taps.d11[k], (double)taps.d21[k], (double)taps.d12[k], (double)taps.d22[k], taps.eps[k], c, hx, hy, &tp);
       double g_eps = 0.0, g_w = 0.0;
       if (tp.act) {
         const double u = hx * lk[0] + hy * lk[1];

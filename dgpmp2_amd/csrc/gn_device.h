@@ -53,8 +53,11 @@ struct DevCtx {
 // for two costs ~40 spilled registers on the d = 4, C <= 2 kernels, which pays only where a launch has more wavefronts
 // than the chip has SIMDs, i.e. for the shapes with 32 or 64 lanes per trajectory (measured at B = 4096, n = 64:
 // (32,2) 33.6 -> 23.0 us, (64,1) 47.9 -> 44.3 us; but (16,2) at n = 32, one wavefront per SIMD, 10.9 -> 12.2 us).
+#ifndef DGP_FORCE_WPS
+#define DGP_FORCE_WPS 0       // tuning aid: -DDGP_FORCE_WPS=2 forces the two-wavefront register budget on every kernel
+#endif
 template <int DOF, int LPT, int C, int MODE>
-struct WavesPerSimd { static constexpr int value = (DOF == 2 && C <= 2 && LPT >= 32 && MODE != dgp::MODE_SOLVE) ? 2 : 1; };
+struct WavesPerSimd { static constexpr int value = DGP_FORCE_WPS ? DGP_FORCE_WPS : (DOF == 2 && C <= 2 && LPT >= 32 && MODE != dgp::MODE_SOLVE) ? 2 : 1; };
 
 // QSTAT: static covariances (p.qc_mode == QC_STATIC) -- the constant GP blocks are scalar operands (see gn_lane.h).
 template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT>
@@ -75,28 +78,33 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
 // mode: dgp::MODE_* or MODE_BACKWARD
 enum { MODE_BACKWARD = 3 };
 
-template <int DOF, typename IO>
+// The kernels are spread over translation units (gn_inst.hip, one per (dof, io dtype, group)) so that they build in
+// parallel.  Group of a launch: static-covariance STEP / SOLVE, the generic STEP / SOLVE plus EVAL, the two backward kernels.
+enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, NUM_GROUPS = 3 };
+inline int launch_group(int mode, const dgp::GnParams& p) {
+  if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
+  return (mode != dgp::MODE_EVAL && p.qc_mode == dgp::QC_STATIC) ? GROUP_STATIC : GROUP_GENERIC;
+}
+
+template <int DOF, typename IO, int GROUP>
 hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const int tpw = 64 / sh.lpt;
   const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
   const bool qstat = (p.qc_mode == dgp::QC_STATIC);
+  if (launch_group(mode, p) != GROUP) return hipErrorInvalidValue;
 #define DGP_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, p)
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
-    switch (mode) {                                                                                                        \
-      case dgp::MODE_STEP:                                                                                                 \
-        if (qstat) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, true>));                                          \
-        else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, false>));                                               \
-        break;                                                                                                             \
-      case dgp::MODE_SOLVE:                                                                                                \
-        if (qstat) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, true>));                                         \
-        else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, false>));                                              \
-        break;                                                                                                             \
-      case dgp::MODE_EVAL: DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, false>)); break;                          \
-      default:                                                                                                             \
-        if (qstat) hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, true>), grid, block, 0, s, p, *g);               \
-        else hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, false>), grid, block, 0, s, p, *g);                    \
-        break;                                                                                                             \
+    if constexpr (GROUP == GROUP_STATIC) {                                                                                 \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, true>));                           \
+      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, true>));                                                 \
+    } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, false>));                          \
+      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, false>));                   \
+      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, false>));                                                 \
+    } else {                                                                                                               \
+      if (qstat) hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, true>), grid, block, 0, s, p, *g);                 \
+      else hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, false>), grid, block, 0, s, p, *g);                      \
     }                                                                                                                      \
     return hipGetLastError();                                                                                              \
   }
@@ -108,8 +116,11 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
 
 }  // namespace dgp_dev
 
-// One translation unit per (dof, io dtype) -- see gn_inst.hip -- so that the 4 x 36 kernels build in parallel.
-hipError_t dgp_launch_2_f32(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
-hipError_t dgp_launch_2_f64(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
-hipError_t dgp_launch_3_f32(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
-hipError_t dgp_launch_3_f64(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+// One translation unit per (dof, io dtype, group) -- see gn_inst.hip.
+typedef hipError_t (*DgpLaunchFn)(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+#define DGP_DECL_INST(d, t) \
+  hipError_t dgp_launch_##d##_##t##_g0(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
+  hipError_t dgp_launch_##d##_##t##_g1(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
+  hipError_t dgp_launch_##d##_##t##_g2(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+DGP_DECL_INST(2, f32) DGP_DECL_INST(2, f64) DGP_DECL_INST(3, f32) DGP_DECL_INST(3, f64)
+#undef DGP_DECL_INST

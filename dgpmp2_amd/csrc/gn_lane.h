@@ -644,16 +644,15 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
 // constant blocks are scalar operands of the FMAs.  The coupling block itself is NOT written: U_g = m_next * p.u_fix.
 //   m_next = 1 iff row g is valid and g < n-1;   m_prev = 1 iff row g is valid and g > 0
 template <int DOF>
-DGP_HD void eval_state_static(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
-                              const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
-                              double ow, double oc, double ohx, double ohy, Sym<2 * DOF>& Dm, double (&r)[2 * DOF],
-                              double& m_next, ErrAcc& acc) {
+DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
+                       const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
+                       double (&r)[2 * DOF], ErrAcc& acc) {
+  // priors + GP factors: everything of row g that does NOT depend on the SDF lookup (runs while the taps are in flight)
   constexpr int D = 2 * DOF;
   const int n = p.n;
   const double dt = p.dt;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
   const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
-  m_next = mN;
   // ---- start / goal priors (prior_factor.py:15-18; plan_layer.py:64-68)
   const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
   double s2 = 0.0;
@@ -683,7 +682,6 @@ DGP_HD void eval_state_static(const GnParams& p, int g, bool valid, const double
     so += eo[a] * eo[a];
   }
   acc.e += mN * (0.5 * q); acc.eext += mN * (0.5 * q); acc.ugp += mN * (0.5 * so);
-  const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double tu = 0.0, tq = 0.0;
@@ -693,11 +691,24 @@ DGP_HD void eval_state_static(const GnParams& p, int g, bool valid, const double
       tq += p.q_fix[Sym<D>::idx(a, c)] * em[c];            // (Q e_prev)_a:  eta -= Q e_prev
     }
     r[a] = w * ep[a] - mN * tu - mP * tq;
+  }
+}
+
+// diagonal block of row g without the single-state factors; m_next = 1 iff the row couples to row g+1
+template <int DOF>
+DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next) {
+  constexpr int D = 2 * DOF;
+  const int n = p.n;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  m_next = mN;
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
+#pragma unroll
+  for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int c = a; c < D; ++c)
       Dm(a, c) = ((a == c) ? dbase + w : 0.0) + mN * p.a_fix[Sym<D>::idx(a, c)] + mP * p.q_fix[Sym<D>::idx(a, c)];
-  }
-  eval_state_local<DOF, true>(p, x, ow, oc, ohx, ohy, Dm, r, acc);
 }
 
 // Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
@@ -709,14 +720,17 @@ struct LaneFactors {          // obstacle factor of each of the lane's C states:
 
 // All loads are UNCONDITIONAL (rows / trajectories that do not exist read element 0 of the same tensor and are masked
 // afterwards): a load inside a divergent `if (valid)` costs its own s_waitcnt, i.e. one exposed memory round trip each.
-template <int C>
+// The tap values stay in the I/O element type until they are used (lane_obstacle_finish): a conversion here would be
+// the first USE of the load and pin the memory wait in front of whatever is scheduled under the loads.
+template <int C, typename IO>
 struct LaneTaps {
   ObsAddr oa[C];
-  double d11[C], d21[C], d12[C], d22[C], eps[C], ow[C];
+  IO d11[C], d21[C], d12[C], d22[C];
+  double eps[C], ow[C];
 };
 
 template <int DOF, int C, typename IO>
-DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneTaps<C>& t) {
+DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneTaps<C, IO>& t) {
   const int n = p.n;
   const int64_t W = p.sdf_cols;
   const IO* grid = (const IO*)p.sdf + (traj_ok ? b : 0) * p.sdf_bstride;
@@ -737,22 +751,66 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
   for (int k = 0; k < C; ++k) {
     // grids have fewer than 2^31 elements (host-checked): 32-bit element offsets
     const int32_t r1 = t.oa[k].y1 * (int32_t)W, r2 = t.oa[k].y2 * (int32_t)W;
-    t.d11[k] = (double)grid[r1 + t.oa[k].x1]; t.d21[k] = (double)grid[r1 + t.oa[k].x2];
-    t.d12[k] = (double)grid[r2 + t.oa[k].x1]; t.d22[k] = (double)grid[r2 + t.oa[k].x2];
+    t.d11[k] = grid[r1 + t.oa[k].x1]; t.d21[k] = grid[r1 + t.oa[k].x2];
+    t.d12[k] = grid[r2 + t.oa[k].x1]; t.d22[k] = grid[r2 + t.oa[k].x2];
+  }
+}
+
+// Orders the first USE of the lane's tap loads after the values in `after` have been computed: an empty asm statement that
+// takes the loaded registers in/out and `after` as inputs.  Without it the compiler schedules the consumers of the loads
+// (and with them the s_waitcnt) directly behind the loads, and the arithmetic that does not need them behind that, so a
+// wavefront that is alone on its SIMD sits out the whole L2 / HBM round trip.  Emits no instruction; no-op on the host.
+template <int C, typename IO, int N>
+DGP_HD void lane_taps_use_after(LaneTaps<C, IO>& t, const double (&after)[N]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(N <= 16, "too many anchor operands");
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    if constexpr (N == 16)
+      asm volatile("" : "+v"(t.d11[k]), "+v"(t.d21[k]), "+v"(t.d12[k]), "+v"(t.d22[k])
+                   : "v"(after[0]), "v"(after[1]), "v"(after[2]), "v"(after[3]), "v"(after[4]), "v"(after[5]), "v"(after[6]),
+                     "v"(after[7]), "v"(after[8]), "v"(after[9]), "v"(after[10]), "v"(after[11]), "v"(after[12]),
+                     "v"(after[13]), "v"(after[14]), "v"(after[15]));
+    else if constexpr (N == 8)
+      asm volatile("" : "+v"(t.d11[k]), "+v"(t.d21[k]), "+v"(t.d12[k]), "+v"(t.d22[k])
+                   : "v"(after[0]), "v"(after[1]), "v"(after[2]), "v"(after[3]), "v"(after[4]), "v"(after[5]), "v"(after[6]),
+                     "v"(after[7]));
+    else
+      asm volatile("" : "+v"(t.d11[k]), "+v"(t.d21[k]), "+v"(t.d12[k]), "+v"(t.d22[k]) : "v"(after[0]), "v"(after[N - 1]));
+  }
+#else
+  (void)t; (void)after;
+#endif
+}
+
+// Orders arithmetic on `v` after the tap addresses of all C states are known (so the loads go out first).
+template <int C, typename IO, int D>
+DGP_HD void lane_after_addresses(const LaneTaps<C, IO>& t, double (&v)[D]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+    asm volatile("" : "+v"(v[a]) : "v"(t.oa[0].y2), "v"(t.oa[C / 2].y2), "v"(t.oa[C - 1].x2), "v"(t.oa[C - 1].y2));
+#else
+  (void)t; (void)v;
+#endif
+}
+
+template <int C, typename IO>
+DGP_HD void lane_obstacle_finish(const GnParams& p, int g0, bool traj_ok, const LaneTaps<C, IO>& t, LaneFactors<C>& f) {
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const bool valid = traj_ok && (g0 + k) < p.n;
+    obstacle_finish(p, t.oa[k], (double)t.d11[k], (double)t.d21[k], (double)t.d12[k], (double)t.d22[k], t.eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
+    f.ow[k] = t.ow[k];
+    if (!valid) { f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0; }
   }
 }
 
 template <int DOF, int C, typename IO>
 DGP_HD void lane_prefetch(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneFactors<C>& f) {
-  LaneTaps<C> t;
+  LaneTaps<C, IO> t;
   lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, t);
-#pragma unroll
-  for (int k = 0; k < C; ++k) {
-    const bool valid = traj_ok && (g0 + k) < p.n;
-    obstacle_finish(p, t.oa[k], t.d11[k], t.d21[k], t.d12[k], t.d22[k], t.eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
-    f.ow[k] = t.ow[k];
-    if (!valid) { f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0; }
-  }
+  lane_obstacle_finish<C, IO>(p, g0, traj_ok, t, f);
 }
 
 // small dense helpers on dxd blocks -----------------------------------------------------------------
@@ -1203,7 +1261,41 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 
   const int g0 = j * C;
   LaneFactors<C> lf;
-  lane_prefetch<DOF, C, IO>(p, b, g0, traj_ok, x, lf);
+  double rgp[QSTAT ? C : 1][D];  // static path: prior + GP part of eta, computed while the SDF taps are in flight
+  {
+    LaneTaps<C, IO> taps;
+    lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
+    if constexpr (QSTAT) {
+      // (the copies xa are tied to the tap ADDRESSES, so that the loads are issued before this arithmetic starts)
+      double xa[C][D];
+#pragma unroll
+      for (int k = 0; k < C; ++k) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) xa[k][a] = x[k][a];
+        lane_after_addresses<C, IO, D>(taps, xa[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+        static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, xa[k], (k == 0) ? x_prev : xa[k > 0 ? k - 1 : 0],
+                        (k == C - 1) ? x_next : xa[k < C - 1 ? k + 1 : 0], mu_s, mu_g, rgp[k], acc);
+      // first components of every row's eta (each is the end of that row's dependency chain)
+      double anchor[2 * C];
+#pragma unroll
+      for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
+      lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
+    }
+    lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
+  }
+#if defined(DGP_PHASE_STOP)     // profiles/tools/phase_probe.hip: cut the program short after a phase (timing aid, never in the product build)
+  if (DGP_PHASE_STOP == 1 || DGP_PHASE_STOP == 2) {
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+        dx[k][a] = x[k][a] + x_prev[a] + x_next[a] + (DGP_PHASE_STOP == 2 ? lf.oc[k] + lf.ohx[k] + lf.ohy[k] + (QSTAT ? rgp[QSTAT ? k : 0][a] : 0.0) : 0.0);
+    return;
+  }
+#endif
   const bool stat = (p.qc_mode == QC_STATIC);
   Sym<D> Qown, Qm;               // generic path: Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
   if (!QSTAT) {
@@ -1227,7 +1319,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
     if constexpr (QSTAT) {
-      eval_state_static<DOF>(p, g, valid, x[k], xm, xp, mu_s, mu_g, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, cp.m[k], acc);
+      static_diag<DOF>(p, g, valid, Dk, cp.m[k]);
+#pragma unroll
+      for (int a = 0; a < D; ++a) rk[a] = rgp[k][a];
+      eval_state_local<DOF, true>(p, x[k], lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, acc);
     } else {
       if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
       eval_state<DOF, IO, true>(p, b, g, valid, x[k], xm, xp, mu_s, mu_g, Qown, Qm, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k],
@@ -1327,10 +1422,28 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     neg_A_B<D>(Us, Wn, Ur);                               // U_red = -U_s W'_0
     Us = Ur;
   }
+#if defined(DGP_PHASE_STOP)
+  if (DGP_PHASE_STOP == 3) {
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) dx[k][a] = Ds(a, a) + Ds(0, a) + rs[a] + Us.v[a][k % D] + Us.v[k % D][a] + (k < CI ? z[k < CI ? k : 0][a] + Sinv[k < CI ? k : 0](a, a) : 0.0);
+    return;
+  }
+#endif
   double xs[D];
   pcr_solve<D, LPT>(cx, j, Ds, Us, rs, xs, ok);
 #pragma unroll
   for (int a = 0; a < D; ++a) dx[C - 1][a] = xs[a];
+#if defined(DGP_PHASE_STOP)
+  if (DGP_PHASE_STOP == 4) {
+#pragma unroll
+    for (int k = 0; k < C - 1; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) dx[k][a] = xs[a] + z[k][a] + Sinv[k](a, a);
+    return;
+  }
+#endif
   // ---- d. interior rows
   if (C > 1) {
     double xps[D];
