@@ -80,6 +80,10 @@ inline void fill_static_blocks(dgp::GnParams& p, int dof) {
     }
   for (int a = 0; a < dof; ++a)
     for (int c = 0; c < d; ++c) { U[a][c] = -Q[a][c]; U[dof + a][c] = -(p.dt * Q[a][c] + Q[dof + a][c]); }
+  p.qc_diag = 1;
+  for (int i = 0; i < dof; ++i)
+    for (int j = 0; j < dof; ++j)
+      if (i != j && p.qc_fix[i * dof + j] != 0.0) p.qc_diag = 0;
   auto sidx = [d](int i, int j) { return i * d - (i * (i - 1)) / 2 + (j - i); };      // Sym<d>::idx for i <= j
   for (int a = 0; a < d; ++a)
     for (int c = 0; c < d; ++c) {
@@ -166,6 +170,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   p.sdf = sdf->data; p.sdf_rows = sdf->rows; p.sdf_cols = sdf->cols; p.sdf_bstride = sdf->batch_stride;
   // obstacle_cost.py:34 and sdf_utils.py:57-58, evaluated exactly as Python does (fp64)
   p.res = (h->cfg.x_lims[1] - h->cfg.x_lims[0]) / (double)sdf->cols;
+  p.inv_res = 1.0 / p.res;
   p.orig_px = (0. - h->cfg.x_lims[0] / p.res);
   p.orig_py = (0. - h->cfg.y_lims[0] / p.res);
   p.qc_mode = DGP_QC_STATIC; p.qc = nullptr; p.obs_w = nullptr; p.eps = nullptr;

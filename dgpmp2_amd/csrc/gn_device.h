@@ -35,6 +35,13 @@ struct DevCtx {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + S, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   }
+  // value of the lane 8 positions away inside the 16-lane DPP row (row_ror:8 -- the two halves of the row swap)
+  __device__ __forceinline__ double row_rotate8(double v) const {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  }
   __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }
   // XCD (accelerator complex die) this wavefront runs on, 0..7 on MI355X: HW_REG_XCC_ID (id 20), bits [3:0]
   __device__ __forceinline__ int xcc_id() const { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }
@@ -83,14 +90,14 @@ enum { MODE_BACKWARD = 3 };
 enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, NUM_GROUPS = 3 };
 inline int launch_group(int mode, const dgp::GnParams& p) {
   if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
-  return (mode != dgp::MODE_EVAL && p.qc_mode == dgp::QC_STATIC) ? GROUP_STATIC : GROUP_GENERIC;
+  return (mode != dgp::MODE_EVAL && dgp::use_static_kernels(p)) ? GROUP_STATIC : GROUP_GENERIC;
 }
 
 template <int DOF, typename IO, int GROUP>
 hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const int tpw = 64 / sh.lpt;
   const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
-  const bool qstat = (p.qc_mode == dgp::QC_STATIC);
+  const bool qstat = dgp::use_static_kernels(p);
   if (launch_group(mode, p) != GROUP) return hipErrorInvalidValue;
 #define DGP_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, p)
 #define DGP_CASE(L, CC)                                                                                                   \

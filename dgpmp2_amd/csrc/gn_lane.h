@@ -66,16 +66,21 @@ struct GnParams {
   double obs_w_fix;          // 1/cost_sigma^2                   (plan_layer.py:74)
   double qc_fix[9];          // gp_params['Q_c_inv']
   double res, orig_px, orig_py;   // sdf_utils.py:57-58, obstacle_cost.py:34
+  double inv_res;                 // 1 / res, correctly rounded (host division)
   double w_d, w_v, vmax[2];  // 1/K_d^2, 1/K_v^2, (v_x, v_y)
   double M;                  // plan_layer.py:43-45
   double tol_delta;
   // Static covariances (qc_mode == QC_STATIC): the three constant blocks every GP factor contributes, precomputed on the
   // host from (dt, Q_c_inv) so that the kernels read them as scalar (SGPR) operands instead of holding them in vector
   // registers.  d = 2 dof; symmetric blocks packed like Sym<d>, u_fix row-major d x d.
+  int32_t qc_diag, pad2_;    // 1: Q_c_inv is diagonal -> the static (QSTAT) kernels apply; else static covariances run the generic ones
   double q_fix[21];          // Q^-1                                   (gp_factor.py:65-73)
   double a_fix[21];          // Phi^T Q^-1 Phi                         (block (i,i) share of factor i -> i+1)
   double u_fix[36];          // U = -Phi^T Q^-1                        (block (i,i+1))
 };
+
+// The QSTAT kernel variants (see Coupling below) apply to static covariances with a diagonal Q_c_inv.
+DGP_HD bool use_static_kernels(const GnParams& p) { return p.qc_mode == QC_STATIC && p.qc_diag != 0; }
 
 // ---------------------------------------------------------------------------------------------------
 // tiny fixed-size linear algebra, fully unrolled so that everything lives in registers
@@ -92,6 +97,11 @@ struct Sym {                 // symmetric DxD, packed upper triangle
 
 template <int D>
 struct Mat { double v[D][D]; };
+
+// Static covariances with a DIAGONAL Q_c_inv (the reference's default, Q_c_inv = I / sigma^2): Q^-1 = [[qa C, qb C],[qb C, qc C]]
+// with C diagonal, so Q^-1, Phi^T Q^-1 Phi and U = -Phi^T Q^-1 only couple position and velocity of the SAME degree of
+// freedom: entry (a, c) is structurally zero unless a = c (mod dof).  The static kernels skip those terms.
+template <int D> constexpr DGP_HD bool gp_nz(int a, int c) { return (a % (D / 2)) == (c % (D / 2)); }
 
 // 1/v for a pivot: on the device v_rcp_f64 refined by two Newton steps (full double accuracy for normal, finite v;
 // the IEEE division expansion's scaling / fix-up of denormals and overflow is not needed for SPD pivots).
@@ -357,11 +367,20 @@ struct ObsAddr {
   int32_t x1, x2, y1, y2;          // clamped to [0, W-1] / [0, H-1]: 32 bits are plenty (and int32 -> fp64 is one instruction)
 };
 
+// a / res, correctly rounded, without the ~11-instruction IEEE division expansion and its quarter-rate v_rcp_f64:
+// q0 = a * (1/res), one exact-residual correction q1 = q0 + (a - q0 res) (1/res) with FMAs (Markstein's division step; with
+// 1/res correctly rounded the result equals the IEEE quotient -- checked against a / res on 2.6e9 operand pairs, including
+// near-integer quotients, in profiles/tools/div_check.c).  Non-finite a gives NaN instead of +-inf; both end as NaN costs.
+DGP_HD double div_res(const GnParams& p, double a) {
+  const double q0 = a * p.inv_res;
+  const double r = __builtin_fma(-q0, p.res, a);
+  return __builtin_fma(r, p.inv_res, q0);
+}
+
 DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
 #pragma clang fp contract(off)
-  const double res = p.res;
-  o.px = p.orig_px + x / res;                             // :61
-  o.py = p.orig_py - y / res;                             // :62
+  o.px = p.orig_px + div_res(p, x);                       // :61   orig + x / res
+  o.py = p.orig_py - div_res(p, y);                       // :62
   double fpx = floor(o.px), fpy = floor(o.py);
   // floor -> int64 -> clamp (:64-72); saturate first so that huge |px| cannot overflow the conversion
   const double big = 1.0e9;                               // |floor| <= 1e9 fits int32 and int32 + 1 does not overflow
@@ -383,7 +402,6 @@ DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
 DGP_HD void obstacle_finish(const GnParams& p, const ObsAddr& o, double d11, double d21, double d12, double d22, double eps,
                             double& cost, double& hx, double& hy, ObsTaps* taps = nullptr) {
 #pragma clang fp contract(off)
-  const double res = p.res;
   const double px = o.px, py = o.py;
   double fx1 = (double)o.x1, fx2 = (double)o.x2, fy1 = (double)o.y1, fy2 = (double)o.y2;
   double wa = (fx2 - px) * (fy2 - py);                    // :81-84
@@ -391,8 +409,8 @@ DGP_HD void obstacle_finish(const GnParams& p, const ObsAddr& o, double d11, dou
   double wc = (fx2 - px) * (py - fy1);
   double wd = (px - fx1) * (py - fy1);
   double dist = wa * d11 + wb * d21 + wc * d12 + wd * d22;   // :90
-  double Jx = (-1.0 * ((fy2 - py) * (d21 - d11) + (py - fy1) * (d22 - d12))) / res;   // :93
-  double Jy = ((fx2 - px) * (d12 - d11) + (px - fx1) * (d22 - d21)) / res;            // :94
+  double Jx = div_res(p, -1.0 * ((fy2 - py) * (d21 - d11) + (py - fy1) * (d22 - d12)));   // :93   (...) / res
+  double Jy = div_res(p, (fx2 - px) * (d12 - d11) + (px - fx1) * (d22 - d21));            // :94
   double eps_tot = eps + p.radius;                        // obstacle_cost.py:30
   bool act = dist <= eps_tot;                             // :36
   cost = act ? (eps_tot - dist) : 0.0;
@@ -677,7 +695,7 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
   for (int a = 0; a < D; ++a) {
     double t = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) t += p.q_fix[Sym<D>::idx(a, c)] * eo[c];
+    for (int c = 0; c < D; ++c) if (gp_nz<D>(a, c)) t += p.q_fix[Sym<D>::idx(a, c)] * eo[c];
     q += eo[a] * t;
     so += eo[a] * eo[a];
   }
@@ -686,7 +704,7 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
   for (int a = 0; a < D; ++a) {
     double tu = 0.0, tq = 0.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
+    for (int c = 0; c < D; ++c) if (gp_nz<D>(a, c)) {
       tu += p.u_fix[a * D + c] * eo[c];                    // (U e_own)_a :  eta += Phi^T Q e = -U e
       tq += p.q_fix[Sym<D>::idx(a, c)] * em[c];            // (Q e_prev)_a:  eta -= Q e_prev
     }
@@ -708,7 +726,7 @@ DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, 
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int c = a; c < D; ++c)
-      Dm(a, c) = ((a == c) ? dbase + w : 0.0) + mN * p.a_fix[Sym<D>::idx(a, c)] + mP * p.q_fix[Sym<D>::idx(a, c)];
+      Dm(a, c) = gp_nz<D>(a, c) ? ((a == c) ? dbase + w : 0.0) + mN * p.a_fix[Sym<D>::idx(a, c)] + mP * p.q_fix[Sym<D>::idx(a, c)] : 0.0;
 }
 
 // Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
@@ -971,12 +989,13 @@ struct Nbr {
   static constexpr bool kDpp = (LPT == 16) || (LPT == 32 && S >= 2);     // DPP path: missing neighbours read as 0
   static constexpr int kShift = (LPT == 32) ? S / 2 : S;                  // lane distance inside the DPP row
   Ctx& cx;
-  int src_lo, src_hi;
+  int src_lo, src_hi, src_par;
   DGP_HD Nbr(Ctx& c, int j) : cx(c) {
     const int lane = c.lane();
     const int base = lane & ~(LPT - 1);
     src_lo = (j >= S) ? base + row_to_lane<LPT>(j - S) : lane;
     src_hi = (j + S < LPT) ? base + row_to_lane<LPT>(j + S) : lane;
+    src_par = base + row_to_lane<LPT>((j ^ S) & (LPT - 1));
   }
   DGP_HD double lo(double v) const {
     if constexpr (kDpp) return cx.template row_from_lower<(kShift > 0 ? kShift : 1)>(v);
@@ -986,12 +1005,69 @@ struct Nbr {
     if constexpr (kDpp) return cx.template row_from_upper<(kShift > 0 ? kShift : 1)>(v);
     else return cx.fetch(v, src_hi);
   }
+  // value held by the lane that owns row j ^ S, for S = LPT / 2 (the only partner of row j in the last PCR round):
+  // with the DPP mappings that lane is 8 positions away inside the 16-lane row in either direction -> one row rotate
+  DGP_HD double partner(double v) const {
+    static_assert(2 * S == LPT || S == 1, "partner() is for the last round");
+    if constexpr (kDpp) return cx.row_rotate8(v);
+    else return cx.fetch(v, src_par);
+  }
 };
+
+// The LAST round (S = LPT / 2): row i has exactly one partner, row i ^ S -- rows i < S couple to it through their own U
+// (block (i, i+S)), rows i >= S through the partner's U transposed (block (i, i-S) = U_{i-S}^T) and their own U is zero.
+// So K = U_i + U_partner^T (one of the two terms is zero) and one elimination  D_i -= K D_p^-1 K^T,  r_i -= K D_p^-1 r_p
+// replaces the two half-empty ones of the generic round; no coupling survives.
+template <int D, int LPT, int S, typename Ctx>
+DGP_HD void pcr_last_round(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], bool& ok) {
+  const Nbr<LPT, S, Ctx> nb(cx, i);
+  Sym<D> Di, DiP;
+  sym_inverse<D>(Dm, Di, ok);
+  double rP[D];
+  Mat<D> K;
+#pragma unroll
+  for (int k = 0; k < D * (D + 1) / 2; ++k) DiP.v[k] = nb.partner(Di.v[k]);
+#pragma unroll
+  for (int a = 0; a < D; ++a) rP[a] = nb.partner(r[a]);
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) K.v[c][a] = nb.partner(U.v[a][c]);            // U_partner^T
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) K.v[a][c] += U.v[a][c];
+  double T[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t += K.v[a][k] * DiP(k, c);
+      T[a][c] = t;
+    }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = r[a];
+#pragma unroll
+    for (int k = 0; k < D; ++k) t -= T[a][k] * rP[k];
+    r[a] = t;
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double w = Dm(a, c);
+#pragma unroll
+      for (int k = 0; k < D; ++k) w -= T[a][k] * K.v[c][k];
+      Dm(a, c) = w;
+    }
+  }
+}
 
 // one PCR round at stride S
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], bool& ok) {
   constexpr bool last = (2 * S >= LPT);
+  if constexpr (last && LPT >= 2) { pcr_last_round<D, LPT, S>(cx, i, Dm, U, r, ok); return; }
   const Nbr<LPT, S, Ctx> nb(cx, i);
   Sym<D> Di;
   sym_inverse<D>(Dm, Di, ok);
@@ -1101,7 +1177,9 @@ DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], dou
   if constexpr (LPT > 8) pcr_round<D, LPT, 8>(cx, i, Dm, U, r, ok);
   if constexpr (LPT > 16) pcr_round<D, LPT, 16>(cx, i, Dm, U, r, ok);
   if constexpr (LPT > 32) pcr_round<D, LPT, 32>(cx, i, Dm, U, r, ok);
-  sym_solve<D>(Dm, r, x, ok);
+  Sym<D> Di;
+  sym_inverse<D>(Dm, Di, ok);                   // (block inverse: two reciprocals deep, against d sequential pivots of a solve)
+  sym_times_vec<D>(Di, r, x);
 }
 
 // sum over the LPT lanes of one trajectory (butterfly); every lane gets the total
@@ -1138,8 +1216,9 @@ DGP_HD int group_or(Ctx& cx, int v) {
 // ---------------------------------------------------------------------------------------------------
 // The coupling blocks U_k (block (k, k+1)) of the rows a lane owns, in two representations:
 //   generic (QSTAT = false): one d x d block per row, already zero where row k has no successor;
-//   static  (QSTAT = true) : U_k = m_k * p.u_fix with a 0/1 mask per row -- nothing but the masks is kept in vector
-//                            registers, the block itself is a scalar operand.
+//   static  (QSTAT = true) : static covariances with a diagonal Q_c_inv.  U_k = m_k * p.u_fix with a 0/1 mask per row --
+//                            nothing but the masks is kept in vector registers, the block itself is a scalar operand and
+//                            its structural zeros (gp_nz) are skipped.
 // ---------------------------------------------------------------------------------------------------
 template <int D, int N, bool QSTAT> struct Coupling;
 template <int D, int N> struct Coupling<D, N, false> { Mat<D> u[N]; };
@@ -1161,7 +1240,7 @@ DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k,
     for (int c = 0; c < D; ++c) {
       double t = 0.0;
 #pragma unroll
-      for (int q = 0; q < D; ++q) t += Sm(a, q) * p.u_fix[q * D + c];
+      for (int q = 0; q < D; ++q) if (gp_nz<D>(q, c)) t += Sm(a, q) * p.u_fix[q * D + c];
       G.v[a][c] = t;
     }
 }
@@ -1178,7 +1257,7 @@ DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int
     for (int c = a; c < D; ++c) {
       double t = S(a, c);
 #pragma unroll
-      for (int q = 0; q < D; ++q) t -= p.u_fix[q * D + a] * B.v[q][c];
+      for (int q = 0; q < D; ++q) if (gp_nz<D>(q, a)) t -= p.u_fix[q * D + a] * B.v[q][c];
       S(a, c) = t;
     }
 }
@@ -1193,7 +1272,7 @@ DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int
   for (int a = 0; a < D; ++a) {
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < D; ++q) t += p.u_fix[q * D + a] * v[q];
+    for (int q = 0; q < D; ++q) if (gp_nz<D>(q, a)) t += p.u_fix[q * D + a] * v[q];
     o[a] -= cp.m[k] * t;
   }
 }
@@ -1208,7 +1287,7 @@ DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int 
   for (int a = 0; a < D; ++a) {
     double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < D; ++q) t += p.u_fix[a * D + q] * v[q];
+    for (int q = 0; q < D; ++q) if (gp_nz<D>(a, q)) t += p.u_fix[a * D + q] * v[q];
     o[a] -= cp.m[k] * t;
   }
 }
@@ -1220,7 +1299,7 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, M
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
-    for (int c = 0; c < D; ++c) U.v[a][c] = cp.m[k] * p.u_fix[a * D + c];
+    for (int c = 0; c < D; ++c) U.v[a][c] = gp_nz<D>(a, c) ? cp.m[k] * p.u_fix[a * D + c] : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1232,9 +1311,10 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, M
 //         z_k = r_k - G_{k-1}^T z_{k-1},   Zl_0 = L_0 = U_{-1}^T,   Zl_k = -G_{k-1}^T Zl_{k-1}
 //     i.e.  x_k = S_k^-1 (z_k - Zl_k x_ps) - G_k x_{k+1}     (x_ps = last row of the previous lane).
 //  b. STREAMED with a.: the first interior unknown as an affine function of the two neighbouring SEPARATOR unknowns
-//         x_0 = P_0 - V_0 x_ps - W_0 x_s,     (x_s = last row of this lane)
-//         P_0 = sum_k Pi_k S_k^-1 z_k,  V_0 = sum_k Pi_k S_k^-1 Zl_k,  W_0 = Pi_{C-2} G_{C-2},  Pi_0 = I, Pi_{k+1} = -Pi_k G_k
-//     so that only running products stay live, not G_k / Zl_k of every row;
+//         x_0 = P_0 - N_0 L_0 x_ps - W_0 x_s,     (x_s = last row of this lane)
+//         P_0 = sum_k Pi_k S_k^-1 z_k,  N_0 = sum_k Pi_k S_k^-1 Pi_k^T,  W_0 = Pi_{C-2} G_{C-2},  Pi_0 = I, Pi_{k+1} = -Pi_k G_k
+//     (Zl_k = Pi_k^T L_0, so the spike never has to be formed: N_0 is the SYMMETRIC (0,0) block of the inverse of the
+//     interior system, and only running products stay live, not G_k / Zl_k of every row);
 //  c. the lane's separator row, with x_{C-2} (own interior; its relation is the last line of a.) and x'_0 (first
 //     interior row of the NEXT lane, whose P'_0, V'_0, W'_0 are fetched across lanes) substituted, is one row of a
 //     block-tridiagonal system over the LPT lanes -> block PCR (log2 LPT rounds) gives x_s;
@@ -1311,7 +1391,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   Mat<D> L0;                     // generic path: left spike seed L_0; static path: L_0 = m_prev0 * p.u_fix^T
   double m_prev0 = 0.0;
   // running quantities of the streamed elimination
-  Mat<D> G, Zl, Pi, V0, W0;
+  Mat<D> G, Pi, W0;
+  Sym<D> N0;
   double P0[D], Pl[D];
 
   // assemble one row (D_k, r_k; U_k goes into cp)
@@ -1340,14 +1421,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     Sym<D> Dk; double rk[D];
     assemble(k, (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Dk, rk);
     if (k == 0) {
-      // left spike Zl_0 = L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
+      // left spike L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
       const bool has_prev = traj_ok && g0 > 0 && g0 < n;
       if constexpr (QSTAT) {
         m_prev0 = has_prev ? 1.0 : 0.0;
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int c = 0; c < D; ++c) Zl.v[a][c] = m_prev0 * p.u_fix[c * D + a];
       } else {
 #pragma unroll
         for (int a = 0; a < D; ++a)
@@ -1356,7 +1433,6 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
             L0.v[a][c] = has_prev ? -Qm(a, c) : 0.0;
             L0.v[a][DOF + c] = has_prev ? -(p.dt * Qm(a, c) + Qm(a, DOF + c)) : 0.0;
           }
-        Zl = L0;
       }
 #pragma unroll
       for (int a = 0; a < D; ++a) z[0][a] = rk[a];
@@ -1365,20 +1441,12 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
       for (int a = 0; a < D; ++a) z[k][a] = rk[a];
       sub_At_v<D>(z[k], G, z[k > 0 ? k - 1 : 0]);          // z_k = r_k - G_{k-1}^T z_{k-1}
-      Mat<D> T;
-      neg_At_B<D>(G, Zl, T);                               // Zl_k = -G_{k-1}^T Zl_{k-1}
-      Zl = T;
     }
     sym_inverse<D>(Dk, Sinv[k], ok);
-    double y[D];
-    Mat<D> Y;
-    sym_times_vec<D>(Sinv[k], z[k], y);                    // y_k = S_k^-1 z_k
-    sym_times_mat<D>(Sinv[k], Zl, Y);                      // Y_k = S_k^-1 Zl_k
     coup_SinvU<D, C>(p, cp, k, Sinv[k], G);                // G_k = S_k^-1 U_k
     if (k == 0) {
-#pragma unroll
-      for (int a = 0; a < D; ++a) P0[a] = y[a];
-      V0 = Y;
+      N0 = Sinv[0];                                        // N_0 = Pi_0 S_0^-1 Pi_0^T, Pi_0 = I
+      sym_times_vec<D>(Sinv[0], z[0], P0);                 // P_0 = S_0^-1 z_0
       if (k == KL) {
         W0 = G;                                            // C == 2: W_0 = G_0
       } else {
@@ -1388,16 +1456,31 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
           for (int c = 0; c < D; ++c) Pi.v[a][c] = -G.v[a][c];       // Pi_1 = -G_0
       }
     } else {
-      add_A_v<D>(P0, Pi, y);                               // P_0 += Pi_k y_k
-      add_A_B<D>(V0, Pi, Y);                               // V_0 += Pi_k Y_k
+      Mat<D> Mk;                                           // M_k = Pi_k S_k^-1
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          double t = 0.0;
+#pragma unroll
+          for (int q = 0; q < D; ++q) t += Pi.v[a][q] * Sinv[k](q, c);
+          Mk.v[a][c] = t;
+        }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = a; c < D; ++c) {                      // N += M_k Pi_k^T  (symmetric)
+          double t = N0(a, c);
+#pragma unroll
+          for (int q = 0; q < D; ++q) t += Mk.v[a][q] * Pi.v[c][q];
+          N0(a, c) = t;
+        }
+      add_A_v<D>(P0, Mk, z[k]);                            // P_0 += Pi_k S_k^-1 z_k
       Mat<D> T;
       if (k == KL) { A_B<D>(Pi, G, T); W0 = T; }           // W_0 = Pi_{C-2} G_{C-2}
       else { neg_A_B<D>(Pi, G, T); Pi = T; }               // Pi_{k+1} = -Pi_k G_k
     }
-    if (k == KL) {
-#pragma unroll
-      for (int a = 0; a < D; ++a) Pl[a] = y[a];            // P_{C-2} = y_{C-2}  (x_{C-2} = y - Y x_ps - G x_s)
-    }
+    if (k == KL) sym_times_vec<D>(Sinv[k], z[k], Pl);      // P_{C-2} = S^-1 z_{C-2}   (x_{C-2} = P - (..) x_ps - G x_s)
     if (!QSTAT && !stat) Qm = Qown;
   }
   // ---- c. separator row -> reduced system row
@@ -1407,16 +1490,36 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   if (C > 1) {
     coup_sub_UtB_sym<D, C>(p, cp, KL, Ds, G);             // D_s -= U_{C-2}^T W_{C-2},  W_{C-2} = G_{C-2}
     coup_sub_Ut_v<D, C>(p, cp, KL, rs, Pl);               // r_s -= U_{C-2}^T P_{C-2}
-    // first interior row of the next lane
-    Mat<D> Vn, Wn; double Pn[D];
+    // first interior row of the next lane: x'_0 = P'_0 - N'_0 L'_0 x_s - W'_0 x'_s, and L'_0 = U_s^T
+    Sym<D> Nn; Mat<D> Wn; double Pn[D];
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; ++i) Nn.v[i] = nb.hi(N0.v[i]);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       Pn[a] = nb.hi(P0[a]);
 #pragma unroll
-      for (int c = 0; c < D; ++c) { Vn.v[a][c] = nb.hi(V0.v[a][c]); Wn.v[a][c] = nb.hi(W0.v[a][c]); }
+      for (int c = 0; c < D; ++c) Wn.v[a][c] = nb.hi(W0.v[a][c]);
     }
     // (Us == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
-    sub_A_B_sym<D>(Ds, Us, Vn);                           // D_s -= U_s V'_0
+    Mat<D> T;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c < D; ++c) {                        // T = U_s N'_0
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) t += Us.v[a][q] * Nn(q, c);
+        T.v[a][c] = t;
+      }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = a; c < D; ++c) {                        // D_s -= U_s N'_0 U_s^T
+        double t = Ds(a, c);
+#pragma unroll
+        for (int q = 0; q < D; ++q) t -= T.v[a][q] * Us.v[c][q];
+        Ds(a, c) = t;
+      }
     sub_A_v<D>(rs, Us, Pn);                               // r_s -= U_s P'_0
     Mat<D> Ur;
     neg_A_B<D>(Us, Wn, Ur);                               // U_red = -U_s W'_0
@@ -1456,7 +1559,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       for (int a = 0; a < D; ++a) {
         double t = 0.0;
 #pragma unroll
-        for (int c = 0; c < D; ++c) t += p.u_fix[c * D + a] * xps[c];
+        for (int c = 0; c < D; ++c) if (gp_nz<D>(c, a)) t += p.u_fix[c * D + a] * xps[c];
         w[a] = m_prev0 * t;
       }
     } else {

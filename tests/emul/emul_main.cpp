@@ -60,6 +60,13 @@ struct HostCtx {
     pthread_barrier_wait(&ws->bar);
     return r;
   }
+  double row_rotate8(double v) {      // DPP row_ror:8 -- the lane 8 positions away inside the 16-lane row
+    ws->slot[lane_] = v;
+    pthread_barrier_wait(&ws->bar);
+    double r = ws->slot[(lane_ & ~15) | ((lane_ + 8) & 15)];
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
   bool any(bool pred) {
     ws->islot[lane_] = pred ? 1 : 0;
     pthread_barrier_wait(&ws->bar);
@@ -84,7 +91,7 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
     th.emplace_back([&, l]() {
       HostCtx cx{&ws, l, wave};
       // same dispatch as dgp_dev::launch_typed: static covariances run the QSTAT specialisation
-      const bool qstat = (p.qc_mode == dgp::QC_STATIC);
+      const bool qstat = dgp::use_static_kernels(p);
       if (mode == dgp::MODE_STEP) {
         if (qstat) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, true>(p, cx);
         else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, false>(p, cx);

@@ -372,5 +372,26 @@ def case_tiny_and_odd_sizes(be, golden, io):
   assert np.array_equal(d0[keep], d1[keep]) and np.all(np.isnan(d1[2]))
 
 
+def case_static_qc_variants(be, golden, io):
+  """Static covariances with (a) a diagonal, non-identity Q_c_inv -- the static kernels with unequal per-dof weights --
+  and (b) a full symmetric Q_c_inv, which the static kernels do not cover (they skip the structural zeros of a diagonal
+  Q_c_inv) and which must therefore run the generic kernels; dof 2 and 3, ragged n."""
+  rs = np.random.RandomState(21)
+  for dof, n, B, Qc in ((2, 24, 5, np.diag([0.7, 2.5])), (2, 24, 5, np.array([[1.5, 0.4], [0.4, 0.8]])),
+                        (3, 13, 3, np.diag([0.5, 1.0, 3.0])), (3, 13, 3, np.array([[1.2, 0.2, -0.1], [0.2, 0.9, 0.3], [-0.1, 0.3, 2.0]]))):
+    p = O.OracleParams(dof=dof, total_time_step=n - 1, Q_c_inv=Qc)
+    d = 2 * dof
+    start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+    start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+    th = np.zeros((B, n, d))
+    t = np.linspace(0, 1, n)[None, :, None]
+    th[:, :, :dof] = start[:, :, :dof] + t * (goal[:, :, :dof] - start[:, :, :dof])
+    th[:, :, dof:] = (goal[:, :, :dof] - start[:, :, :dof]) / 10.0
+    th = th + rs.randn(B, n, d) * 0.1
+    sdf = O.circles_sdf(96, O.C2_CIRCLES)[None, None]
+    check_step(be, p, th, start, goal, sdf, io, tag='static Qc dof=%d diag=%s' % (dof, bool(np.all(Qc == np.diag(np.diag(Qc))))))
+
+
+ALL_CASES.append(case_static_qc_variants)
 ALL_CASES.append(case_tiny_and_odd_sizes)
 ALL_CASES.append(case_shared_sdf_gradient_partial_copies)

@@ -71,12 +71,14 @@ def test_hip_c2_ten_iterations_reduce_error(be):
   tho, its, eh, eeh, ef, info = be.solve(p, th, start, goal, sdf, 10, 0.0, io='f64')
   assert np.all(its == 10) and np.all(info == 0)
   assert ef.mean() < 0.25 * eh[:, 0].mean()          # GN without line search: not monotone per trajectory, but converging overall
+  # the fused loop and the step kernel are separately compiled programs (different FMA contraction / operation order), and
+  # ten undamped GN iterations amplify that rounding noise: agreement is to the fp64 parity tolerance, not to the last bit
   cur = th.copy()
   for k in range(10):
     dth, err, _, _ = be.step(p, cur, start, goal, sdf, io='f64')
-    assert rel_err(err, eh[:, k]) < 1e-12
+    assert rel_err(err, eh[:, k]) < 1e-9
     cur = cur + dth
-  assert rel_err(cur, tho) < 1e-12
+  assert rel_err(cur, tho) < 1e-9
 
 
 @pytest.mark.parametrize('B,n', [(65537, 64), (1, 64), (3, 256), (1000, 101), (257, 7)])
