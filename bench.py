@@ -30,9 +30,9 @@ B_PER_GPU, N_STATES, DOF, GRID = 4096, 64, 2, 256
 GN_ITERS = 10
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (spec)
-# fp64 FMA/MUL/ADD instructions one wavefront of gn_kernel<DOF=2,LPT=16,C=4,STEP> executes (ISA histogram of the
+# fp64 FMA/MUL/ADD instructions one wavefront of gn_kernel<DOF=2,LPT=16,C=4,float,STEP,static> executes (ISA histogram of the
 # straight-line kernel); every one is a 64-lane operation, an FMA counting 2 flops
-FP64_VALU_INSTS_PER_WAVE_16x4 = {'fma': 3130, 'mul_add': 707}
+FP64_VALU_INSTS_PER_WAVE_16x4 = {'fma': 2488, 'mul_add': 525}
 
 
 def algorithmic_bytes_per_trajectory(n, d, nl=1, io_bytes=4):
@@ -228,7 +228,7 @@ def main():
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
         'trajectory_steps_per_s': world * args.steps * B / elapsed,
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(), 'kernel': 'gn_kernel<DOF=2,LPT=%d,C=%d,float,STEP>' % solver.launch_shape(B), 'kernel_avg_ms': kernel_ms,
+                     'traffic': measured_traffic(), 'kernel': 'gn_kernel<DOF=2,LPT=%d,C=%d,float,STEP,static>' % solver.launch_shape(B), 'kernel_avg_ms': kernel_ms,
                      'algorithmic_bytes_per_launch': bytes_per_launch,
                      'note': 'HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'},
         'valu_fp64': None if fp64_flops is None else {'achieved_tflops': fp64_flops / (kernel_ms * 1e-3) / 1e12, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,

@@ -1215,19 +1215,36 @@ DGP_HD int group_or(Ctx& cx, int v) {
 
 // ---------------------------------------------------------------------------------------------------
 // The coupling blocks U_k (block (k, k+1)) of the rows a lane owns, in two representations:
-//   generic (QSTAT = false): one d x d block per row, already zero where row k has no successor;
+//   generic (QSTAT = false): U_k = -m_k Phi^T Q_k with the row's symmetric Q_k^-1 (d(d+1)/2 values instead of d^2) and a
+//                            0/1 mask; products with U_k are formed from Q_k and the two-band Phi on the fly;
 //   static  (QSTAT = true) : static covariances with a diagonal Q_c_inv.  U_k = m_k * p.u_fix with a 0/1 mask per row --
 //                            nothing but the masks is kept in vector registers, the block itself is a scalar operand and
 //                            its structural zeros (gp_nz) are skipped.
 // ---------------------------------------------------------------------------------------------------
 template <int D, int N, bool QSTAT> struct Coupling;
-template <int D, int N> struct Coupling<D, N, false> { Mat<D> u[N]; };
+template <int D, int N> struct Coupling<D, N, false> { Sym<D> q[N]; double m[N]; double dt; };
 template <int D, int N> struct Coupling<D, N, true> { double m[N]; };
 
 // G = S^-1 U_k
 template <int D, int N>
 DGP_HD void coup_SinvU(const GnParams&, const Coupling<D, N, false>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
-  sym_times_mat<D>(Si, cp.u[k], G);
+  // S^-1 U = -m (S^-1 Phi^T) Q,   (S^-1 Phi^T)[a][c] = S^-1[a][c] + (c < dof ? dt S^-1[a][dof + c] : 0)
+  constexpr int DOF = D / 2;
+  double A[D][D];
+  const double nm = -cp.m[k];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) A[a][c] = nm * ((c < DOF) ? Si(a, c) + cp.dt * Si(a, DOF + c) : Si(a, c));
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) t += A[a][q] * cp.q[k](q, c);
+      G.v[a][c] = t;
+    }
 }
 template <int D, int N>
 DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
@@ -1247,7 +1264,22 @@ DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k,
 // S -= U_k^T B (symmetric result).  Static form: B is G_k = S_k^-1 U_k, which already carries the mask.
 template <int D, int N>
 DGP_HD void coup_sub_UtB_sym(const GnParams&, const Coupling<D, N, false>& cp, int k, Sym<D>& S, const Mat<D>& B) {
-  sub_At_B_sym<D>(S, cp.u[k], B);
+  // U^T B = -Q Phi B (B carries the mask):  S += Q (Phi B),  (Phi B)[a] = B[a] + dt B[dof + a] for a < dof
+  constexpr int DOF = D / 2;
+  double PB[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) PB[a][c] = (a < DOF) ? B.v[a][c] + cp.dt * B.v[DOF + a][c] : B.v[a][c];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double t = S(a, c);
+#pragma unroll
+      for (int q = 0; q < D; ++q) t += cp.q[k](a, q) * PB[q][c];
+      S(a, c) = t;
+    }
 }
 template <int D, int N>
 DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int, Sym<D>& S, const Mat<D>& B) {
@@ -1264,7 +1296,18 @@ DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int
 // o -= U_k^T v
 template <int D, int N>
 DGP_HD void coup_sub_Ut_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
-  sub_At_v<D>(o, cp.u[k], v);
+  // o -= U^T v = o + m Q (Phi v)
+  constexpr int DOF = D / 2;
+  double pv[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) pv[a] = (a < DOF) ? v[a] + cp.dt * v[DOF + a] : v[a];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) t += cp.q[k](a, q) * pv[q];
+    o[a] += cp.m[k] * t;
+  }
 }
 template <int D, int N>
 DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
@@ -1279,7 +1322,18 @@ DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int
 // o -= U_k v
 template <int D, int N>
 DGP_HD void coup_sub_U_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
-  sub_A_v<D>(o, cp.u[k], v);
+  // o -= U v = o + m Phi^T (Q v)
+  constexpr int DOF = D / 2;
+  double w[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) t += cp.q[k](a, q) * v[q];
+    w[a] = t;
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) o[a] += cp.m[k] * ((a < DOF) ? w[a] : cp.dt * w[a - DOF] + w[a]);
 }
 template <int D, int N>
 DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
@@ -1293,7 +1347,17 @@ DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int 
 }
 // the block itself, in vector registers (the separator row's coupling is PCR state)
 template <int D, int N>
-DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Mat<D>& U) { U = cp.u[k]; }
+DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Mat<D>& U) {
+  constexpr int DOF = D / 2;
+  const double nm = -cp.m[k];
+#pragma unroll
+  for (int a = 0; a < DOF; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      U.v[a][c] = nm * cp.q[k](a, c);
+      U.v[DOF + a][c] = nm * (cp.dt * cp.q[k](a, c) + cp.q[k](DOF + a, c));
+    }
+}
 template <int D, int N>
 DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, Mat<D>& U) {
 #pragma unroll
@@ -1378,18 +1442,20 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #endif
   const bool stat = (p.qc_mode == QC_STATIC);
   Sym<D> Qown, Qm;               // generic path: Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
+  Sym<D> Qm0;                    // generic path: Q^-1 of the factor into the lane's FIRST row (kept for the recovery)
   if (!QSTAT) {
     fixed_Qinv<DOF>(p, Qown);    // static covariances on the generic path: built once; per-state modes: reloaded per row
     fixed_Qinv<DOF>(p, Qm);
     if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
+    Qm0 = Qm;
   }
 
   // kept for the interior recovery (d.)
   Sym<D> Sinv[CI];
   double z[CI][D];
   Coupling<D, C, QSTAT> cp;      // U_k of all C rows
-  Mat<D> L0;                     // generic path: left spike seed L_0; static path: L_0 = m_prev0 * p.u_fix^T
-  double m_prev0 = 0.0;
+  if constexpr (!QSTAT) cp.dt = p.dt;
+  double m_prev0 = 0.0;          // L_0 = -m_prev0 Qm0 Phi  (static path: m_prev0 * p.u_fix^T)
   // running quantities of the streamed elimination
   Mat<D> G, Pi, W0;
   Sym<D> N0;
@@ -1406,8 +1472,11 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       eval_state_local<DOF, true>(p, x[k], lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, acc);
     } else {
       if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
+      Mat<D> Utmp;                                          // (eval_state's own U; the kept form is Q_k + mask)
       eval_state<DOF, IO, true>(p, b, g, valid, x[k], xm, xp, mu_s, mu_g, Qown, Qm, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k],
-                                Dk, cp.u[k], rk, acc);
+                                Dk, Utmp, rk, acc);
+      cp.q[k] = Qown;
+      cp.m[k] = (valid && g < n - 1) ? 1.0 : 0.0;
     }
     if (RHS_OVERRIDE) {
 #pragma unroll
@@ -1423,17 +1492,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     if (k == 0) {
       // left spike L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
       const bool has_prev = traj_ok && g0 > 0 && g0 < n;
-      if constexpr (QSTAT) {
-        m_prev0 = has_prev ? 1.0 : 0.0;
-      } else {
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-          for (int c = 0; c < DOF; ++c) {
-            L0.v[a][c] = has_prev ? -Qm(a, c) : 0.0;
-            L0.v[a][DOF + c] = has_prev ? -(p.dt * Qm(a, c) + Qm(a, DOF + c)) : 0.0;
-          }
-      }
+      m_prev0 = has_prev ? 1.0 : 0.0;
 #pragma unroll
       for (int a = 0; a < D; ++a) z[0][a] = rk[a];
     } else {
@@ -1563,9 +1622,17 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
         w[a] = m_prev0 * t;
       }
     } else {
+      // L_0 x_ps = -m_prev0 Qm0 (Phi x_ps)
+      double pv[D];
 #pragma unroll
-      for (int a = 0; a < D; ++a) w[a] = 0.0;
-      add_A_v<D>(w, L0, xps);
+      for (int a = 0; a < D; ++a) pv[a] = (a < DOF) ? xps[a] + p.dt * xps[DOF + a] : xps[a];
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) t += Qm0(a, c) * pv[c];
+        w[a] = -m_prev0 * t;
+      }
     }
 #pragma unroll
     for (int a = 0; a < D; ++a) q[0][a] = z[0][a] - w[a];
