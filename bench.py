@@ -211,6 +211,22 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+  # Beside the headline (one launch per GN step, the reference's step()): the same 10 GN iterations from th_init as ONE
+  # launch of the fused loop (the reference's forward(); dgp_gn_solve, tol 0 so that all 10 run) -- no launch gaps, th
+  # stays in registers, err / err_ext of every iteration written.  Reported as an extra field, never as `value`.
+  tho = torch.empty_like(th0); its = torch.zeros(B, dtype=torch.int32, device=device)
+  eh = torch.empty(B, GN_ITERS, device=device); eeh = torch.empty(B, GN_ITERS, device=device)
+  def run_fused(reps):
+    for _ in range(reps):
+      solver.gn_solve(B, th_ptrs[0], sp, gp, sdf_arg, None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(), eh.data_ptr(), eeh.data_ptr(),
+                      None, None, stream)
+  fused_reps = max(1, args.steps // GN_ITERS)
+  run_fused(max(1, args.warmup // GN_ITERS))
+  fe0 = torch.cuda.Event(enable_timing=True); fe1 = torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize(); fe0.record(); run_fused(fused_reps); fe1.record(); torch.cuda.synchronize()
+  fused_ms = fe0.elapsed_time(fe1) / fused_reps
+  assert int(its.min()) == GN_ITERS
+
   if rank == 0:
     bytes_per_launch = algorithmic_bytes_per_trajectory(n, d) * B
     achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
@@ -234,6 +250,9 @@ def main():
         'valu_fp64': None if fp64_flops is None else {'achieved_tflops': fp64_flops / (kernel_ms * 1e-3) / 1e12, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
                                                       'frac': fp64_flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 'flops_per_launch': fp64_flops},
     }
+    out['fused_forward'] = {'gn_iterations_per_launch': GN_ITERS, 'ms_per_launch': fused_ms, 'us_per_gn_iteration': 1e3 * fused_ms / GN_ITERS,
+                            'gn_steps_per_s_per_gpu': GN_ITERS / (fused_ms * 1e-3),
+                            'note': 'dgp_gn_solve: the 10 GN iterations of BASELINE configs[1] in one launch (rank 0, outside the timed region)'}
     if world == 1 and not args.no_cpu_baseline:
       hist_cpu = [t.cpu() for t in th_hist]
       out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())

@@ -147,6 +147,7 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   p.w_v = (cfg->flags & DGP_FLAG_VEL_LIMITS) ? 1.0 / pow(cfg->K_v, 2.0) : 0.0;
   p.vmax[0] = cfg->v_x; p.vmax[1] = cfg->v_y;
   p.M = (double)h->M;
+  p.inv_M = 1.0 / p.M;
   fill_static_blocks(p, dof);
   *out = h;
   return DGP_OK;

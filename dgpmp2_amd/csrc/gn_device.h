@@ -35,11 +35,12 @@ struct DevCtx {
     hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + S, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   }
-  // value of the lane 8 positions away inside the 16-lane DPP row (row_ror:8 -- the two halves of the row swap)
-  __device__ __forceinline__ double row_rotate8(double v) const {
+  // value of the lane N positions below (cyclically) inside the 16-lane DPP row (row_ror:N; N = 8 swaps the two halves)
+  template <int N>
+  __device__ __forceinline__ double row_rotate(double v) const {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, true);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
   }
   __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }

@@ -31,6 +31,28 @@
 #define DGP_HD __host__ __device__ __forceinline__
 #endif
 
+// profiles/tools/phase_probe.hip -DDGP_PHASE_STAMPS: lane 0 of every wavefront writes s_memrealtime (100 MHz) at a few
+// points of the program into the buffer smuggled in through GnParams::err_hist (unused by MODE_STEP).  Never in the product.
+#if defined(DGP_PHASE_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define DGP_STAMP(p, cx, slot)                                                                                          \
+  do {                                                                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                   \
+    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 8 + (slot)] = t_;  \
+  } while (0)
+#define DGP_STAMP_NOWAIT(p, cx, slot)                                                                                   \
+  do {                                                                                                                 \
+    const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                   \
+    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 8 + (slot)] = t_;  \
+  } while (0)
+#elif defined(DGP_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)      // "; DGPMARK n" comments in the ISA at the same points
+#define DGP_STAMP(p, cx, slot) asm volatile("; DGPMARK " #slot ::: "memory")
+#define DGP_STAMP_NOWAIT(p, cx, slot) asm volatile("; DGPMARK " #slot ::: "memory")
+#else
+#define DGP_STAMP(p, cx, slot) ((void)0)
+#define DGP_STAMP_NOWAIT(p, cx, slot) ((void)0)
+#endif
+
 namespace dgp {
 
 enum { MODE_STEP = 0, MODE_SOLVE = 1, MODE_EVAL = 2 };
@@ -68,7 +90,7 @@ struct GnParams {
   double res, orig_px, orig_py;   // sdf_utils.py:57-58, obstacle_cost.py:34
   double inv_res;                 // 1 / res, correctly rounded (host division)
   double w_d, w_v, vmax[2];  // 1/K_d^2, 1/K_v^2, (v_x, v_y)
-  double M;                  // plan_layer.py:43-45
+  double M, inv_M;           // plan_layer.py:43-45; 1 / M correctly rounded
   double tol_delta;
   // Static covariances (qc_mode == QC_STATIC): the three constant blocks every GP factor contributes, precomputed on the
   // host from (dt, Q_c_inv) so that the kernels read them as scalar (SGPR) operands instead of holding them in vector
@@ -376,25 +398,32 @@ DGP_HD double div_res(const GnParams& p, double a) {
   const double r = __builtin_fma(-q0, p.res, a);
   return __builtin_fma(r, p.inv_res, q0);
 }
+// a / M the same way (err, err_ext normalisation, plan_layer.py:308,345)
+DGP_HD double div_M(const GnParams& p, double a) {
+  const double q0 = a * p.inv_M;
+  const double r = __builtin_fma(-q0, p.M, a);
+  return __builtin_fma(r, p.inv_M, q0);
+}
+
+DGP_HD int32_t imin32(int32_t a, int32_t b) { return a < b ? a : b; }
+DGP_HD int32_t imax32(int32_t a, int32_t b) { return a > b ? a : b; }
 
 DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
 #pragma clang fp contract(off)
   o.px = p.orig_px + div_res(p, x);                       // :61   orig + x / res
   o.py = p.orig_py - div_res(p, y);                       // :62
   double fpx = floor(o.px), fpy = floor(o.py);
-  // floor -> int64 -> clamp (:64-72); saturate first so that huge |px| cannot overflow the conversion
+  // floor -> int64 -> clamp (:64-72); saturate first so that huge |px| cannot overflow the conversion.  fmax / fmin return
+  // the non-NaN operand, so NaN coordinates land on an in-range index too (the interpolated result is NaN anyway).
   const double big = 1.0e9;                               // |floor| <= 1e9 fits int32 and int32 + 1 does not overflow
-  double cx = fpx < -big ? -big : (fpx > big ? big : fpx);
-  double cy = fpy < -big ? -big : (fpy > big ? big : fpy);
-  if (!(cx == cx)) cx = 0.0;                              // NaN coordinates: any in-range index (the result is NaN anyway)
-  if (!(cy == cy)) cy = 0.0;
-  int32_t x1 = (int32_t)cx, y1 = (int32_t)cy;
-  int32_t x2 = x1 + 1, y2 = y1 + 1;                       // :65,67 (before clamping)
-  const int32_t W = p.sdf_cols, H = p.sdf_rows;
-  o.x1 = x1 < 0 ? 0 : (x1 > W - 1 ? W - 1 : x1);
-  o.x2 = x2 < 0 ? 0 : (x2 > W - 1 ? W - 1 : x2);
-  o.y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
-  o.y2 = y2 < 0 ? 0 : (y2 > H - 1 ? H - 1 : y2);
+  const double cx = fmin(fmax(fpx, -big), big), cy = fmin(fmax(fpy, -big), big);
+  const int32_t x1 = (int32_t)cx, y1 = (int32_t)cy;
+  const int32_t x2 = x1 + 1, y2 = y1 + 1;                 // :65,67 (before clamping)
+  const int32_t W1 = p.sdf_cols - 1, H1 = p.sdf_rows - 1;
+  o.x1 = imax32(0, imin32(x1, W1));
+  o.x2 = imax32(0, imin32(x2, W1));
+  o.y1 = imax32(0, imin32(y1, H1));
+  o.y2 = imax32(0, imin32(y2, H1));
 }
 
 // Phase 2 (utils/sdf_utils.py:81-94, obstacle_cost.py:30,36-37): weights, distance, gradient, hinge -- bit-for-bit the
@@ -1009,7 +1038,7 @@ struct Nbr {
   // with the DPP mappings that lane is 8 positions away inside the 16-lane row in either direction -> one row rotate
   DGP_HD double partner(double v) const {
     static_assert(2 * S == LPT || S == 1, "partner() is for the last round");
-    if constexpr (kDpp) return cx.row_rotate8(v);
+    if constexpr (kDpp) return cx.template row_rotate<8>(v);
     else return cx.fetch(v, src_par);
   }
 };
@@ -1185,10 +1214,18 @@ DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], dou
 // sum over the LPT lanes of one trajectory (butterfly); every lane gets the total
 template <int LPT, typename Ctx>
 DGP_HD double group_sum(Ctx& cx, double v) {
-  const int lane = cx.lane();
+  if constexpr (LPT == 16) {       // the group is one DPP row: four row rotations, no LDS round trips
+    v += cx.template row_rotate<8>(v);
+    v += cx.template row_rotate<4>(v);
+    v += cx.template row_rotate<2>(v);
+    v += cx.template row_rotate<1>(v);
+    return v;
+  } else {
+    const int lane = cx.lane();
 #pragma unroll
-  for (int m = LPT / 2; m >= 1; m >>= 1) v += cx.fetch(v, lane ^ m);
-  return v;
+    for (int m = LPT / 2; m >= 1; m >>= 1) v += cx.fetch(v, lane ^ m);
+    return v;
+  }
 }
 // sum over the LPT lanes of one trajectory, valid in the FIRST lane of the group only (that is where err / err_ext are
 // written from).  With 16 lanes per trajectory it is four DPP row shifts + adds, no LDS round trips.
@@ -1410,18 +1447,15 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
     if constexpr (QSTAT) {
-      // (the copies xa are tied to the tap ADDRESSES, so that the loads are issued before this arithmetic starts)
-      double xa[C][D];
+      // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
+      double mu_ga[D];
 #pragma unroll
-      for (int k = 0; k < C; ++k) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) xa[k][a] = x[k][a];
-        lane_after_addresses<C, IO, D>(taps, xa[k]);
-      }
+      for (int a = 0; a < D; ++a) mu_ga[a] = mu_g[a];
+      lane_after_addresses<C, IO, D>(taps, mu_ga);
 #pragma unroll
       for (int k = 0; k < C; ++k)
-        static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, xa[k], (k == 0) ? x_prev : xa[k > 0 ? k - 1 : 0],
-                        (k == C - 1) ? x_next : xa[k < C - 1 ? k + 1 : 0], mu_s, mu_g, rgp[k], acc);
+        static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0],
+                        (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0], mu_s, mu_ga, rgp[k], acc);
       // first components of every row's eta (each is the end of that row's dependency chain)
       double anchor[2 * C];
 #pragma unroll
@@ -1430,6 +1464,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     }
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
+  DGP_STAMP_NOWAIT(p, cx, 2);
 #if defined(DGP_PHASE_STOP)     // profiles/tools/phase_probe.hip: cut the program short after a phase (timing aid, never in the product build)
   if (DGP_PHASE_STOP == 1 || DGP_PHASE_STOP == 2) {
 #pragma unroll
@@ -1593,6 +1628,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     return;
   }
 #endif
+  DGP_STAMP_NOWAIT(p, cx, 3);
   double xs[D];
   pcr_solve<D, LPT>(cx, j, Ds, Us, rs, xs, ok);
 #pragma unroll
@@ -1696,12 +1732,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
   const bool traj_ok = b < p.B;
+  DGP_STAMP_NOWAIT(p, cx, 0);
 
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];
   load_lane_rows<DOF, C, IO>(p, p.th, b, j * C, traj_ok, vec, x);
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
+  DGP_STAMP(p, cx, 1);
 
   if (MODE == MODE_EVAL) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1710,8 +1748,8 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     const double usg = group_sum_to_first<LPT>(cx, acc.usg), ugp = group_sum_to_first<LPT>(cx, acc.ugp);
     const double uobs = group_sum_to_first<LPT>(cx, acc.uobs);
     if (traj_ok && j == 0) {
-      if (p.err) st<IO>(p.err, b, e / p.M);
-      if (p.err_ext) st<IO>(p.err_ext, b, ee / p.M);
+      if (p.err) st<IO>(p.err, b, div_M(p, e));
+      if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
       if (p.unw_sg) st<IO>(p.unw_sg, b, usg);
       if (p.unw_gp) st<IO>(p.unw_gp, b, ugp / (double)(n - 1));     // torch.mean over the n-1 factors
       if (p.unw_obs) st<IO>(p.unw_obs, b, uobs / (double)n);
@@ -1729,6 +1767,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     double dx[C][D];
     bool ok = true;
     gn_linear_solve<DOF, LPT, C, IO, false, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
+    DGP_STAMP_NOWAIT(p, cx, 4);
     const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
@@ -1738,8 +1777,8 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
       }
       if (traj_ok && j == 0) {
-        if (p.err) st<IO>(p.err, b, e / p.M);
-        if (p.err_ext) st<IO>(p.err_ext, b, ee / p.M);
+        if (p.err) st<IO>(p.err, b, div_M(p, e));
+        if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
       }
     } else {
       double s2 = 0.0;
@@ -1750,8 +1789,8 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       s2 = group_sum<LPT>(cx, s2);
       if (active) {
         if (j == 0) {
-          if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, e / p.M);
-          if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, ee / p.M);
+          if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));
+          if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, div_M(p, ee));
         }
 #pragma unroll
         for (int k = 0; k < C; ++k)
@@ -1763,8 +1802,12 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       if (!cx.any(active)) break;
     }
   }
-  bad = group_or<LPT>(cx, bad);
-  if (p.info && traj_ok && j == 0) p.info[b] = bad;
+  DGP_STAMP_NOWAIT(p, cx, 5);
+  if (p.info) {                                        // (wave-uniform: the reduction is skipped when nobody asked)
+    bad = group_or<LPT>(cx, bad);
+    if (traj_ok && j == 0) p.info[b] = bad;
+  }
+  DGP_STAMP(p, cx, 6);
   if (MODE == MODE_SOLVE) {
 #pragma unroll
     for (int k = 0; k < C; ++k) {
@@ -1776,7 +1819,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
       gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
       const double e = group_sum_to_first<LPT>(cx, acc.e);
-      if (traj_ok && j == 0) st<IO>(p.err_final, b, e / p.M);
+      if (traj_ok && j == 0) st<IO>(p.err_final, b, div_M(p, e));
     }
   }
 }

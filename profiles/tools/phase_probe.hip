@@ -10,6 +10,7 @@
 #include "gn_device.h"
 #include <vector>
 #include <random>
+#include <algorithm>
 
 int main(int argc, char** argv) {
   const int B = argc > 1 ? atoi(argv[1]) : 4096, n = 64, G = 256;
@@ -75,6 +76,32 @@ int main(int argc, char** argv) {
     float gms; hipEventElapsedTime(&gms, e0, e1);
     printf("hipGraph replay : %.2f us/launch\n", gms * 1e3 / 500);
   }
+#if defined(DGP_PHASE_STAMPS)
+  {  // in-kernel timeline: two consecutive launches in the middle of a back-to-back series write their stamps
+    const int waves = (B + 3) / 4;
+    unsigned long long *d_s0, *d_s1;
+    hipMalloc(&d_s0, (size_t)waves * 64); hipMalloc(&d_s1, (size_t)waves * 64);
+    dgp::GnParams p0 = p, p1 = p;
+    p0.err_hist = d_s0; p1.err_hist = d_s1;
+    for (int i = 0; i < 400; ++i) {
+      const dgp::GnParams& q = (i == 200) ? p0 : ((i == 201) ? p1 : p);
+      hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, q);
+    }
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> s0((size_t)waves * 8), s1((size_t)waves * 8);
+    hipMemcpy(s0.data(), d_s0, s0.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(s1.data(), d_s1, s1.size() * 8, hipMemcpyDeviceToHost);
+    const char* names[7] = {"entry", "th/start/goal loaded", "taps + factors done", "local elimination done", "PCR + recovery done", "stores issued", "stores acked"};
+    unsigned long long first0 = ~0ull, last0 = 0, first1 = ~0ull;
+    for (int w = 0; w < waves; ++w) { first0 = std::min(first0, s0[w * 8]); last0 = std::max(last0, s0[w * 8 + 6]); first1 = std::min(first1, s1[w * 8]); }
+    printf("launch k: first entry -> last ack %.2f us;  gap to first entry of launch k+1: %.2f us\n", (last0 - first0) * 0.01, ((double)first1 - (double)last0) * 0.01);
+    for (int sl = 0; sl < 7; ++sl) {
+      std::vector<double> v;
+      for (int w = 0; w < waves; ++w) v.push_back((s0[w * 8 + sl] - first0) * 0.01);
+      std::sort(v.begin(), v.end());
+      printf("  %-24s min %5.2f  median %5.2f  max %5.2f us after the first wavefront's entry\n", names[sl], v.front(), v[v.size() / 2], v.back());
+    }
+  }
+#endif
   std::vector<float> out(16);
   hipMemcpy(out.data(), d_dth, 64, hipMemcpyDeviceToHost);
   printf("stop_after=%d  B=%d  %.2f us/launch   (dtheta[0..3] = %g %g %g %g)\n", PROBE_STOP, B, ms * 1e3 / reps, out[0], out[1], out[2], out[3]);

@@ -60,10 +60,11 @@ struct HostCtx {
     pthread_barrier_wait(&ws->bar);
     return r;
   }
-  double row_rotate8(double v) {      // DPP row_ror:8 -- the lane 8 positions away inside the 16-lane row
+  template <int N>
+  double row_rotate(double v) {       // DPP row_ror:N -- lane i reads lane (i - N) mod 16 of its 16-lane row
     ws->slot[lane_] = v;
     pthread_barrier_wait(&ws->bar);
-    double r = ws->slot[(lane_ & ~15) | ((lane_ + 8) & 15)];
+    double r = ws->slot[(lane_ & ~15) | ((lane_ - N) & 15)];
     pthread_barrier_wait(&ws->bar);
     return r;
   }
