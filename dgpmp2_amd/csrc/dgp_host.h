@@ -42,26 +42,28 @@ inline int fail(int code, const char* fmt, ...) {
 constexpr int kMaxStates = 256;
 inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || lpt == 64) && (c == 1 || c == 2 || c == 4); }
 
-// Pick (LPT, C) for n states and a batch of B trajectories.  More states per lane (larger C) means less arithmetic per
-// trajectory (the local elimination is O(C) per lane while every PCR round costs the same whatever LPT is) but fewer
-// wavefronts; MI355X has 1024 SIMDs, so C grows only while the launch still has about one wavefront per SIMD.
+// Pick (LPT, C) for n states and a batch of B trajectories: the cheapest supported shape under a two-parameter timing model
+// fitted to profiles/tools/shape_grid.py on MI355X (static-covariance kernels, steady clocks):
+//   time(shape, B) ~ fixed + T[shape] * max(1, 1.25 * wavefronts / 1024)
+// T = per-wavefront time in us when every wavefront has a SIMD to itself (B = 256 column of the grid); a launch with more
+// wavefronts than the chip has SIMDs (1024) runs them in turns and each then costs ~1.25 T (shared LDS crossbar / L2).
+// More states per lane (larger C) means less arithmetic per trajectory (the local elimination is O(C) per lane while
+// every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6: the measured ratios to d = 4 --
+// x3.8, and x7.2 for the C = 4 kernels, which no longer fit the register file.
 inline DgpShape choose_shape(const DgpHandle* h, int B) {
   if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
+  static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
   const int n = h->cfg.num_states;
   DgpShape best{64, 4};
   double best_cost = 1e300;
-  // d = 6 blocks: four states per lane do not fit the 512-register budget (measured: C=4 spills ~1200 dwords and is 1.6x
-  // slower than C=2 at B=4096), so C is capped at 2 whenever that still covers n
-  const int c_max = (h->cfg.dof == 3 && 64 * 2 >= n) ? 2 : 4;
-  for (int c = 1; c <= c_max; c *= 2)
-    for (int lpt = 16; lpt <= 64; lpt *= 2) {
+  for (int li = 0; li < 3; ++li)
+    for (int ci = 0; ci < 3; ++ci) {
+      const int lpt = 16 << li, c = 1 << ci;
       if (lpt * c < n) continue;
-      int rounds = 0;
-      for (int s = 1; s < lpt; s <<= 1) ++rounds;
-      const double per_wave = 600.0 * rounds + 650.0 * (c - 1) + 250.0 * c + (c > 1 ? 300.0 : 0.0);   // instruction estimate
+      const double t = T4[li][ci] * (h->cfg.dof == 3 ? (c == 4 ? 7.2 : 3.8) : 1.0);
       const double waves = (double)((B + (64 / lpt) - 1) / (64 / lpt));
-      const double passes = waves <= 1024.0 ? 1.0 : waves / 1024.0;        // wavefronts per SIMD, at least one
-      const double cost = per_wave * passes;
+      const double turns = 1.25 * waves / 1024.0;
+      const double cost = t * (turns > 1.0 ? turns : 1.0);
       if (cost < best_cost) { best_cost = cost; best = DgpShape{lpt, c}; }
     }
   return best;

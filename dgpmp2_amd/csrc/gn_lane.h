@@ -1382,6 +1382,40 @@ DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int 
     o[a] -= cp.m[k] * t;
   }
 }
+// O = sgn * A U_k   (sgn = +1 / -1)
+template <int D, int N>
+DGP_HD void coup_A_U(const GnParams&, const Coupling<D, N, false>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
+  // A U = -m (A Phi^T) Q,   (A Phi^T)[a][c] = A[a][c] + (c < dof ? dt A[a][dof + c] : 0)
+  constexpr int DOF = D / 2;
+  double AP[D][D];
+  const double f = -sgn * cp.m[k];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) AP[a][c] = f * ((c < DOF) ? A.v[a][c] + cp.dt * A.v[a][DOF + c] : A.v[a][c]);
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) t += AP[a][q] * cp.q[k](q, c);
+      O.v[a][c] = t;
+    }
+}
+template <int D, int N>
+DGP_HD void coup_A_U(const GnParams& p, const Coupling<D, N, true>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
+  const double f = sgn * cp.m[k];
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) if (gp_nz<D>(q, c)) t += A.v[a][q] * p.u_fix[q * D + c];
+      O.v[a][c] = f * t;
+    }
+}
 // the block itself, in vector registers (the separator row's coupling is PCR state)
 template <int D, int N>
 DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Mat<D>& U) {
@@ -1570,9 +1604,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
           N0(a, c) = t;
         }
       add_A_v<D>(P0, Mk, z[k]);                            // P_0 += Pi_k S_k^-1 z_k
-      Mat<D> T;
-      if (k == KL) { A_B<D>(Pi, G, T); W0 = T; }           // W_0 = Pi_{C-2} G_{C-2}
-      else { neg_A_B<D>(Pi, G, T); Pi = T; }               // Pi_{k+1} = -Pi_k G_k
+      Mat<D> T;                                            // Pi_k G_k = (Pi_k S_k^-1) U_k = M_k U_k: U's structure applies
+      if (k == KL) { coup_A_U<D, C>(p, cp, k, Mk, 1.0, T); W0 = T; }      // W_0 = Pi_{C-2} G_{C-2}
+      else { coup_A_U<D, C>(p, cp, k, Mk, -1.0, T); Pi = T; }            // Pi_{k+1} = -Pi_k G_k
     }
     if (k == KL) sym_times_vec<D>(Sinv[k], z[k], Pl);      // P_{C-2} = S^-1 z_{C-2}   (x_{C-2} = P - (..) x_ps - G x_s)
     if (!QSTAT && !stat) Qm = Qown;
@@ -1580,7 +1614,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   // ---- c. separator row -> reduced system row
   Sym<D> Ds; Mat<D> Us; double rs[D];
   assemble(C - 1, (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Ds, rs);
-  coup_get<D, C>(p, cp, C - 1, Us);
+  if (C == 1 || !QSTAT) coup_get<D, C>(p, cp, C - 1, Us);
   if (C > 1) {
     coup_sub_UtB_sym<D, C>(p, cp, KL, Ds, G);             // D_s -= U_{C-2}^T W_{C-2},  W_{C-2} = G_{C-2}
     coup_sub_Ut_v<D, C>(p, cp, KL, rs, Pl);               // r_s -= U_{C-2}^T P_{C-2}
@@ -1594,29 +1628,56 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
       for (int c = 0; c < D; ++c) Wn.v[a][c] = nb.hi(W0.v[a][c]);
     }
-    // (Us == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
-    Mat<D> T;
+    // (U_s == 0 whenever there is no next lane / next row, so fetched-own values are harmless)
+    Mat<D> T, Ur;
+    if constexpr (QSTAT) {
+      // U_s = m_s * p.u_fix: scalar operands, structural zeros skipped, the mask applied to the results
+      const double ms = cp.m[C - 1];
 #pragma unroll
-    for (int a = 0; a < D; ++a)
+      for (int a = 0; a < D; ++a)
 #pragma unroll
-      for (int c = 0; c < D; ++c) {                        // T = U_s N'_0
-        double t = 0.0;
+        for (int c = 0; c < D; ++c) {
+          double t = 0.0, u = 0.0;
 #pragma unroll
-        for (int q = 0; q < D; ++q) t += Us.v[a][q] * Nn(q, c);
-        T.v[a][c] = t;
-      }
+          for (int q = 0; q < D; ++q) if (gp_nz<D>(a, q)) {
+            t += p.u_fix[a * D + q] * Nn(q, c);            // U N'_0
+            u += p.u_fix[a * D + q] * Wn.v[q][c];          // U W'_0
+          }
+          T.v[a][c] = ms * t;
+          Ur.v[a][c] = -ms * u;                            // U_red = -U_s W'_0
+        }
 #pragma unroll
-    for (int a = 0; a < D; ++a)
+      for (int a = 0; a < D; ++a)
 #pragma unroll
-      for (int c = a; c < D; ++c) {                        // D_s -= U_s N'_0 U_s^T
-        double t = Ds(a, c);
+        for (int c = a; c < D; ++c) {                      // D_s -= U_s N'_0 U_s^T   (m_s^2 = m_s)
+          double t = Ds(a, c);
 #pragma unroll
-        for (int q = 0; q < D; ++q) t -= T.v[a][q] * Us.v[c][q];
-        Ds(a, c) = t;
-      }
-    sub_A_v<D>(rs, Us, Pn);                               // r_s -= U_s P'_0
-    Mat<D> Ur;
-    neg_A_B<D>(Us, Wn, Ur);                               // U_red = -U_s W'_0
+          for (int q = 0; q < D; ++q) if (gp_nz<D>(c, q)) t -= T.v[a][q] * p.u_fix[c * D + q];
+          Ds(a, c) = t;
+        }
+      coup_sub_U_v<D, C>(p, cp, C - 1, rs, Pn);           // r_s -= U_s P'_0
+    } else {
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {                      // T = U_s N'_0
+          double t = 0.0;
+#pragma unroll
+          for (int q = 0; q < D; ++q) t += Us.v[a][q] * Nn(q, c);
+          T.v[a][c] = t;
+        }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = a; c < D; ++c) {                      // D_s -= U_s N'_0 U_s^T
+          double t = Ds(a, c);
+#pragma unroll
+          for (int q = 0; q < D; ++q) t -= T.v[a][q] * Us.v[c][q];
+          Ds(a, c) = t;
+        }
+      sub_A_v<D>(rs, Us, Pn);                             // r_s -= U_s P'_0
+      neg_A_B<D>(Us, Wn, Ur);                             // U_red = -U_s W'_0
+    }
     Us = Ur;
   }
 #if defined(DGP_PHASE_STOP)

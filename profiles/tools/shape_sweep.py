@@ -10,7 +10,7 @@ from dgpmp2_amd import _capi
 from dgpmp2_amd.gpmp2.plan_layer import solver_config
 
 
-def time_step(B, n, G, dtype, reps, shape, dof=2):
+def time_step(B, n, G, dtype, reps, shape, dof=2, warm=0.3):
   dev = torch.device('cuda:0')
   if shape: os.environ['DGP_FORCE_SHAPE'] = shape
   else: os.environ.pop('DGP_FORCE_SHAPE', None)
@@ -28,7 +28,7 @@ def time_step(B, n, G, dtype, reps, shape, dof=2):
   f = lambda: s.gn_step(B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sa, None, dth.data_ptr(), err.data_ptr(), eex.data_ptr(), None, st)
   import time
   t0 = time.time()
-  while time.time() - t0 < 0.3:                 # steady clocks: a cold GPU runs the first milliseconds ~12 % slower
+  while time.time() - t0 < warm:                 # steady clocks: a cold GPU runs the first milliseconds ~12 % slower
     for _ in range(50): f()
   torch.cuda.synchronize()
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -74,3 +74,20 @@ def test_calls_validate_arguments_without_gpu(api):
     s.gn_step(0, 0x1000, 0x1000, 0x1000, sdf, None, 0x1000)
   with pytest.raises(_capi.DgpError):
     s.gn_step(8, 0x1000, 0x1000, 0x1000, sdf, s.covs_arg(_capi.DGP_QC_PERSTATE, None), 0x1000)
+
+
+def test_launch_shape_choice(api):
+  """dgp_launch_shape (host logic, dgp_host::choose_shape): the shape always covers n, the benchmark batch gets 16 lanes x 4
+  states, short trajectories get one state per lane, long ones the only shape that fits."""
+  for n in (2, 7, 16, 33, 64, 101, 128, 200, 256):
+    s = _capi.Solver(_cfg(num_states=n))
+    for B in (1, 3, 256, 1024, 4096, 65536):
+      lpt, c = s.launch_shape(B)
+      assert lpt in (16, 32, 64) and c in (1, 2, 4) and lpt * c >= n, (n, B, lpt, c)
+  assert _capi.Solver(_cfg(num_states=64)).launch_shape(4096) == (16, 4)
+  assert _capi.Solver(_cfg(num_states=64)).launch_shape(32768) == (16, 4)
+  assert _capi.Solver(_cfg(num_states=16)).launch_shape(4096) == (16, 1)
+  assert _capi.Solver(_cfg(num_states=101)).launch_shape(4096) == (32, 4)
+  assert _capi.Solver(_cfg(num_states=256)).launch_shape(8) == (64, 4)
+  s6 = _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]]))
+  assert s6.launch_shape(4096) == (32, 2)                   # d = 6: four states per lane do not fit the register file
