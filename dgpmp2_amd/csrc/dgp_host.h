@@ -165,6 +165,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   if (!th || !start || !goal) return fail(DGP_EINVAL, "th/start/goal must be non-null device pointers");
   if (!sdf || !sdf->data) return fail(DGP_EINVAL, "sdf must be non-null");
   if (sdf->rows < 1 || sdf->cols < 1) return fail(DGP_EINVAL, "sdf grid must be at least 1x1, got %dx%d", sdf->rows, sdf->cols);
+  if (sdf->cols < 2) return fail(DGP_EUNSUPPORTED, "sdf grids with a single column are not implemented (the taps are fetched as column pairs)");
   if (sdf->batch_stride < 0) return fail(DGP_EINVAL, "negative sdf batch stride");
   if ((int64_t)sdf->rows * sdf->cols >= ((int64_t)1 << 31)) return fail(DGP_EUNSUPPORTED, "sdf grid of %dx%d elements is too large", sdf->rows, sdf->cols);
   p = h->base;

@@ -192,7 +192,9 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       const double w = taps.ow[k];
       double c, hx, hy;
       ObsTaps tp;
-      obstacle_finish(p, taps.oa[k], (double)taps.d11[k], (double)taps.d21[k], (double)taps.d12[k], (double)taps.d22[k], taps.eps[k], c, hx, hy, &tp);
+      double d11, d21, d12, d22;
+      tap_values<C, IO>(taps, k, d11, d21, d12, d22);
+      obstacle_finish(p, taps.oa[k], d11, d21, d12, d22, taps.eps[k], c, hx, hy, &tp);
       double g_eps = 0.0, g_w = 0.0;
       if (tp.act) {
         const double u = hx * lk[0] + hy * lk[1];

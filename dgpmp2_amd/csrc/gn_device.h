@@ -67,15 +67,39 @@ struct DevCtx {
 template <int DOF, int LPT, int C, int MODE>
 struct WavesPerSimd { static constexpr int value = DGP_FORCE_WPS ? DGP_FORCE_WPS : (DOF == 2 && C <= 2 && LPT >= 32 && MODE != dgp::MODE_SOLVE) ? 2 : 1; };
 
+// Touch every 64-byte line of the kernel-argument segment with a scalar load at kernel entry.  The argument block is
+// ~1.3 KB and the compiler loads its fields where they are first used, one exposed scalar-cache miss (a fresh address every
+// launch, so always a miss) per line, serially, in the middle of the program; issued together up front the misses overlap each
+// other and the first global loads, and the later loads hit the scalar cache.  Results are discarded.
+// (The loads target one fixed, clobbered SGPR and are waited for inside the same asm statement: scalar loads may return
+// out of order, so a discarded load must never be outstanding while the compiler reuses its destination register.)
+template <int OFF, int END>
+__device__ __forceinline__ void warm_kernarg_lines(const void* ka) {
+  if constexpr (OFF < END) {
+    asm volatile("s_load_dword s90, %0, %1" :: "s"(ka), "n"(OFF) : "s90");
+    warm_kernarg_lines<OFF + 64, END>(ka);
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "s90", "memory");
+  }
+}
+template <int BYTES>
+__device__ __forceinline__ void warm_kernarg() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  warm_kernarg_lines<0, BYTES>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+#endif
+}
+
 // QSTAT: static covariances (p.qc_mode == QC_STATIC) -- the constant GP blocks are scalar operands (see gn_lane.h).
 template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
+  warm_kernarg<(int)sizeof(dgp::GnParams)>();
   DevCtx cx;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QSTAT>(p, cx);
 }
 
 template <int DOF, int LPT, int C, typename IO, bool QSTAT>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
+  warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
   DevCtx cx;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QSTAT>(p, g, cx);
 }

@@ -38,16 +38,16 @@
   do {                                                                                                                 \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                        \
     const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                   \
-    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 8 + (slot)] = t_;  \
+    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 16 + (slot)] = t_;  \
   } while (0)
 #define DGP_STAMP_NOWAIT(p, cx, slot)                                                                                   \
   do {                                                                                                                 \
     const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                   \
-    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 8 + (slot)] = t_;  \
+    if ((cx).lane() == 0 && (p).err_hist) ((unsigned long long*)(p).err_hist)[(size_t)(cx).wave() * 16 + (slot)] = t_;  \
   } while (0)
 #elif defined(DGP_ISA_MARKS) && defined(__HIP_DEVICE_COMPILE__)      // "; DGPMARK n" comments in the ISA at the same points
-#define DGP_STAMP(p, cx, slot) asm volatile("; DGPMARK " #slot ::: "memory")
-#define DGP_STAMP_NOWAIT(p, cx, slot) asm volatile("; DGPMARK " #slot ::: "memory")
+#define DGP_STAMP(p, cx, slot) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; DGPMARK " #slot ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DGP_STAMP_NOWAIT(p, cx, slot) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; DGPMARK " #slot ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define DGP_STAMP(p, cx, slot) ((void)0)
 #define DGP_STAMP_NOWAIT(p, cx, slot) ((void)0)
@@ -769,12 +769,25 @@ struct LaneFactors {          // obstacle factor of each of the lane's C states:
 // afterwards): a load inside a divergent `if (valid)` costs its own s_waitcnt, i.e. one exposed memory round trip each.
 // The tap values stay in the I/O element type until they are used (lane_obstacle_finish): a conversion here would be
 // the first USE of the load and pin the memory wait in front of whatever is scheduled under the loads.
+// The four taps of a state are fetched as TWO pair loads (dwordx2 for f32 grids): elements xb, xb+1 of rows y1 and y2 with
+// xb = min(x1, W-2), so that both clamped columns x1, x2 of sdf_utils.py:64-72 are among the two elements whatever the
+// clamping did (x1 = x2 = 0 left of the grid, x1 = x2 = W-1 right of it).  Half the load instructions and half the L1
+// tag look-ups of four scalar gathers -- the gather of 1024 lane addresses per wavefront is what the texture path of a CU
+// spends ~0.5 us on per wavefront.  (Needs W >= 2: host-checked.)
+template <typename IO> struct __attribute__((packed, aligned(sizeof(IO)))) TapPair { IO a, b; };
 template <int C, typename IO>
 struct LaneTaps {
   ObsAddr oa[C];
-  IO d11[C], d21[C], d12[C], d22[C];
+  IO d11[C], d21[C], d12[C], d22[C];    // RAW pair elements: row y1 (a, b), row y2 (a, b) -- see tap_values()
+  bool first1[C], first2[C];            // column x1 / x2 is the FIRST element of the pair
   double eps[C], ow[C];
 };
+// the taps in the reference's naming: d11 = (x1,y1), d21 = (x2,y1), d12 = (x1,y2), d22 = (x2,y2)   (sdf_utils.py:76-79)
+template <int C, typename IO>
+DGP_HD void tap_values(const LaneTaps<C, IO>& t, int k, double& d11, double& d21, double& d12, double& d22) {
+  d11 = (double)(t.first1[k] ? t.d11[k] : t.d21[k]); d21 = (double)(t.first2[k] ? t.d11[k] : t.d21[k]);
+  d12 = (double)(t.first1[k] ? t.d12[k] : t.d22[k]); d22 = (double)(t.first2[k] ? t.d12[k] : t.d22[k]);
+}
 
 template <int DOF, int C, typename IO>
 DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_ok, const double (&x)[C][2 * DOF], LaneTaps<C, IO>& t) {
@@ -797,9 +810,11 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     // grids have fewer than 2^31 elements (host-checked): 32-bit element offsets
-    const int32_t r1 = t.oa[k].y1 * (int32_t)W, r2 = t.oa[k].y2 * (int32_t)W;
-    t.d11[k] = grid[r1 + t.oa[k].x1]; t.d21[k] = grid[r1 + t.oa[k].x2];
-    t.d12[k] = grid[r2 + t.oa[k].x1]; t.d22[k] = grid[r2 + t.oa[k].x2];
+    const int32_t xb = imin32(t.oa[k].x1, (int32_t)W - 2);
+    const int32_t r1 = t.oa[k].y1 * (int32_t)W + xb, r2 = t.oa[k].y2 * (int32_t)W + xb;
+    const TapPair<IO> p1 = *(const TapPair<IO>*)(grid + r1), p2 = *(const TapPair<IO>*)(grid + r2);
+    t.d11[k] = p1.a; t.d21[k] = p1.b; t.d12[k] = p2.a; t.d22[k] = p2.b;
+    t.first1[k] = (t.oa[k].x1 == xb); t.first2[k] = (t.oa[k].x2 == xb);
   }
 }
 
@@ -847,7 +862,9 @@ DGP_HD void lane_obstacle_finish(const GnParams& p, int g0, bool traj_ok, const 
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const bool valid = traj_ok && (g0 + k) < p.n;
-    obstacle_finish(p, t.oa[k], (double)t.d11[k], (double)t.d21[k], (double)t.d12[k], (double)t.d22[k], t.eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
+    double d11, d21, d12, d22;
+    tap_values<C, IO>(t, k, d11, d21, d12, d22);
+    obstacle_finish(p, t.oa[k], d11, d21, d12, d22, t.eps[k], f.oc[k], f.ohx[k], f.ohy[k]);
     f.ow[k] = t.ow[k];
     if (!valid) { f.ow[k] = 0.0; f.oc[k] = 0.0; f.ohx[k] = 0.0; f.ohy[k] = 0.0; }
   }
@@ -1480,6 +1497,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   {
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
+    DGP_STAMP_NOWAIT(p, cx, 8);
     if constexpr (QSTAT) {
       // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
       double mu_ga[D];
@@ -1494,7 +1512,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       double anchor[2 * C];
 #pragma unroll
       for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
+      DGP_STAMP_NOWAIT(p, cx, 9);
       lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
+      DGP_STAMP_NOWAIT(p, cx, 10);
     }
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }

@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
   {  // in-kernel timeline: two consecutive launches in the middle of a back-to-back series write their stamps
     const int waves = (B + 3) / 4;
     unsigned long long *d_s0, *d_s1;
-    hipMalloc(&d_s0, (size_t)waves * 64); hipMalloc(&d_s1, (size_t)waves * 64);
+    hipMalloc(&d_s0, (size_t)waves * 128); hipMalloc(&d_s1, (size_t)waves * 128);
     dgp::GnParams p0 = p, p1 = p;
     p0.err_hist = d_s0; p1.err_hist = d_s1;
     for (int i = 0; i < 400; ++i) {
@@ -88,15 +88,15 @@ int main(int argc, char** argv) {
       hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, q);
     }
     hipDeviceSynchronize();
-    std::vector<unsigned long long> s0((size_t)waves * 8), s1((size_t)waves * 8);
+    std::vector<unsigned long long> s0((size_t)waves * 16), s1((size_t)waves * 16);
     hipMemcpy(s0.data(), d_s0, s0.size() * 8, hipMemcpyDeviceToHost); hipMemcpy(s1.data(), d_s1, s1.size() * 8, hipMemcpyDeviceToHost);
-    const char* names[7] = {"entry", "th/start/goal loaded", "taps + factors done", "local elimination done", "PCR + recovery done", "stores issued", "stores acked"};
+    const char* names[11] = {"entry", "th/start/goal loaded", "taps + factors done", "local elimination done", "PCR + recovery done", "stores issued", "stores acked", "-", "tap loads issued", "GP right-hand sides done", "taps arrived"};
     unsigned long long first0 = ~0ull, last0 = 0, first1 = ~0ull;
-    for (int w = 0; w < waves; ++w) { first0 = std::min(first0, s0[w * 8]); last0 = std::max(last0, s0[w * 8 + 6]); first1 = std::min(first1, s1[w * 8]); }
+    for (int w = 0; w < waves; ++w) { first0 = std::min(first0, s0[w * 16]); last0 = std::max(last0, s0[w * 16 + 6]); first1 = std::min(first1, s1[w * 16]); }
     printf("launch k: first entry -> last ack %.2f us;  gap to first entry of launch k+1: %.2f us\n", (last0 - first0) * 0.01, ((double)first1 - (double)last0) * 0.01);
-    for (int sl = 0; sl < 7; ++sl) {
+    for (int sl : {0, 1, 8, 9, 10, 2, 3, 4, 5, 6}) {
       std::vector<double> v;
-      for (int w = 0; w < waves; ++w) v.push_back((s0[w * 8 + sl] - first0) * 0.01);
+      for (int w = 0; w < waves; ++w) v.push_back((s0[w * 16 + sl] - first0) * 0.01);
       std::sort(v.begin(), v.end());
       printf("  %-24s min %5.2f  median %5.2f  max %5.2f us after the first wavefront's entry\n", names[sl], v.front(), v[v.size() / 2], v.back());
     }
