@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (spec)
 # fp64 FMA/MUL/ADD instructions one wavefront of gn_kernel<DOF=2,LPT=16,C=4,float,STEP,static> executes (ISA histogram of the
 # straight-line kernel); every one is a 64-lane operation, an FMA counting 2 flops
-FP64_VALU_INSTS_PER_WAVE_16x4 = {'fma': 2488, 'mul_add': 525}
+FP64_VALU_INSTS_PER_WAVE_16x4 = {'fma': 2330, 'mul_add': 579}
 
 
 def algorithmic_bytes_per_trajectory(n, d, nl=1, io_bytes=4):
