@@ -11,6 +11,9 @@ namespace dgp_dev {
 // Device lane context: cross-lane fetches are ds_bpermute (any lane -> any lane inside the wavefront; the LDS
 // crossbar is used, no LDS memory is touched).
 struct DevCtx {
+  char* lds_;      // the workgroup's (= wavefront's) LDS staging block, dgp::WaveStore<...>::kLdsBytes
+  __device__ __forceinline__ char* lds() const { return lds_; }
+  __device__ __forceinline__ void lds_sync() const { __syncthreads(); }      // one wavefront per workgroup
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
   __device__ __forceinline__ int fetch_i(int v, int src) const { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
@@ -93,7 +96,9 @@ __device__ __forceinline__ void warm_kernarg() {
 template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   warm_kernarg<(int)sizeof(dgp::GnParams)>();
+  __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
   DevCtx cx;
+  cx.lds_ = lds;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QSTAT>(p, cx);
 }
 
@@ -101,6 +106,7 @@ template <int DOF, int LPT, int C, typename IO, bool QSTAT>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
   DevCtx cx;
+  cx.lds_ = nullptr;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QSTAT>(p, g, cx);
 }
 

@@ -1802,6 +1802,47 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Row stores of a whole wavefront through LDS.  A lane owns C consecutive rows = one contiguous chunk of C*D elements, so
+// a direct store instruction writes 16 bytes at a C*D*sizeof(IO)-byte lane stride: 64 partially written cache lines per
+// instruction, which the memory pipeline acknowledges ~0.4 us later than the same bytes written as full lines
+// (profiles/tools/launch_probe.hip).  When the wavefront's rows are one contiguous block of memory (n == LPT*C, identity
+// lane mapping, every trajectory of the wavefront exists, 16-byte aligned rows) the chunks are written to LDS (lane stride
+// padded by 16 bytes: conflict-free 128-bit writes) and read back so that lane l stores the l-th 16 bytes of each 1 KB.
+// ---------------------------------------------------------------------------------------------------
+template <typename IO, int C, int D>
+struct WaveStore {
+  static constexpr int kChunk = C * D * (int)sizeof(IO);          // bytes per lane
+  static constexpr bool kUsable = (kChunk % 16) == 0;
+  static constexpr int kCells = kUsable ? kChunk / 16 : 1;        // 16-byte cells per lane
+  static constexpr int kStride = kChunk + 16;
+  static constexpr int kLdsBytes = kUsable ? 64 * kStride : 16;
+};
+
+template <typename IO, int C, int D, typename Ctx>
+DGP_HD void store_rows_through_lds(Ctx& cx, void* out, int64_t wave_first_elem, const double (&v)[C][D]) {
+  typedef WaveStore<IO, C, D> WS;
+  typedef IO V16 __attribute__((vector_size(16)));
+  constexpr int EPV = 16 / (int)sizeof(IO);                       // elements per 16-byte cell
+  const int lane = cx.lane();
+  char* l = cx.lds();
+#pragma unroll
+  for (int i = 0; i < WS::kCells; ++i) {
+    V16 t;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) t[e] = (IO)v[(i * EPV + e) / D][(i * EPV + e) % D];
+    *(V16*)(l + lane * WS::kStride + i * 16) = t;
+  }
+  cx.lds_sync();
+  char* o = (char*)out + wave_first_elem * (int64_t)sizeof(IO);
+#pragma unroll
+  for (int i = 0; i < WS::kCells; ++i) {
+    const int c = i * 64 + lane;                                  // cell index inside the wavefront's block
+    const V16 t = *(const V16*)(l + (c / WS::kCells) * WS::kStride + (c % WS::kCells) * 16);
+    *(V16*)(o + (int64_t)c * 16) = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
 template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT, typename Ctx>
@@ -1852,10 +1893,19 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
+      // wave-uniform: the wavefront's dtheta rows are one contiguous, fully populated block -> full-line stores via LDS
+      bool block_store = false;
+      if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32)
+        block_store = vec && n == LPT * C && ((int64_t)cx.wave() + 1) * TPW <= (int64_t)p.B;
+      if (block_store) {
+        if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32)
+          store_rows_through_lds<IO, C, D>(cx, p.dtheta, (int64_t)cx.wave() * TPW * n * D, dx);
+      } else {
 #pragma unroll
-      for (int k = 0; k < C; ++k) {
-        const int g = j * C + k;
-        if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
+        for (int k = 0; k < C; ++k) {
+          const int g = j * C + k;
+          if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
+        }
       }
       if (traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, div_M(p, e));
