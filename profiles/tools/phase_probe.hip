@@ -43,15 +43,20 @@ int main(int argc, char** argv) {
       sdf[(size_t)r * G + c] = d;
     }
   float *d_th, *d_st, *d_go, *d_sdf, *d_dth, *d_err, *d_eex;
-  hipMalloc(&d_th, th.size() * 4); hipMalloc(&d_st, st.size() * 4); hipMalloc(&d_go, go.size() * 4); hipMalloc(&d_sdf, sdf.size() * 4);
+  hipMalloc(&d_th, th.size() * 4 * 10); hipMalloc(&d_st, st.size() * 4); hipMalloc(&d_go, go.size() * 4); hipMalloc(&d_sdf, sdf.size() * 4);
   hipMalloc(&d_dth, th.size() * 4); hipMalloc(&d_err, B * 4); hipMalloc(&d_eex, B * 4);
-  hipMemcpy(d_th, th.data(), th.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_st, st.data(), st.size() * 4, hipMemcpyHostToDevice);
+  for (int c = 0; c < 10; ++c) hipMemcpy(d_th + (size_t)c * th.size(), th.data(), th.size() * 4, hipMemcpyHostToDevice);   // ten input buffers, cycled like bench.py
+  hipMemcpy(d_st, st.data(), st.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_go, go.data(), go.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_sdf, sdf.data(), sdf.size() * 4, hipMemcpyHostToDevice);
   DgpSdf sa; sa.data = d_sdf; sa.rows = G; sa.cols = G; sa.batch_stride = 0;
   dgp::GnParams p;
   if (dgp_host::fill_step(h, B, d_th, d_st, d_go, &sa, nullptr, d_dth, d_err, d_eex, nullptr, p) != DGP_OK) { printf("fill failed\n"); return 1; }
   const dim3 grid((B + 3) / 4), block(64);
-  auto launch = [&]() { hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, p); };
+  int launch_no = 0;
+  auto launch = [&]() {
+    p.th = d_th + (size_t)(launch_no++ % 10) * th.size();
+    hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, p);
+  };
   for (int i = 0; i < 2000; ++i) launch();        // clocks up
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
