@@ -2,14 +2,18 @@
 //
 // Mapping (MI355X, wave64): one trajectory occupies LPT consecutive lanes of a wavefront (LPT = 16, 32 or 64) and every
 // lane OWNS C consecutive support states (n <= LPT*C).  Every lane
-//   1. loads its C states and everything else it reads from memory (start/goal, covariances, SDF taps) up front and
-//      branch-free, gets the two states across its lane boundaries with cross-lane moves (DPP row shifts for LPT = 16),
+//   1. loads its C states, gets the two states across its lane boundaries with cross-lane moves (DPP row shifts), computes the
+//      bilinear tap addresses and issues the SDF loads (two column-pair loads per state); everything that does not need the
+//      taps (priors, GP factors) is evaluated while they are in flight,
 //   2. evaluates the factors touching its states and writes their block rows of the block-tridiagonal normal
-//      equations (D sym dxd, U dxd, eta) straight into registers,
-//   3. eliminates its C-1 interior rows locally (block Thomas with a left spike), which leaves ONE row per lane,
+//      equations (D sym dxd, U dxd, eta) straight into registers (static covariances: the constant GP blocks are scalar
+//      kernel arguments, see eval_state / static_rhs / Coupling),
+//   3. eliminates its C-1 interior rows locally (streamed block forward sweep that accumulates the Schur-complement pieces
+//      the separator rows need), which leaves ONE row per lane,
 //   4. takes part in a block parallel-cyclic-reduction (PCR) solve over the LPT lanes: log2(LPT) rounds, in each
-//      round a lane inverts its own D, fetches (D^-1, U, eta) of lanes j-s and j+s, and eliminates them,
-//   5. recovers its interior unknowns from the two neighbouring separator unknowns.
+//      round a lane inverts its own D, fetches (D^-1, U, eta) of lanes j-s and j+s, and eliminates them (the last round has
+//      a single partner per row),
+//   5. recovers its interior unknowns by a vector forward / back substitution from the two neighbouring separator unknowns.
 // Lambda never exists in memory.  All arithmetic is fp64 (the reference is fp64-only).
 //
 // The program is written against a tiny "lane context" (cross-lane fetch + ids) so that the very same
