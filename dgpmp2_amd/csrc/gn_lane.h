@@ -1859,6 +1859,12 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int n = p.n;
   const bool traj_ok = b < p.B;
   DGP_STAMP_NOWAIT(p, cx, 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the scalars of the pixel-coordinate / tap-address arithmetic are fetched now, under the th load, instead of at their
+  // first use right after it (the compiler places scalar loads in the block that first needs them)
+  asm volatile("" :: "s"(p.res), "s"(p.inv_res), "s"(p.orig_px), "s"(p.orig_py), "s"(p.sdf), "s"(p.sdf_cols), "s"(p.sdf_rows),
+               "s"(p.sdf_bstride), "s"(p.eps), "s"(p.obs_w));
+#endif
 
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];

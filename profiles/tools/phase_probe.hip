@@ -105,6 +105,20 @@ int main(int argc, char** argv) {
       std::sort(v.begin(), v.end());
       printf("  %-24s min %5.2f  median %5.2f  max %5.2f us after the first wavefront's entry\n", names[sl], v.front(), v[v.size() / 2], v.back());
     }
+    // per-wavefront phase DURATIONS, and their medians split by XCD (workgroup id mod 8)
+    const int seq[10] = {0, 1, 8, 9, 10, 2, 3, 4, 5, 6};
+    for (int q = 1; q < 10; ++q) {
+      std::vector<double> v;
+      std::vector<std::vector<double>> byx(8);
+      for (int w = 0; w < waves; ++w) {
+        const double dur = ((double)s0[w * 16 + seq[q]] - (double)s0[w * 16 + seq[q - 1]]) * 0.01;
+        v.push_back(dur); byx[w % 8].push_back(dur);
+      }
+      std::sort(v.begin(), v.end());
+      printf("  duration -> %-24s min %5.2f  p10 %5.2f  median %5.2f  p90 %5.2f  max %5.2f   per-XCD medians:", names[seq[q]], v.front(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+      for (int x = 0; x < 8; ++x) { std::sort(byx[x].begin(), byx[x].end()); printf(" %.2f", byx[x][byx[x].size() / 2]); }
+      printf("\n");
+    }
   }
 #endif
   std::vector<float> out(16);
