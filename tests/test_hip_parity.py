@@ -63,6 +63,42 @@ def test_hip_c2_full_size_properties(be, io):
   assert np.array_equal(dth3, dth)
 
 
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('config', ['c3_vel_limits', 'c4_xyh'])
+def test_hip_c3_c4_full_size_vs_oracles(be, config, io):
+  """BASELINE configs 3 (2D point robot + velocity-limit factors) and 4 (non-holonomic (x,y,theta) robot, 6-dim state,
+  512x512 SDF) at full size, B=4096 x 64 states: every trajectory against oracle/gn_blocktri.c, a random subset of 48
+  against the dense numpy restatement of the reference."""
+  from oracle import blocktri as BT
+  B, n = 4096, 64
+  rs = np.random.RandomState(11)
+  if config == 'c3_vel_limits':
+    G, dof = 256, 2
+    p = O.OracleParams(dof=2, total_time_step=n - 1, use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0)
+  else:
+    G, dof = 512, 3
+    p = O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)
+  d = 2 * dof
+  start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+  start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+  if dof == 3: goal[:, 0, 2] = np.pi / 2                          # examples/diff_gpmp2_nonholonomic_example.py:44-46
+  th = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + rs.randn(B, n, d) * 0.05
+  sdf = O.circles_sdf(G, O.C2_CIRCLES)[None, None]
+  th, start, goal, sdf = PC.rnd(th, io), PC.rnd(start, io), PC.rnd(goal, io), PC.rnd(sdf, io)
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, io=io)
+  assert np.all(info == 0) and np.all(np.isfinite(dth))
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, nthreads=4)
+  assert not c_info.any()
+  per_traj = np.abs(dth - c_dth).reshape(B, -1).max(1) / np.abs(c_dth).reshape(B, -1).max(1)
+  assert per_traj.max() < PC.TOL[io], per_traj.max()
+  assert rel_err(err, c_err) < PC.TOL_ERR[io] and rel_err(eex, c_eex) < PC.TOL_ERR[io]
+  idx = rs.choice(B, 48, replace=False)
+  qc, ow, eps = p.static_covs(48)
+  r_dth, r_err, r_eex = O.plan_layer_forward(th[idx], start[idx], goal[idx], np.broadcast_to(sdf, (48, 1, G, G)), qc, ow, eps, p)
+  assert rel_err(dth[idx], r_dth) < PC.TOL[io]
+  assert rel_err(err[idx], r_err.reshape(-1)) < PC.TOL_ERR[io] and rel_err(eex[idx], r_eex.reshape(-1)) < PC.TOL_ERR[io]
+
+
 def test_hip_c2_ten_iterations_reduce_error(be):
   """10 GN iterations on the C2 workload (fused loop): error decreases overall and equals 10 chained steps."""
   B, n, G = 256, 64, 256
