@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Randomised stress run (not collected by pytest): random trajectory lengths, batch sizes, robots, factor flags, SDF shapes
+(non-square, trajectories leaving the grid), I/O dtypes and covariance modes through the C-ABI on the GPU, every
+trajectory compared with oracle/gn_blocktri.c.   usage (GPU box): python tests/stress_random_configs.py [--cases 200]"""
+import argparse, os, sys
+import numpy as np
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
+import harness
+import parity_cases as PC
+from oracle import gpmp2_oracle as O, blocktri as BT
+
+ap = argparse.ArgumentParser(); ap.add_argument('--cases', type=int, default=200); ap.add_argument('--seed', type=int, default=0)
+args = ap.parse_args()
+be = harness.Backend('hip')
+rs = np.random.RandomState(args.seed)
+worst = 0.0
+for case in range(args.cases):
+  dof = int(rs.choice([2, 2, 3]))
+  n = int(rs.choice([2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 63, 64, 65, 101, 128, 129, 200, 256]))
+  B = int(rs.choice([1, 2, 3, 4, 5, 7, 8, 63, 64, 65, 257, 1000]))
+  io = str(rs.choice(['f64', 'f32']))
+  kw = {}
+  if dof == 3 and rs.rand() < 0.6: kw.update(non_holonomic=True, K_d=float(rs.choice([0.01, 0.1])))
+  if rs.rand() < 0.4: kw.update(use_vel_limits=True, K_v=0.01, v_x=float(rs.uniform(0.2, 1.5)), v_y=float(rs.uniform(0.2, 1.5)))
+  qmode = rs.choice(['identity', 'diag', 'full'])
+  if qmode == 'diag': kw['Q_c_inv'] = np.diag(rs.uniform(0.5, 2.0, dof))
+  if qmode == 'full':
+    A = rs.randn(dof, dof) * 0.3
+    kw['Q_c_inv'] = np.eye(dof) + A @ A.T
+  p = O.OracleParams(dof=dof, total_time_step=n - 1, reg=float(rs.choice([0.1, 0.1, 1e-3])), epsilon_dist=float(rs.uniform(0.1, 0.6)), **kw)
+  d = 2 * dof
+  H, W = int(rs.choice([2, 5, 33, 64, 100, 256])), int(rs.choice([2, 3, 33, 64, 100, 256]))
+  yy, xx = np.meshgrid(np.linspace(5, -5, H), np.linspace(-5, 5, W), indexing='ij')
+  per_sample = rs.rand() < 0.3 and B <= 65
+  nsd = B if per_sample else 1
+  cs = rs.uniform(-3, 3, (nsd, 3, 2)); rr = rs.uniform(0.4, 1.2, (nsd, 3))
+  sdf = np.min(np.sqrt((xx[None, None] - cs[:, :, 0, None, None]) ** 2 + (yy[None, None] - cs[:, :, 1, None, None]) ** 2) - rr[:, :, None, None], axis=1)[:, None]
+  span = float(rs.choice([4.0, 4.0, 5.5]))          # 5.5: some trajectories leave the grid
+  start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+  start[:, 0, :2] = rs.uniform(-span, span, (B, 2)); goal[:, 0, :2] = rs.uniform(-span, span, (B, 2))
+  if dof == 3: goal[:, 0, 2] = rs.uniform(-np.pi, np.pi, B)
+  th = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + rs.randn(B, n, d) * float(rs.choice([0.0, 0.05, 0.3]))
+  qc = ow = eps = None; q_full = False
+  cov = rs.choice(['static', 'static', 'perstate', 'qfull'])
+  if cov != 'static':
+    ow = rs.uniform(50, 2e4, (B, n)); eps = rs.uniform(0.1, 0.6, (B, n))
+    if cov == 'perstate':
+      A = rs.randn(B, n - 1, dof, dof) * 0.2; qc = np.eye(dof) + A @ np.swapaxes(A, -1, -2)
+    else:
+      A = rs.randn(B, n - 1, d, d) * 0.2; qc = (np.eye(d) + A @ np.swapaxes(A, -1, -2)) * rs.uniform(0.5, 3.0); q_full = True
+  r = lambda a: None if a is None else PC.rnd(a, io)
+  th, start, goal, sdf, qc, ow, eps = r(th), r(start), r(goal), r(sdf), r(qc), r(ow), r(eps)
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
+  sh = (B, n, 1, 1)
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh),
+                                           q_full=q_full, nthreads=4)
+  ok = (c_info == 0) & (info == 0)
+  assert np.array_equal(c_info != 0, info != 0), ('SPD flags differ', case)
+  if ok.any():
+    scale = np.abs(c_dth).reshape(B, -1).max(1) + 1e-300
+    e = (np.abs(dth - c_dth).reshape(B, -1).max(1) / scale)[ok].max()
+    ee = np.abs(err - c_err)[ok].max() / (np.abs(c_err)[ok].max() + 1e-300)
+    tol = PC.TOL[io] * (30 if p.reg < 0.01 else 1)          # weakly regularised systems: cond(Lambda) up to 1e7
+    worst = max(worst, e / tol)
+    status = 'ok' if (e < tol and ee < 10 * PC.TOL_ERR[io]) else 'FAIL'
+    print('%3d %s dof=%d n=%3d B=%4d %s sdf=%dx%d%s cov=%s Qc=%s flags=%s  dth %.1e err %.1e' % (case, status, dof, n, B, io, H, W, '(per-sample)' if per_sample else '', cov, qmode,
+          ','.join(k for k in ('non_holonomic', 'use_vel_limits') if k in kw), e, ee), flush=True)
+    assert status == 'ok'
+print('all %d cases ok; worst dtheta error / tolerance = %.2f' % (args.cases, worst))
