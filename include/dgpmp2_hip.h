@@ -82,7 +82,8 @@ typedef struct DgpHandle DgpHandle;
 typedef struct DgpSdf {
   const void* data;
   int32_t     rows;          /* H' */
-  int32_t     cols;          /* W'; res = (x_lims[1]-x_lims[0])/W'  (obstacle_cost.py:34)     */
+  int32_t     cols;          /* W' >= 2; res = (x_lims[1]-x_lims[0])/W'  (obstacle_cost.py:34); a single-column grid
+                                is rejected with DGP_EUNSUPPORTED: the taps are fetched as column pairs */
   int64_t     batch_stride;
 } DgpSdf;
 

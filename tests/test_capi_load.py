@@ -74,6 +74,9 @@ def test_calls_validate_arguments_without_gpu(api):
     s.gn_step(0, 0x1000, 0x1000, 0x1000, sdf, None, 0x1000)
   with pytest.raises(_capi.DgpError):
     s.gn_step(8, 0x1000, 0x1000, 0x1000, sdf, s.covs_arg(_capi.DGP_QC_PERSTATE, None), 0x1000)
+  with pytest.raises(_capi.DgpError) as e:                       # single-column grids: taps are fetched as column pairs
+    s.gn_step(8, 0x1000, 0x1000, 0x1000, s.sdf_arg(0x1000, 64, 1, 0), None, 0x1000)
+  assert e.value.code == _capi.DGP_EUNSUPPORTED
 
 
 def test_launch_shape_choice(api):
