@@ -105,8 +105,9 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
 template <int DOF, int LPT, int C, typename IO, bool QSTAT>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
+  __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
   DevCtx cx;
-  cx.lds_ = nullptr;
+  cx.lds_ = lds;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QSTAT>(p, g, cx);
 }
 
