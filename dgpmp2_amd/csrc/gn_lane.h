@@ -1481,10 +1481,12 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, M
 // With C == 1 there are no interior rows and this is plain block PCR on the original system.
 // QSTAT: static covariances, rows assembled by eval_state_static, U_k = m_k * p.u_fix (see Coupling).
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx>
+// `before_pcr(acc)` is called once every factor of the lane has been evaluated (the error partials are complete) and before
+// the PCR rounds: MODE_STEP reduces and stores err / err_ext there, off the tail of the kernel.
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
-                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
+                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok, Hook&& before_pcr) {
   constexpr int D = 2 * DOF;
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
   constexpr int KL = (C > 1) ? C - 2 : 0;       // last interior row
@@ -1714,6 +1716,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   }
 #endif
   DGP_STAMP_NOWAIT(p, cx, 3);
+  before_pcr(acc);
   double xs[D];
   pcr_solve<D, LPT>(cx, j, Ds, Us, rs, xs, ok);
 #pragma unroll
@@ -1778,6 +1781,13 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       for (int a = 0; a < D; ++a) dx[k][a] = xn[a];
     }
   }
+}
+
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx>
+DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
+                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
+                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
+  gn_linear_solve<DOF, LPT, C, IO, RHS_OVERRIDE, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, rhs, dx, acc, ok, [](const ErrAcc&) {});
 }
 
 // errors only (no assembly): sums over the lane's C rows
@@ -1936,9 +1946,15 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
     bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, false, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok);
+    double e = 0.0, ee = 0.0;
+    gn_linear_solve<DOF, LPT, C, IO, false, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, [&](const ErrAcc& a) {
+      e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
+      if (MODE == MODE_STEP && traj_ok && j == 0) {
+        if (p.err) st<IO>(p.err, b, div_M(p, e));
+        if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
+      }
+    });
     DGP_STAMP_NOWAIT(p, cx, 4);
-    const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
       // wave-uniform: the wavefront's dtheta rows are one contiguous, fully populated block -> full-line stores via LDS
@@ -1954,10 +1970,6 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
           const int g = j * C + k;
           if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
         }
-      }
-      if (traj_ok && j == 0) {
-        if (p.err) st<IO>(p.err, b, div_M(p, e));
-        if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
       }
     } else {
       double s2 = 0.0;
