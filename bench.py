@@ -5,15 +5,22 @@ Workload (BASELINE.json configs[1]): 2-D point robot, batch B = 4096 
 states (d = 4), one shared 256x256 signed-distance field (union of three circles), static covariances from
 examples/configs/gpmp2_2d_params.yaml, fp32 I/O, fp64 arithmetic.  A "step" is one whole-batch Gauss-Newton step ==
 one call of the C-ABI's dgp_gn_step == the reference's PlanLayer.forward (factor evaluation + block-tridiagonal
-assembly + solve + err + err_ext).  The inputs of step k are the trajectories after (k mod 10) GN iterations from the
-straight-line initialisation ("10 GN iters"), precomputed before the timed region and resident in HBM.
+assembly + solve + err + err_ext + the per-trajectory SPD flags the planner always asks for).  The inputs of step k are
+the trajectories after (k mod 10) GN iterations from the straight-line initialisation ("10 GN iters"), precomputed
+before the timed region and resident in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
+Before the W warm-up steps the GPU is brought to its steady clocks by a TIME-based pre-warm (>= 0.6 s of the same launches,
+reported as `prewarm_s`): a cold MI355X runs the first milliseconds ~12 % slower, and K = 20 steps last 0.2 ms.
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU (RCCL): every rank owns its own 4096
 trajectories (weak scaling, no data-path collective); the only collective is one all-gather of the final trajectories
-at the end of the timed region.  Rank 0 prints ONE JSON line.
+at the end of the timed region, through the product's helper dgpmp2_amd.parallel.all_gather_trajectories.
+Rank 0 prints ONE JSON line.  Beside the headline it carries (rank 0, N = 1, outside the timed region): the fused 10-iteration
+launch, BASELINE configs[2] and [3], the per-sample-SDF and learned-covariance regimes of configs[1], each with its own
+roofline block, the planner-API call rate, and the CPU baselines.
 """
 import argparse
+import contextlib
 import ctypes
 import json
 import os
@@ -28,40 +35,76 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, N_STATES, DOF, GRID = 4096, 64, 2, 256
 GN_ITERS = 10
+PREWARM_S = 0.6
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (spec)
-# fp64 FMA/MUL/ADD instructions one wavefront of gn_kernel<DOF=2,LPT=16,C=4,float,STEP,static> executes (ISA histogram of the
-# straight-line kernel); every one is a 64-lane operation, an FMA counting 2 flops
-FP64_VALU_INSTS_PER_WAVE_16x4 = {'fma': 2330, 'mul_add': 579}
 
 
-def algorithmic_bytes_per_trajectory(n, d, nl=1, io_bytes=4):
-  """th in + dtheta out + 4 SDF taps per state + start, goal + err, err_ext (static covariances)."""
-  return io_bytes * (2 * n * d + 4 * n * nl + 2 * d + 2)
+def algorithmic_bytes_per_trajectory(n, d, nl=1, io_bytes=4, cov_tensors=False, dof=None):
+  """th in + dtheta out + 4 SDF taps per state + start, goal + err, err_ext; plus, when the per-state
+  covariance tensors are streamed (the learned mode / the reference's API shape), qc_inv (n-1, dof, dof) + obs_w + eps."""
+  b = io_bytes * (2 * n * d + 4 * n * nl + 2 * d + 2)
+  if cov_tensors:
+    dof = d // 2 if dof is None else dof
+    b += io_bytes * ((n - 1) * dof * dof + 2 * n * nl)
+  return b
 
 
-def make_inputs(B, n, G, device, seed=0):
+def make_inputs(B, n, G, device, seed=0, dof=2):
   """Deterministic synthetic inputs of SURVEY 8(d): start/goal ~ U(-4,4)^2 (start first, then goal), zero velocities,
-  straight-line initial trajectories (utils/planner_utils.py:47-56), analytic three-circle SDF."""
+  straight-line initial trajectories (utils/planner_utils.py:47-56), analytic three-circle SDF.  dof = 3 (BASELINE
+  configs[3]): start heading 0, goal heading pi/2 (examples/diff_gpmp2_nonholonomic_example.py:44-46)."""
   from dgpmp2_amd.utils.planner_utils import straight_line_trajb
   from dgpmp2_amd.utils.sdf_utils import circles_sdf, C2_CIRCLES
   g = torch.Generator().manual_seed(seed)
-  start = torch.cat([torch.rand(B, 1, 2, generator=g, dtype=torch.float64) * 8 - 4, torch.zeros(B, 1, 2, dtype=torch.float64)], -1)
-  goal = torch.cat([torch.rand(B, 1, 2, generator=g, dtype=torch.float64) * 8 - 4, torch.zeros(B, 1, 2, dtype=torch.float64)], -1)
-  th0 = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2)
+  sp = torch.rand(B, 1, 2, generator=g, dtype=torch.float64) * 8 - 4
+  gp = torch.rand(B, 1, 2, generator=g, dtype=torch.float64) * 8 - 4
+  if dof == 3:
+    sp = torch.cat([sp, torch.zeros(B, 1, 1, dtype=torch.float64)], -1)
+    gp = torch.cat([gp, torch.full((B, 1, 1), float(np.pi / 2), dtype=torch.float64)], -1)
+  start = torch.cat([sp, torch.zeros(B, 1, dof, dtype=torch.float64)], -1)
+  goal = torch.cat([gp, torch.zeros(B, 1, dof, dtype=torch.float64)], -1)
+  th0 = straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof)
   sdf = torch.from_numpy(circles_sdf(G, C2_CIRCLES))[None, None]
   f = lambda t: t.to(torch.float32).contiguous().to(device)
   return f(th0), f(start), f(goal), f(sdf)
 
 
-def measured_traffic():
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic.json, produced by
-  profiles/tools/pmc_traffic.sh with the guide's gfx950 FETCH_SIZE correction); None when no such measurement is committed."""
+def make_per_sample_sdfs(B, G, device, seed=1, chunk=256):
+  """SURVEY 8(d) per-sample mode: one GxG grid per trajectory, three circles each, centres ~ U(-3.5,3.5)^2, radii ~
+  U(0.4,1.0), torch.Generator().manual_seed(1); fp64 arithmetic on the device, stored in fp32 (B,1,G,G)."""
+  g = torch.Generator().manual_seed(seed)
+  c = (torch.rand(B, 3, 2, generator=g, dtype=torch.float64) * 7.0 - 3.5).to(device)
+  r = (torch.rand(B, 3, generator=g, dtype=torch.float64) * 0.6 + 0.4).to(device)
+  xs = torch.linspace(-5.0, 5.0, G, dtype=torch.float64, device=device)
+  ys = torch.linspace(5.0, -5.0, G, dtype=torch.float64, device=device)
+  out = torch.empty(B, 1, G, G, dtype=torch.float32, device=device)
+  for lo in range(0, B, chunk):
+    cc, rr = c[lo:lo + chunk], r[lo:lo + chunk]
+    dx = xs.view(1, 1, 1, G) - cc[:, :, 0].reshape(-1, 3, 1, 1)
+    dy = ys.view(1, 1, G, 1) - cc[:, :, 1].reshape(-1, 3, 1, 1)
+    out[lo:lo + chunk, 0] = (torch.sqrt(dx * dx + dy * dy) - rr.reshape(-1, 3, 1, 1)).min(1).values.to(torch.float32)
+  return out
+
+
+def measured_traffic(key='gn_step'):
+  """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by profiles/tools/pmc_report.py
+  with the guide's gfx950 FETCH_SIZE correction); None when no such measurement is committed for this workload."""
   f = os.path.join(ROOT, 'profiles', 'traffic.json')
   try:
-    return float(json.load(open(f))['hbm_bytes_per_launch'])
-  except (OSError, ValueError, KeyError):
+    d = json.load(open(f))
+    if key == 'gn_step' and 'hbm_bytes_per_launch' in d: return float(d['hbm_bytes_per_launch'])
+    return float(d[key]['hbm_bytes_per_launch'])
+  except (OSError, ValueError, KeyError, TypeError):
     return None
+
+
+def kernel_stats():
+  """Per-kernel static ISA statistics written by __graft_entry__.build() (profiles/tools/isa_stats.py)."""
+  try:
+    return json.load(open(os.path.join(ROOT, 'dgpmp2_amd', 'lib', 'kernel_stats.json')))
+  except (OSError, ValueError):
+    return {}
 
 
 def usable_cores():
@@ -80,6 +123,32 @@ def usable_cores():
   return n
 
 
+def cpu_model():
+  try:
+    for line in open('/proc/cpuinfo'):
+      if line.lower().startswith('model name'):
+        return line.split(':', 1)[1].strip()
+  except OSError:
+    pass
+  return 'unknown'
+
+
+@contextlib.contextmanager
+def quiet_fds():
+  """Silence C-level writes to stdout / stderr (MKL prints 'Intel oneMKL ERROR: Parameter 6 was incorrect on entry to DLASWP'
+  once per matrix when batched torch.inverse fails on some hosts) so that nothing precedes the JSON line."""
+  sys.stdout.flush(); sys.stderr.flush()
+  saved = [os.dup(1), os.dup(2)]
+  null = os.open(os.devnull, os.O_WRONLY)
+  try:
+    os.dup2(null, 1); os.dup2(null, 2)
+    yield
+  finally:
+    sys.stdout.flush(); sys.stderr.flush()
+    os.dup2(saved[0], 1); os.dup2(saved[1], 2)
+    for fd in saved + [null]: os.close(fd)
+
+
 def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
   """The reference's dense PyTorch-CPU op sequence (oracle/dense_torch.py, kind 'port'), fp64, all host cores, on a
   bounded sample: `chunk` of the 4096 trajectories, 1 warm-up + `steps` timed steps; scaled to whole-batch steps/s."""
@@ -92,27 +161,32 @@ def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
   B = chunk
   qc = torch.from_numpy(p.static_covs(B)[0]); ow = torch.from_numpy(p.static_covs(B)[1]); eps = torch.from_numpy(p.static_covs(B)[2])
   sdf = sdf_cpu.double().expand(B, 1, GRID, GRID)
-  ts = []
+  # does this host's MKL accept batched torch.inverse (what the reference calls, plan_layer.py:227-228)?  Probe it on a tiny
+  # batch with the C-level output silenced; if it does not, form the two explicit inverses with triangular solves against I.
   inverse_impl = 'torch.inverse'
+  with quiet_fds():
+    try:
+      t = torch.eye(N_STATES * 2 * DOF, dtype=torch.float64).expand(2, -1, -1).contiguous().triu() + 0.0
+      ok = bool(torch.isfinite(torch.inverse(t)).all())
+    except RuntimeError:
+      ok = False
+    if ok:
+      try:
+        DT.plan_layer_forward(th_hist_cpu[0][:2].double(), start_cpu[:2].double(), goal_cpu[:2].double(), sdf[:2], qc[:2], ow[:2], eps[:2], P)
+      except RuntimeError:
+        ok = False
+  if not ok:
+    inverse_impl = 'torch.linalg.solve_triangular(u, I) (torch.inverse fails in MKL on this host)'
+    DT.set_explicit_inverse('solve_triangular')
+  ts = []
   with torch.no_grad():
-    k = 0
-    while k < steps + 1:
+    for k in range(steps + 1):
       th = th_hist_cpu[k % len(th_hist_cpu)][:B].double()
       t0 = time.perf_counter()
-      try:
-        DT.plan_layer_forward(th, start_cpu[:B].double(), goal_cpu[:B].double(), sdf, qc, ow, eps, P)
-      except RuntimeError:
-        # some hosts' MKL rejects batched torch.inverse ("Parameter 6 was incorrect on entry to DLASWP" -> "Pivots given to
-        # lu_solve ..."): form the two explicit inverses with triangular solves against I instead and start over
-        if inverse_impl != 'torch.inverse': raise
-        inverse_impl = 'torch.linalg.solve_triangular(u, I) (torch.inverse fails in MKL on this host)'
-        DT.set_explicit_inverse('solve_triangular')
-        ts, k = [], 0
-        continue
+      DT.plan_layer_forward(th, start_cpu[:B].double(), goal_cpu[:B].double(), sdf, qc, ow, eps, P)
       ts.append(time.perf_counter() - t0)
-      k += 1
   t_chunk = float(np.median(ts[1:]))
-  return {'value': 1.0 / (t_chunk * (B_PER_GPU / B)), 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'kind': 'port',
+  return {'value': 1.0 / (t_chunk * (B_PER_GPU / B)), 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
           'sample': 'dense PyTorch-CPU fp64 restatement of PlanLayer.forward on %d of the 4096 trajectories, 1 warm-up + %d timed '
                     'steps, median %.3f s per %d-trajectory step, scaled by 4096/%d; explicit inverses via %s' % (B, steps, t_chunk, B, B, inverse_impl),
           'torch_threads': torch.get_num_threads()}
@@ -132,17 +206,125 @@ def cpu_blocktri(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, steps=5):
     th = a(th_hist_cpu[k % len(th_hist_cpu)])
     t0 = time.perf_counter(); BT.gn_step(p, th, st, go, sdf, nthreads=cores); ts.append(time.perf_counter() - t0)
   t = float(np.median(ts[1:]))
-  return {'value': 1.0 / t, 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'kind': 'port',
+  return {'value': 1.0 / t, 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
           'sample': 'block-tridiagonal fp64 C restatement (oracle/gn_blocktri.c), full 4096-trajectory batch, 1 warm-up + %d timed '
                     'steps, median %.4f s' % (steps, t)}
+
+
+def prewarm(launch, seconds=PREWARM_S, chunk=400):
+  """Run `launch(k)` back to back for at least `seconds` of wall time (device kept busy: one synchronisation per chunk)."""
+  t0 = time.perf_counter(); k = 0
+  while True:
+    for _ in range(chunk):
+      launch(k); k += 1
+    torch.cuda.synchronize()
+    if time.perf_counter() - t0 >= seconds: break
+  return time.perf_counter() - t0
+
+
+def time_launches(launch, reps, warm_s=0.3):
+  """Steady-clock average per-launch time in microseconds over `reps` launches, HIP events on the launch stream."""
+  prewarm(launch, warm_s, 100)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize(); e0.record()
+  for k in range(reps): launch(k)
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / reps * 1e3
+
+
+def roofline_block(bytes_per_launch, us, kernel, traffic_key=None, note=None):
+  achieved = bytes_per_launch / (us * 1e-6) / 1e9
+  r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+       'traffic': measured_traffic(traffic_key) if traffic_key else None, 'kernel': kernel, 'kernel_avg_ms': us * 1e-3,
+       'algorithmic_bytes_per_launch': bytes_per_launch}
+  if note: r['note'] = note
+  return r
+
+
+def extra_workloads(device, stream, reps=1500):
+  """BASELINE configs[2] (velocity limits) and configs[3] (non-holonomic x,y,theta robot, 512x512 SDF), and configs[1] in its
+  two other input regimes (one SDF per trajectory; per-state covariance tensors streamed): steady-clock kernel time of
+  dgp_gn_step at B = 4096 x 64 states, each with its own SURVEY 8(d) algorithmic byte count."""
+  from dgpmp2_amd import _capi
+  from dgpmp2_amd.gpmp2.plan_layer import solver_config
+  B, n = B_PER_GPU, N_STATES
+  out = {}
+
+  def run(tag, dof, G, cfg_kw, sdf=None, sdf_stride=0, covs=False, note=None, traffic_key=None):
+    d = 2 * dof
+    th0, start, goal, sdf_shared = make_inputs(B, n, G, device, seed=0, dof=dof)
+    s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=torch.float32, **cfg_kw))
+    grid = sdf_shared if sdf is None else sdf
+    sa = s.sdf_arg(grid.data_ptr(), G, G, sdf_stride)
+    dth = torch.empty_like(th0); err = torch.empty(B, device=device); eex = torch.empty(B, device=device)
+    info = torch.zeros(B, dtype=torch.int32, device=device)
+    cv, keep = None, []
+    if covs:
+      qc = torch.eye(dof, device=device).expand(B, n - 1, dof, dof).contiguous(); ow = torch.full((B, n), 1e4, device=device)
+      ep = torch.full((B, n), float(cfg_kw.get('epsilon_dist', 0.4)), device=device); keep = [qc, ow, ep]
+      cv = s.covs_arg(_capi.DGP_QC_PERSTATE, qc.data_ptr(), ow.data_ptr(), ep.data_ptr())
+    # a few GN iterations so that the timed inputs are not the straight line (hinge active on a realistic share of states)
+    ths = [th0]
+    for _ in range(3):
+      s.gn_step(B, ths[-1].data_ptr(), start.data_ptr(), goal.data_ptr(), sa, cv, dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
+      ths.append(ths[-1] + dth)
+    torch.cuda.synchronize()
+    assert int(info.abs().max()) == 0 and bool(torch.isfinite(ths[-1]).all()), tag
+    ptrs = [t.data_ptr() for t in ths]
+    sp, gp, dp, ep_, xp, ip = start.data_ptr(), goal.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr()
+    us = time_launches(lambda k: s.gn_step(B, ptrs[k % 4], sp, gp, sa, cv, dp, ep_, xp, ip, stream), reps)
+    by = algorithmic_bytes_per_trajectory(n, d, cov_tensors=covs) * B
+    lpt, c = s.launch_shape(B)
+    kname = 'gn_kernel<%d,%d,%d,float,0,%s>' % (dof, lpt, c, 'false' if covs else 'true')
+    out[tag] = {'workload': note, 'kernel_avg_us': us, 'gn_steps_per_s': 1e6 / us,
+                'roofline': roofline_block(by, us, kname, traffic_key=traffic_key)}
+    del keep
+
+  run('config3_vel_limits', 2, GRID, dict(use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0),
+      note='BASELINE configs[2]: 2D point robot + velocity-limit factors, batch=4096, 64 states, 256x256 shared SDF')
+  run('config4_xyh', 3, 512, dict(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0), traffic_key='config4_xyh',
+      note='BASELINE configs[3]: non-holonomic (x,y,theta) robot, 6-dim state, batch=4096, 64 states, 512x512 shared SDF')
+  run('learned_covariances', 2, GRID, {}, covs=True, traffic_key='learned_covariances',
+      note='configs[1] with per-state qc_inv (B,n-1,2,2), obs_w, eps tensors streamed (the learned mode; generic kernels)')
+  ps = make_per_sample_sdfs(B, GRID, device)
+  run('per_sample_sdf', 2, GRID, {}, sdf=ps, sdf_stride=GRID * GRID, traffic_key='per_sample_sdf',
+      note='configs[1] with one 256x256 SDF PER trajectory (the reference API shape sdfb (B,1,H,W); 1 GiB of grids, 4 taps per state read)')
+  del ps
+  return out
+
+
+def planner_api_rate(device, reps=300):
+  """DiffGPMP2Planner.step() through the Python mirror (reference param dicts, autograd Function, info buffer), no_grad:
+  wall microseconds per call at B = 4096 -- what a caller of the reference API sees, next to the C-ABI kernel rate."""
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  B, n = B_PER_GPU, N_STATES
+  t = lambda v: torch.tensor(v, dtype=torch.float64)
+  gp = {'Q_c_inv': torch.eye(2, dtype=torch.float64), 'K_s': t(0.01), 'K_g': t(0.01)}
+  ob = {'cost_sigma': t(0.01), 'epsilon_dist': t(0.4)}
+  pp = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
+  op = {'method': 'gauss_newton', 'reg': 0.1, 'max_iters': GN_ITERS, 'tol_err': 1e-3, 'tol_delta': 1e-4}
+  planner = DiffGPMP2Planner(gp, ob, pp, op, {'x_lims': [-5.0, 5.0], 'y_lims': [-5.0, 5.0]}, PointRobot2D(t(0.4), B, n, use_cuda=True),
+                             batch_size=B, use_cuda=True)
+  th0, start, goal, sdf = make_inputs(B, n, GRID, device)
+  sdfb = sdf.expand(B, 1, GRID, GRID)
+  with torch.no_grad():
+    for _ in range(50): planner.step(th0, start, goal, None, sdfb)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): planner.step(th0, start, goal, None, sdfb)
+    torch.cuda.synchronize()
+  us = (time.perf_counter() - t0) / reps * 1e6
+  return {'us_per_call': us, 'gn_steps_per_s': 1e6 / us, 'note': 'DiffGPMP2Planner.step() under torch.no_grad(), B=4096, wall time per call '
+          '(host-side Python + ctypes + one kernel launch); the headline `value` is the C-ABI launch rate'}
 
 
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20000)
-  ap.add_argument('--warmup', type=int, default=2000)
+  ap.add_argument('--steps', type=int, default=5000)
+  ap.add_argument('--warmup', type=int, default=500)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-extras', action='store_true', help='skip the extra workload blocks (profiling runs)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -162,7 +344,7 @@ def main():
   import __graft_entry__
   if rank == 0: __graft_entry__.build()
   if dist is not None: dist.barrier()
-  from dgpmp2_amd import _capi
+  from dgpmp2_amd import _capi, parallel
   from dgpmp2_amd.gpmp2.plan_layer import solver_config
 
   B, n, d = B_PER_GPU, N_STATES, 2 * DOF
@@ -183,30 +365,31 @@ def main():
   torch.cuda.synchronize()
   assert int(info.abs().max()) == 0 and bool(torch.isfinite(th_hist[-1]).all())
   th_ptrs = [t.data_ptr() for t in th_hist]
-  sp, gp, dp, ep, xp = start.data_ptr(), goal.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr()
+  sp, gp, dp, ep, xp, ip = start.data_ptr(), goal.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr()
 
-  def run(k0, k1):
-    for k in range(k0, k1):
-      solver.gn_step(B, th_ptrs[k % GN_ITERS], sp, gp, sdf_arg, None, dp, ep, xp, None, stream)
+  def step(k):      # exactly what PlanLayer.forward launches (plan_layer.py: _GNStep.forward), info buffer included
+    solver.gn_step(B, th_ptrs[k % GN_ITERS], sp, gp, sdf_arg, None, dp, ep, xp, ip, stream)
 
-  run(0, args.warmup)
-  gathered = [torch.empty_like(th0) for _ in range(world)] if world > 1 else None
+  prewarm_s = prewarm(step)
+  for k in range(args.warmup): step(k)
   ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
   torch.cuda.synchronize()
   if dist is not None: dist.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   ev0.record()
-  run(0, args.steps)
+  for k in range(args.steps): step(k)
   ev1.record()
-  if dist is not None:
-    dist.all_gather(gathered, th_hist[-1])          # collect final trajectories (the only collective of the path)
+  gathered = None
+  if dist is not None:      # collect final trajectories (the only collective of the path), through the product's helper
+    gathered = parallel.all_gather_trajectories(th_hist[-1], world * B)
   torch.cuda.synchronize()
   if dist is not None: dist.barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   kernel_ms = ev0.elapsed_time(ev1) / args.steps      # average per-launch duration on the launch stream
   if dist is not None:
+    assert tuple(gathered.shape) == (world * B, n, d)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -216,43 +399,44 @@ def main():
   # stays in registers, err / err_ext of every iteration written.  Reported as an extra field, never as `value`.
   tho = torch.empty_like(th0); its = torch.zeros(B, dtype=torch.int32, device=device)
   eh = torch.empty(B, GN_ITERS, device=device); eeh = torch.empty(B, GN_ITERS, device=device)
-  def run_fused(reps):
-    for _ in range(reps):
-      solver.gn_solve(B, th_ptrs[0], sp, gp, sdf_arg, None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(), eh.data_ptr(), eeh.data_ptr(),
-                      None, None, stream)
-  fused_reps = max(1, args.steps // GN_ITERS)
-  run_fused(max(1, args.warmup // GN_ITERS))
-  fe0 = torch.cuda.Event(enable_timing=True); fe1 = torch.cuda.Event(enable_timing=True)
-  torch.cuda.synchronize(); fe0.record(); run_fused(fused_reps); fe1.record(); torch.cuda.synchronize()
-  fused_ms = fe0.elapsed_time(fe1) / fused_reps
+  fused_us = time_launches(lambda k: solver.gn_solve(B, th_ptrs[0], sp, gp, sdf_arg, None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(),
+                                                     eh.data_ptr(), eeh.data_ptr(), None, ip, stream), max(20, min(400, args.steps // GN_ITERS)), warm_s=0.1)
   assert int(its.min()) == GN_ITERS
 
   if rank == 0:
     bytes_per_launch = algorithmic_bytes_per_trajectory(n, d) * B
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
     lpt, cc = solver.launch_shape(B)
     waves = (B + (64 // lpt) - 1) // (64 // lpt)
-    fp64_flops = (2 * FP64_VALU_INSTS_PER_WAVE_16x4['fma'] + FP64_VALU_INSTS_PER_WAVE_16x4['mul_add']) * 64 * waves if (lpt, cc) == (16, 4) else None
+    kname = 'gn_kernel<%d,%d,%d,float,0,true>' % (DOF, lpt, cc)
+    ks = kernel_stats().get(kname)
     out = {
         'metric': 'Gauss-Newton steps/sec (whole node), batch=4096 x 64 states, 2D point robot',
         'value': world * args.steps / elapsed, 'unit': 'GN steps/s (one step = one whole-batch step of 4096 trajectories; per-GPU batches add up)',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'prewarm_s': prewarm_s, 'ms_per_step': 1e3 * elapsed / args.steps,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[1]: 2D point robot, batch=4096 per GPU, 64 states, 256x256 shared SDF, '
-                               'static covariances, inputs = trajectories after (k mod 10) GN iterations',
+                               'static covariances, inputs = trajectories after (k mod 10) GN iterations; C-ABI dgp_gn_step launch rate '
+                               '(err, err_ext and the SPD info flags written every step, as PlanLayer.forward does)',
                    'batch_per_gpu': B, 'num_states': n, 'state_dim': d, 'sdf': [GRID, GRID], 'io_dtype': 'f32',
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
+        'rccl_ranks': world if dist is not None else 0,
         'trajectory_steps_per_s': world * args.steps * B / elapsed,
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                     'traffic': measured_traffic(), 'kernel': 'gn_kernel<DOF=2,LPT=%d,C=%d,float,STEP,static>' % solver.launch_shape(B), 'kernel_avg_ms': kernel_ms,
-                     'algorithmic_bytes_per_launch': bytes_per_launch,
-                     'note': 'HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'},
-        'valu_fp64': None if fp64_flops is None else {'achieved_tflops': fp64_flops / (kernel_ms * 1e-3) / 1e12, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
-                                                      'frac': fp64_flops / (kernel_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 'flops_per_launch': fp64_flops},
+        'roofline': roofline_block(bytes_per_launch, kernel_ms * 1e3, kname, traffic_key='gn_step',
+                                   note='HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'),
     }
-    out['fused_forward'] = {'gn_iterations_per_launch': GN_ITERS, 'ms_per_launch': fused_ms, 'us_per_gn_iteration': 1e3 * fused_ms / GN_ITERS,
-                            'gn_steps_per_s_per_gpu': GN_ITERS / (fused_ms * 1e-3),
+    if ks:
+      flops = (2 * ks['fma_f64'] + ks['mul_f64'] + ks['add_f64']) * 64 * waves
+      tf = flops / (kernel_ms * 1e-3) / 1e12
+      out['valu_fp64'] = {'achieved_tflops': tf, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS, 'frac': tf / FP64_VECTOR_PEAK_TFLOPS, 'flops_per_launch': flops,
+                          'insts_per_wave': {k: ks[k] for k in ('valu', 'fma_f64', 'mul_f64', 'add_f64', 'rcp_f64', 'dpp', 'agpr_moves')},
+                          'registers': {'vgpr': ks.get('vgpr'), 'agpr': ks.get('agpr'), 'scratch_bytes_per_lane': ks.get('scratch_bytes_per_lane')},
+                          'source': 'static ISA counts of %s from the build (dgpmp2_amd/lib/kernel_stats.json)' % kname}
+    out['fused_forward'] = {'gn_iterations_per_launch': GN_ITERS, 'ms_per_launch': fused_us * 1e-3, 'us_per_gn_iteration': fused_us / GN_ITERS,
+                            'gn_steps_per_s_per_gpu': GN_ITERS / (fused_us * 1e-6),
                             'note': 'dgp_gn_solve: the 10 GN iterations of BASELINE configs[1] in one launch (rank 0, outside the timed region)'}
+    if world == 1 and not args.no_extras:
+      out.update(extra_workloads(device, stream))
+      out['planner_step_api'] = planner_api_rate(device)
     if world == 1 and not args.no_cpu_baseline:
       hist_cpu = [t.cpu() for t in th_hist]
       out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())

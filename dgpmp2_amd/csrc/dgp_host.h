@@ -48,11 +48,13 @@ inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || 
 // T = per-wavefront time in us when every wavefront has a SIMD to itself (B = 256 column of the grid); a launch with more
 // wavefronts than the chip has SIMDs (1024) runs them in turns and each then costs ~1.25 T (shared LDS crossbar / L2).
 // More states per lane (larger C) means less arithmetic per trajectory (the local elimination is O(C) per lane while
-// every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6: the measured ratios to d = 4 --
-// x3.8, and x7.2 for the C = 4 kernels, which no longer fit the register file.
+// every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6 has its own table (T6), from the
+// B = 4096, n = 64 sweep of the d = 6 kernels (profiles/r02_shape_sweep.txt): (64,1) 110 us over 4 turns, (32,2) 45.8 us over
+// 2, (16,4) 29.0 us in one; the unmeasured entries scale the d = 4 table by the measured ratio of their C column.
 inline DgpShape choose_shape(const DgpHandle* h, int B) {
   if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
   static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
+  static const double T6[3][3] = {{5.7, 10.2, 29.0}, {11.0, 18.3, 39.0}, {21.7, 31.5, 62.7}};  // d = 6
   const int n = h->cfg.num_states;
   DgpShape best{64, 4};
   double best_cost = 1e300;
@@ -60,7 +62,7 @@ inline DgpShape choose_shape(const DgpHandle* h, int B) {
     for (int ci = 0; ci < 3; ++ci) {
       const int lpt = 16 << li, c = 1 << ci;
       if (lpt * c < n) continue;
-      const double t = T4[li][ci] * (h->cfg.dof == 3 ? (c == 4 ? 7.2 : 3.8) : 1.0);
+      const double t = h->cfg.dof == 3 ? T6[li][ci] : T4[li][ci];
       const double waves = (double)((B + (64 / lpt) - 1) / (64 / lpt));
       const double turns = 1.25 * waves / 1024.0;
       const double cost = t * (turns > 1.0 ? turns : 1.0);
@@ -159,11 +161,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Fill the per-call part of the kernel arguments; returns DGP_OK or an error code.
 inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
-                     const DgpCovs* covs, dgp::GnParams& p) {
+                     const DgpCovs* covs, dgp::GnParams& p, bool sdf_optional = false) {
   if (!h) return fail(DGP_EINVAL, "null handle");
   if (batch <= 0) return fail(DGP_EINVAL, "batch must be positive, got %d", batch);
   if (!th || !start || !goal) return fail(DGP_EINVAL, "th/start/goal must be non-null device pointers");
-  if (!sdf || !sdf->data) return fail(DGP_EINVAL, "sdf must be non-null");
+  static const DgpSdf no_sdf = {nullptr, 2, 2, 0};      // dgp_eval_errors without obstacle outputs: no grid is read
+  if (sdf_optional && (!sdf || !sdf->data)) sdf = &no_sdf;
+  else if (!sdf || !sdf->data) return fail(DGP_EINVAL, "sdf must be non-null");
   if (sdf->rows < 1 || sdf->cols < 1) return fail(DGP_EINVAL, "sdf grid must be at least 1x1, got %dx%d", sdf->rows, sdf->cols);
   if (sdf->cols < 2) return fail(DGP_EUNSUPPORTED, "sdf grids with a single column are not implemented (the taps are fetched as column pairs)");
   if (sdf->batch_stride < 0) return fail(DGP_EINVAL, "negative sdf batch stride");
@@ -213,7 +217,10 @@ inline int fill_solve(const DgpHandle* h, int32_t batch, const void* th_init, co
 
 inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                      const DgpCovs* covs, void* err, void* err_ext, void* unw_sg, void* unw_gp, void* unw_obs, dgp::GnParams& p) {
-  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  const bool no_grid = !sdf || !sdf->data;
+  if (no_grid && (err || err_ext || unw_obs))
+    return fail(DGP_EINVAL, "sdf may be NULL only when err, err_ext and unw_obs (the outputs that read the grid) are NULL");
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p, /*sdf_optional=*/true);
   if (rc != DGP_OK) return rc;
   p.err = err; p.err_ext = err_ext; p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
   p.vec_io = aligned16(th) ? 1 : 0;

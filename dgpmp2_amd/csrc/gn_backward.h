@@ -16,6 +16,8 @@
 
 namespace dgp {
 
+enum { kMaxXcds = 8 };               // XCDs (each with its own, mutually non-coherent L2) on a gfx950 device
+
 struct GnGradParams {
   const void *dtheta;                 // dtheta of the forward pass (B,n,d)
   const void *g_dtheta, *g_err_ext;   // cotangents; either may be null (= 0)
@@ -210,8 +212,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         g_w = u * rho;
         if (gp.g_sdf) {
           IO* gs = (IO*)gp.g_sdf + b * gp.g_sdf_bstride;
-          const bool local = gp.g_sdf_copies > 1;
-          if (local) gs += (int64_t)(cx.xcc_id() % gp.g_sdf_copies) * ((int64_t)p.sdf_rows * p.sdf_cols);
+          // XCD-local (workgroup-scope) atomics are only sound when no two XCDs share a copy: gfx950 has at most 8 XCDs
+          // (XCC_ID 0..7), so with >= 8 copies xcc_id % copies is unique per XCD; fewer copies still spread the same-address
+          // contention but two non-coherent L2s may then target one copy -> device-scope atomics
+          const bool local = gp.g_sdf_copies >= kMaxXcds;
+          if (gp.g_sdf_copies > 1) gs += (int64_t)(cx.xcc_id() % gp.g_sdf_copies) * ((int64_t)p.sdf_rows * p.sdf_cols);
           const double wa = tp.wjc * tp.wja, wb = tp.wjd * tp.wja, wc = tp.wjc * tp.wjb, wd = tp.wjd * tp.wjb;
           cx.atomic_add(gs + tp.i11, (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa), local);
           cx.atomic_add(gs + tp.i21, (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb), local);

@@ -1800,7 +1800,12 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
 #pragma unroll
   for (int a = 0; a < D; ++a) x_next[a] = nb.hi(x[0][a]);
   LaneFactors<C> lf;
-  lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
+  if (p.sdf) {               // wave-uniform.  No grid (host-checked: no output that depends on it was requested): no obstacle factors
+    lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; ++k) { lf.ow[k] = 0.0; lf.oc[k] = 0.0; lf.ohx[k] = 0.0; lf.ohy[k] = 0.0; }
+  }
   const bool stat = (p.qc_mode == QC_STATIC);
   Sym<D> Qown;
   fixed_Qinv<DOF>(p, Qown);

@@ -178,7 +178,7 @@ class DiffGPMP2Planner(nn.Module):
     B = th_initb.shape[0]
     dt, dev = th_initb.dtype, th_initb.device
     solver = pl._solver(dt)
-    sdf_arg, keep = pl._sdf_arg(solver, sdfb, dt)
+    sdf_arg, keep = pl._sdf_arg(solver, sdfb, dt, B)
     th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
     th_out = torch.empty_like(th0)
     iters = torch.empty(B, dtype=torch.int32, device=dev)
@@ -186,8 +186,9 @@ class DiffGPMP2Planner(nn.Module):
     eeh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
     ef = torch.empty(B, dtype=dt, device=dev)
     info = torch.empty(B, dtype=torch.int32, device=dev)
-    solver.gn_solve(B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sdf_arg, None, max_iters, tol_delta, th_out.data_ptr(),
-                    iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _stream())
+    with torch.cuda.device(dev):
+      solver.gn_solve(B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sdf_arg, None, max_iters, tol_delta, th_out.data_ptr(),
+                      iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _stream())
     pl.last_info = info
     pl._last = (st, go, None, None, None)
     jb = iters.cpu().tolist()                       # synchronises

@@ -19,6 +19,7 @@ import ctypes
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from .. import _capi
 
@@ -61,6 +62,13 @@ def _require_cuda(t, name):
     raise RuntimeError('dgpmp2_amd: `%s` must be a CUDA/ROCm tensor (got device %s); this build has no CPU path' % (name, t.device))
 
 
+def _same_device(ref, **named):
+  """Every tensor argument must live on the device of `thb`: the kernel receives raw addresses."""
+  for name, t in named.items():
+    if t is not None and torch.is_tensor(t) and t.device != ref.device:
+      raise RuntimeError('dgpmp2_amd: `%s` is on %s but `thb` is on %s; all inputs of one call must share a device' % (name, t.device, ref.device))
+
+
 class _GNStep(torch.autograd.Function):
   """dtheta, err, err_ext = GN step; backward through dgp_gn_step_backward (adjoint block-tridiagonal solve)."""
 
@@ -68,15 +76,17 @@ class _GNStep(torch.autograd.Function):
   def forward(ctx, layer, static, th, start, goal, sdf, qc, ow, eps):
     B = th.shape[0]
     solver = layer._solver(th.dtype)
-    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype)
+    _same_device(th, startb=start, goalb=goal, sdfb=sdf, qc_inv_trajb=qc, obscov_inv_trajb=ow, eps_trajb=eps)
+    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
     covs, cov_keep = layer._covs_arg(solver, qc, ow, eps, th.dtype, B, static)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
     err = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
     eex = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
     info = torch.empty(B, dtype=torch.int32, device=th.device)
-    solver.gn_step(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, dth.data_ptr(), err.data_ptr(), eex.data_ptr(),
-                   info.data_ptr(), _stream())
+    with torch.cuda.device(th.device):      # the launch goes to the CURRENT device's stream: make that the tensors' device
+      solver.gn_step(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, dth.data_ptr(), err.data_ptr(), eex.data_ptr(),
+                     info.data_ptr(), _stream())
     layer.last_info = info
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
@@ -86,15 +96,17 @@ class _GNStep(torch.autograd.Function):
     ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)
     ctx.keep = (sdf_keep, cov_keep)
     ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
+    ctx.set_materialize_grads(False)              # an unused output arrives as None: no adjoint solve for an err_ext-only loss
     return dth, err, eex
 
   @staticmethod
+  @once_differentiable                            # the backward is a raw kernel: double backward raises instead of returning zeros
   def backward(ctx, g_dth, g_err, g_eex):
     layer = ctx.layer
     th, start, goal, sdf, qc, ow, eps, dth = ctx.saved_tensors
     B, n, d = th.shape
     solver = layer._solver(th.dtype)
-    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype)
+    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
     covs, cov_keep = layer._covs_arg(solver, qc, ow, eps, th.dtype, B, ctx.static)
     need = (None,) + tuple(ctx.needs_input_grad[2:])      # -> need[1..7] = th, start, goal, sdf, qc, ow, eps
     g_dth = None if g_dth is None else g_dth.contiguous().to(th.dtype)
@@ -111,9 +123,10 @@ class _GNStep(torch.autograd.Function):
     g_ow = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[6] and covs.obs_w) else None
     g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[7] and covs.eps) else None
     p = lambda t: None if t is None else t.data_ptr()
-    solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
-                            p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream(),
-                            g_sdf_copies=copies)
+    with torch.cuda.device(th.device):
+      solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
+                              p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream(),
+                              g_sdf_copies=copies)
     if g_sdf is not None and shared:
       g_sdf = g_sdf.sum(0, keepdim=True)
     if g_sdf is not None and shared and sdf.shape[0] != 1:
@@ -179,12 +192,18 @@ class PlanLayer(nn.Module):
       self._solvers[code] = s
     return self._solvers[code]
 
-  def _sdf_arg(self, solver, sdfb, dtype):
-    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35).  An expand()ed / single grid is passed as shared."""
+  def _sdf_arg(self, solver, sdfb, dtype, B):
+    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35).  An expand()ed / single grid is passed as shared.
+    None: no grid (dgp_eval_errors without obstacle outputs only)."""
+    if sdfb is None:
+      return solver.sdf_arg(None, 2, 2, 0), None
     _require_cuda(sdfb, 'sdfb')
     if sdfb.dim() != 4: raise ValueError('sdfb must be (B,1,H,W)')
     H, W = sdfb.shape[-2], sdfb.shape[-1]
     shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
+    if not shared and sdfb.shape[0] != B:       # a per-sample grid tensor with fewer grids than trajectories would be read out of bounds
+      raise ValueError('sdfb has %d grids for a batch of %d trajectories (expected %d, or 1 / an expand()ed view for a shared grid)'
+                       % (sdfb.shape[0], B, B))
     t = sdfb[0:1, 0:1] if shared else sdfb[:, 0:1]
     if t.dtype != dtype or not t.is_contiguous():
       t = t.to(dtype).contiguous()
@@ -244,13 +263,18 @@ class PlanLayer(nn.Module):
     return _GNStep.apply(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
 
   def _eval(self, thb, sdfb, startb, goalb, qc, ow, eps):
+    """-> [err, err_ext, start_goal_error, gp_error, obs_error]; without a grid (sdfb None) the three that read it are None."""
     B = thb.shape[0]
     solver = self._solver(thb.dtype)
-    sdf_arg, k1 = self._sdf_arg(solver, sdfb, thb.dtype)
+    _same_device(thb, startb=startb, goalb=goalb, sdfb=sdfb, qc_inv_trajb=qc, obscov_inv_trajb=ow, eps_trajb=eps)
+    sdf_arg, k1 = self._sdf_arg(solver, sdfb, thb.dtype, B)
     covs, k2 = self._covs_arg(solver, qc, ow, eps, thb.dtype, B, self.static_flags(qc, ow, eps))
-    outs = [torch.empty(B, 1, 1, dtype=thb.dtype, device=thb.device) for _ in range(5)]
+    want = [sdfb is not None, sdfb is not None, True, True, sdfb is not None]
+    outs = [torch.empty(B, 1, 1, dtype=thb.dtype, device=thb.device) if w else None for w in want]
     thc, stc, goc = thb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
-    solver.eval_errors(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, *[o.data_ptr() for o in outs], stream=_stream())
+    with torch.cuda.device(thb.device):
+      solver.eval_errors(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, *[None if o is None else o.data_ptr() for o in outs],
+                         stream=_stream())
     return outs
 
   def errors(self, thb, startb, goalb, sdfb, qc_inv_trajb=None, obscov_inv_trajb=None, eps_trajb=None):
@@ -282,12 +306,12 @@ class PlanLayer(nn.Module):
   def start_goal_error(self, thb):
     """plan_layer.py:384-388 (unweighted)."""
     st, go, qc, ow, eps = self._last_or_raise()
-    return self._eval(thb, self._dummy_sdf(thb), st, go, None, None, None)[2]
+    return self._eval(thb, None, st, go, None, None, None)[2]
 
   def gp_error(self, thb):
     """plan_layer.py:374-377 (unweighted, mean over the GP factors)."""
     st, go, qc, ow, eps = self._last_or_raise()
-    return self._eval(thb, self._dummy_sdf(thb), st, go, None, None, None)[3]
+    return self._eval(thb, None, st, go, None, None, None)[3]
 
   def obs_error(self, thb, sdfb):
     """plan_layer.py:379-382 (unweighted, mean over states; uses the eps of the last forward())."""
@@ -299,6 +323,3 @@ class PlanLayer(nn.Module):
     st, go, qc, ow, eps = self._last_or_raise()
     o = self._eval(thb, sdfb, st, go, None, None, eps)
     return o[2], o[3], o[4]
-
-  def _dummy_sdf(self, thb):
-    return torch.zeros(1, 1, 1, 1, dtype=thb.dtype, device=thb.device)

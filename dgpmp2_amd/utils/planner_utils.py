@@ -18,13 +18,15 @@ def check_convergence(dtheta, j, err_delta, tol_err, tol_delta, max_iters, metho
 
 
 def check_convergence_batch(dthetab, j, err_delta, tol_err, tol_delta, max_iters, method='gauss_newton', device=None):
-  """Per-sample convergence mask (B,1,1) uint8.  As in the reference (planner_utils.py:24-27) the second torch.where
-  overwrites the first, so only the err_delta criterion (and max_iters) survives."""
+  """Per-sample convergence mask (B,1,1).  As in the reference (planner_utils.py:24-27) the second torch.where overwrites the
+  first, so only the err_delta criterion survives: int64 ones/zeros from torch.where, or -- once j >= max_iters -- all ones
+  as uint8 (the reference's torch.ones(...).byte(), created on the CPU whatever `device` says; here on dthetab's device)."""
   B = dthetab.shape[0]
+  dev = dthetab.device if device is None else device
   err_delta_norm = torch.norm(err_delta.reshape(B, -1), dim=1, p=2)
-  conv = (err_delta_norm < tol_err).to(torch.uint8)
+  conv = torch.where(err_delta_norm < tol_err, torch.tensor(1, device=dev), torch.tensor(0, device=dev))
   if j >= max_iters:
-    conv = torch.ones(B, dtype=torch.uint8, device=dthetab.device)
+    conv = torch.ones(B, 1, 1, dtype=torch.uint8, device=dthetab.device)
   return conv.view(B, 1, 1)
 
 

@@ -137,7 +137,9 @@ int dgp_gn_solve(const DgpHandle* h, int32_t batch,
 
 /* Factor evaluation only == PlanLayer.error_batch / error_ext_batch (plan_layer.py:273-345) and the
  * unweighted errors of DiffGPMP2Planner.unweighted_errors_batch (diff_gpmp2_planner.py:229-237 ->
- * plan_layer.py:374-388).  Any output may be NULL.  err, err_ext, unw_sg, unw_gp, unw_obs: (B). */
+ * plan_layer.py:374-388).  Any output may be NULL.  err, err_ext, unw_sg, unw_gp, unw_obs: (B).
+ * `sdf` (or sdf->data) may be NULL when err, err_ext and unw_obs are all NULL: PlanLayer.gp_error(thb) and
+ * start_goal_error(thb) (plan_layer.py:374-377, :384-388) take no grid, and then none is read. */
 int dgp_eval_errors(const DgpHandle* h, int32_t batch,
                     const void* th, const void* start, const void* goal,
                     const DgpSdf* sdf, const DgpCovs* covs,
@@ -151,9 +153,10 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch,
  * (same shapes), dL/d(qc_inv) (shape of the qc_mode), dL/d(obs_w), dL/d(eps) (B,n), and ACCUMULATES dL/d(sdf)
  * into g_sdf with atomics (layout given by g_sdf_batch_stride; the caller zeroes it).  NULL outputs are skipped.
  * g_sdf_copies: 1, or (shared grid, g_sdf_batch_stride == 0, only) the number of PARTIAL grids laid out back to back
- * in g_sdf: every XCD of the GPU accumulates into copy (xcc_id % g_sdf_copies) with XCD-local L2 atomics instead of
- * device-scope ones (the per-XCD L2s are not coherent with each other), and the caller sums the copies afterwards.
- * 8 copies remove the cross-XCD contention of a shared grid (2.5x faster backward at batch 4096). */
+ * in g_sdf: a wavefront accumulates into copy (xcc_id % g_sdf_copies) and the caller sums the copies afterwards.  With
+ * g_sdf_copies >= 8 (gfx950 has at most 8 XCDs, so no two XCDs share a copy) the accumulation uses XCD-local L2 atomics
+ * instead of device-scope ones (the per-XCD L2s are not coherent with each other; every copy is then only ever touched
+ * by ONE L2 during the kernel); with 2..7 copies the atomics stay device-scope and the copies only spread contention. */
 int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          const void* th, const void* start, const void* goal,
                          const DgpSdf* sdf, const DgpCovs* covs,

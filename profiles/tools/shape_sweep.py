@@ -46,7 +46,10 @@ if __name__ == '__main__':
   for B in (4096, 32768):
     for shape in ('64,1', '32,2', '16,4', '64,2', '64,4', '32,4', None):
       print(json.dumps(time_step(B, 64, 256, torch.float32, 500 if B == 4096 else 100, shape)), flush=True)
-  for shape in ('64,1', '32,2', '16,4', None):
-    print(json.dumps(time_step(4096, 64, 512, torch.float32, 200, shape, dof=3)), flush=True)
+  for B in (256, 4096, 32768):       # d = 6 (BASELINE configs[3]): B = 256 gives the per-wavefront time T6 of dgp_host::choose_shape
+    for shape in ('64,1', '32,2', '16,4', '64,2', '32,4', '64,4', None):
+      print(json.dumps(time_step(B, 64, 512, torch.float32, 200 if B <= 4096 else 40, shape, dof=3)), flush=True)
+  for (n, shape) in ((16, '16,1'), (32, '16,2'), (32, '32,1'), (101, '32,4'), (101, '64,2'), (16, None), (32, None), (101, None)):
+    print(json.dumps(time_step(4096, n, 512, torch.float32, 200, shape, dof=3)), flush=True)
   for (n, shape) in ((32, '32,1'), (32, '16,2'), (16, '16,1'), (101, '64,2'), (101, '32,4'), (128, '64,2'), (128, '32,4'), (256, '64,4')):
     print(json.dumps(time_step(4096, n, 256, torch.float32, 300, shape)), flush=True)

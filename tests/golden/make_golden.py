@@ -404,5 +404,93 @@ def g3_c4_xyh():
        err=torch.cat(errs, 0), M=pl.M)
 
 
+# ------------------------------------------------------------------------------------------------
+# G6: caller-side helpers and the data path
+#   utils/planner_utils.py:18-56 (check_convergence_batch incl. its overwritten-where quirk, straight_line_traj[b]),
+#   utils/sdf_utils.py:6-21 (sdf_2d) and datasets/utils.py:4-18 (the dataset tools' sdf_2d), datasets/planning_dataset.py:15-69
+#   reading a mini dataset written with the reference's own writer conventions
+#   (generate_2d_im_dataset.py:84-89: plt.imsave(cmap=gray) + np.save(sdf); generate_optimal_paths_gpmp2.py:198-206:
+#   np.savez(start, goal, th_opt) + yaml.dump(meta)).
+# ------------------------------------------------------------------------------------------------
+def g6_helpers():
+  from diff_gpmp2.utils.planner_utils import check_convergence_batch, check_convergence, straight_line_traj
+  import contextlib, io
+  out = {}
+  g = torch.Generator().manual_seed(61)
+  B = 6
+  dthb = torch.randn(B, 16, 4, generator=g) * torch.tensor([1e-6, 1e-3, 1.0, 1e-6, 1e-3, 1.0]).view(B, 1, 1)
+  errd = torch.randn(B, 1, 1, generator=g) * torch.tensor([1e-5, 1.0, 1e-5, 1.0, 1e-5, 1.0]).view(B, 1, 1)
+  out.update(ccb_dth=dthb, ccb_errd=errd, ccb_tol_err=1e-3, ccb_tol_delta=1e-4, ccb_max_iters=10)
+  with contextlib.redirect_stdout(io.StringIO()):
+    for j in (3, 10, 11):
+      c = check_convergence_batch(dthb, j, errd, 1e-3, 1e-4, 10)
+      out['ccb_conv_j%d' % j] = N(c).astype(np.int64); out['ccb_dtype_j%d' % j] = str(c.dtype); out['ccb_shape_j%d' % j] = np.asarray(c.shape)
+    out['cc_scalar'] = np.asarray([[int(check_convergence(dthb[b], j, errd[b], 1e-3, 1e-4, 10)) for j in (3, 10)] for b in range(B)])
+  s, e = rand_start_goal(5, seed=62)
+  for n, dof in ((32, 2), (7, 2), (64, 3)):
+    ss = torch.cat([s[:, :, :2], torch.rand(5, 1, dof - 2, generator=g)], -1) if dof > 2 else s[:, :, :2]
+    ee = torch.cat([e[:, :, :2], torch.rand(5, 1, dof - 2, generator=g)], -1) if dof > 2 else e[:, :, :2]
+    out['sl_start_n%d_dof%d' % (n, dof)] = ss; out['sl_goal_n%d_dof%d' % (n, dof)] = ee
+    out['sl_thb_n%d_dof%d' % (n, dof)] = straight_line_trajb(ss, ee, 10.0, n - 1, dof)
+    out['sl_th1_n%d_dof%d' % (n, dof)] = straight_line_traj(ss[0], ee[0], 10.0, n - 1, dof)
+  # sdf_2d on the real map of BASELINE config 1 and on a small random occupancy image, both padding conventions
+  im5 = plt.imread(os.path.join(REF, 'diff_gpmp2/env/simple_2d/5.png'))
+  if im5.ndim > 2: im5 = np.dot(im5[..., :3], [0.299, 0.587, 0.114])
+  rs = np.random.RandomState(63)
+  imr = (rs.rand(24, 40) > 0.3).astype(np.float64)
+  out.update(sdf_im5=im5.astype(np.float32), sdf_im5_pad1=sdf_2d(im5, res=10.0 / im5.shape[0]), sdf_imr=imr,
+             sdf_imr_pad0=sdf_2d(imr, padlen=0, res=0.25), sdf_imr_pad2=sdf_2d(imr, padlen=2, res=1.0))
+  save('g6_helpers', **out)
+
+
+def g6_dataset():
+  """Writes tests/golden/mini_dataset/ with the reference's writer conventions and stores what the REFERENCE PlanningDataset
+  reads back from it (shim: yaml.load without a Loader argument, planning_dataset.py:32, fails on PyYAML >= 6)."""
+  import shutil, yaml
+  import matplotlib.cm as cm
+  from diff_gpmp2.datasets.utils import sdf_2d as ds_sdf_2d
+  root = os.path.join(HERE, 'mini_dataset')
+  shutil.rmtree(root, ignore_errors=True)
+  folder = os.path.join(root, 'train')
+  os.makedirs(os.path.join(folder, 'im_sdf'))
+  n, num_envs, ppe = 16, 2, 2
+  planner = make_planner(1, n, max_iters=5)
+  for i, name in enumerate(('5.png', '7.png')):
+    im = plt.imread(os.path.join(REF, 'diff_gpmp2/env/simple_2d', name))
+    if im.ndim > 2: im = np.dot(im[..., :3], [0.299, 0.587, 0.114])
+    im = np.ascontiguousarray(im[::4, ::4])                                        # 50 x 50: keeps the fixture small
+    sdf = ds_sdf_2d(im) * (10.0 / im.shape[0])                                     # generate_2d_im_dataset.py:84 (pad 1) in metres
+    plt.imsave(os.path.join(folder, 'im_sdf', '%d_im.png' % i), im, cmap=cm.gray)    # generate_2d_im_dataset.py:88
+    np.save(os.path.join(folder, 'im_sdf', '%d_sdf.npy' % i), sdf)                   # :89
+    for j in range(ppe):
+      s, e = rand_start_goal(1, seed=70 + 2 * i + j)
+      th_init = straight_line_trajb(s[:, :, :2], e[:, :, :2], 10.0, n - 1, 2)
+      imp = torch.tensor(im); sdfp = torch.tensor(sdf)
+      import contextlib, io
+      with contextlib.redirect_stdout(io.StringIO()):
+        res = planner.forward(th_init, s, e, imp.unsqueeze(0).unsqueeze(0), sdfp.unsqueeze(0).unsqueeze(0))
+      os.makedirs(os.path.join(folder, 'opt_trajs_gpmp2'), exist_ok=True)
+      np.savez(os.path.join(folder, 'opt_trajs_gpmp2', 'env_%d_prob_%d' % (i, j)), start=N(s)[0, 0], goal=N(e)[0, 0],
+               th_opt=N(res[0])[0])                                                # generate_optimal_paths_gpmp2.py:192-198
+  with open(os.path.join(folder, 'meta.yaml'), 'w') as fp:                         # generate_optimal_paths_gpmp2.py:201-206
+    yaml.dump({'num_envs': num_envs, 'probs_per_env': ppe, 'env_params': ENV, 'im_size': 50}, fp)
+  _load = yaml.load
+  yaml.load = lambda f, Loader=None: _load(f, Loader=Loader or yaml.FullLoader)
+  import contextlib, io
+  try:
+    from diff_gpmp2.datasets.planning_dataset import PlanningDataset
+    with contextlib.redirect_stdout(io.StringIO()):
+      ds = PlanningDataset(root, mode='train')
+      sub = PlanningDataset(root, mode='train', num_envs=1, num_env_probs=1)
+    out = {'len': len(ds), 'len_sub': len(sub)}
+    for k in range(len(ds)):
+      smp = ds[k]
+      for key in ('im', 'sdf', 'start', 'goal', 'th_opt'):
+        out['s%d_%s' % (k, key)] = smp[key]; out['s%d_%s_dtype' % (k, key)] = str(smp[key].dtype)
+  finally:
+    yaml.load = _load
+  save('g6_dataset', **out)
+
+
 if __name__ == '__main__':
-  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh()
+  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset()

@@ -102,12 +102,15 @@ class Backend(object):
     _, th_p = self.to_dev(th, io)
     _, st_p = self.to_dev(start, io)
     _, go_p = self.to_dev(goal, io)
-    sdf = np.asarray(sdf)
-    assert sdf.ndim == 4 and sdf.shape[1] == 1
-    shared = sdf.shape[0] == 1 and B >= 1
-    _, sdf_p = self.to_dev(sdf, io)
-    H, W = sdf.shape[-2], sdf.shape[-1]
-    sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
+    if sdf is None:              # dgp_eval_errors without obstacle outputs: no grid
+      sdf_arg = solver.sdf_arg(None, 2, 2, 0)
+    else:
+      sdf = np.asarray(sdf)
+      assert sdf.ndim == 4 and sdf.shape[1] == 1
+      shared = sdf.shape[0] == 1 and B >= 1
+      _, sdf_p = self.to_dev(sdf, io)
+      H, W = sdf.shape[-2], sdf.shape[-1]
+      sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
     mode = _capi.DGP_QC_STATIC if qc is None else (_capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE)
     _, qc_p = self.to_dev(qc, io)
     _, ow_p = self.to_dev(ow, io)
@@ -141,7 +144,8 @@ class Backend(object):
   def eval_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
     """-> err, err_ext, unw_sg, unw_gp, unw_obs  (each (B,))"""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
-    outs = [self.empty((B,), io) for _ in range(5)]
+    want = [sdf is not None, sdf is not None, True, True, sdf is not None]      # without a grid only unw_sg / unw_gp may be requested
+    outs = [self.empty((B,), io) if w else (None, None) for w in want]
     solver.eval_errors(B, th_p, st_p, go_p, sdf_arg, covs, *[o[1] for o in outs], stream=self.stream())
     return tuple(self.to_np(o[0]) for o in outs)
 

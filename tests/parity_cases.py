@@ -2,13 +2,13 @@
 and the GPU tests proper (tests/test_hip_parity.py, -m gpu).  Each case feeds the same seeded inputs to a
 harness.Backend and to the numpy oracle / golden fixtures and compares.
 
-Tolerances (max-norm relative error, conftest.rel_err):
+Tolerances (max-norm relative error over the whole tensor, conftest.rel_err, AND per trajectory, conftest.rel_err_per_traj):
   fp64 I/O : 1e-9   (fp64 block-PCR vs fp64 Cholesky + explicit inverses; cond(Lambda) ~ 1e4..2e5)
   fp32 I/O : 1e-5   (BASELINE.json north_star: "within 1e-5 relative fp32"); inputs are rounded to fp32
                     first and the oracle is fed exactly those rounded values.
 """
 import numpy as np
-from conftest import rel_err
+from conftest import rel_err, rel_err_per_traj
 from oracle import gpmp2_oracle as O
 
 TOL = {'f64': 1e-9, 'f32': 1e-5}
@@ -38,11 +38,13 @@ def check_step(be, p, th, start, goal, sdf, io, qc=None, ow=None, eps=None, q_fu
   r_dth, r_err, r_eex = O.plan_layer_forward(th, start, goal, sdf_full, o_qc, o_ow, o_eps, p, q_full=q_full)
   assert np.all(info == 0), tag
   assert rel_err(dth, r_dth) < TOL[io], (tag, rel_err(dth, r_dth))
+  assert rel_err_per_traj(dth, r_dth) < TOL[io], (tag, 'per trajectory', rel_err_per_traj(dth, r_dth))
   assert rel_err(err, r_err.reshape(-1)) < TOL_ERR[io], (tag, rel_err(err, r_err.reshape(-1)))
   assert rel_err(eex, r_eex.reshape(-1)) < TOL_ERR[io], (tag, rel_err(eex, r_eex.reshape(-1)))
   if ref is not None and io == 'f64':      # golden straight from the reference
     g_dth, g_err, g_eex = ref
     assert rel_err(dth, g_dth) < TOL[io], (tag, 'golden', rel_err(dth, g_dth))
+    assert rel_err_per_traj(dth, g_dth) < TOL[io], (tag, 'golden, per trajectory', rel_err_per_traj(dth, g_dth))
     if g_err is not None: assert rel_err(err, np.reshape(g_err, -1)) < TOL_ERR[io], (tag, 'golden err')
     if g_eex is not None: assert rel_err(eex, np.reshape(g_eex, -1)) < TOL_ERR[io], (tag, 'golden err_ext')
   return dth, err, eex
@@ -164,6 +166,15 @@ def case_eval_errors(be, golden, io):
   if io == 'f64':
     assert rel_err(err, g['err_hist'][3].reshape(-1)) < t
     assert rel_err(ugp, g['unw_gp'].reshape(-1)) < t and rel_err(uobs, g['unw_obs'].reshape(-1)) < t
+  # PlanLayer.gp_error(thb) / start_goal_error(thb) take no grid (plan_layer.py:374-377, :384-388): sdf == NULL, same numbers
+  _, _, usg2, ugp2, _ = be.eval_errors(p, th, start, goal, None, io=io)
+  assert np.array_equal(usg2, usg) and np.array_equal(ugp2, ugp)
+  from dgpmp2_amd import _capi
+  import pytest
+  solver = _capi.Solver(__import__('harness').config_from_oracle(p, io), api=be.api)
+  with pytest.raises(_capi.DgpError) as e:          # ... but an output that reads the grid cannot be requested without one
+    solver.eval_errors(1, 0x1000, 0x1000, 0x1000, solver.sdf_arg(None, 2, 2, 0), None, err=0x1000)
+  assert e.value.code == _capi.DGP_EINVAL
 
 
 def case_solve(be, golden, io):
@@ -347,6 +358,10 @@ def case_shared_sdf_gradient_partial_copies(be, golden, io):
   if be.kind == 'hip' and reps > 8: assert (np.abs(r8['sdf']).reshape(8, -1).max(1) > 0).sum() >= 2      # really spread over XCDs
   assert rel_err(r8['sdf'].sum(0, keepdims=True), r1['sdf']) < (1e-11 if io == 'f64' else 2e-5)
   assert np.array_equal(r8['th'], r1['th'])
+  # fewer copies than XCDs: two XCDs share a copy, so the kernel must stay on device-scope atomics (no lost updates)
+  r3 = be.backward(p, th, st, go, sdf, dth, gbar, None, io=io, sdf_copies=3)
+  assert r3['sdf'].shape[0] == 3
+  assert rel_err(r3['sdf'].sum(0, keepdims=True), r1['sdf']) < (1e-11 if io == 'f64' else 2e-5)
 
 
 def case_tiny_and_odd_sizes(be, golden, io):

@@ -137,3 +137,73 @@ def test_hip_rejects_too_long_trajectory(be):
   with pytest.raises(_capi.DgpError) as e:
     _capi.Solver(harness.config_from_oracle(PC.P2d(257), 'f64'))
   assert e.value.code == _capi.DGP_EUNSUPPORTED
+
+
+@pytest.mark.parametrize('covs', ['static', 'perstate'])
+@pytest.mark.parametrize('shape', ['16,4', '32,2', '64,1', '32,4', '64,2', '64,4'])
+def test_hip_d6_every_launch_shape(be, shape, covs, monkeypatch):
+  """Non-holonomic (x,y,theta) robot, d = 6, n = 64: every launch shape that covers 64 states (the library picks (16,4) for
+  BASELINE configs[3]; the others serve other lengths / batch sizes), pinned with DGP_FORCE_SHAPE, static and per-state
+  covariance kernels, ragged batch, every trajectory against oracle/gn_blocktri.c."""
+  from oracle import blocktri as BT
+  monkeypatch.setenv('DGP_FORCE_SHAPE', shape)
+  B, n, G, d = 37, 64, 128, 6
+  rs = np.random.RandomState(31)
+  p = O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)
+  start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+  start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, 2] = np.pi / 2
+  th = O.straight_line_trajb(start[:, :, :3], goal[:, :, :3], 10.0, n - 1, 3) + rs.randn(B, n, d) * 0.05
+  sdf = O.circles_sdf(G, O.C2_CIRCLES)[None, None]
+  qc = ow = eps = None
+  if covs == 'perstate':
+    a = rs.randn(B, n - 1, 3, 3) * 0.3
+    qc = a @ a.transpose(0, 1, 3, 2) + 0.5 * np.eye(3)
+    ow = rs.uniform(0.25, 1.75, (B, n)) * 1e4; eps = rs.uniform(0.1, 0.4, (B, n))
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc, ow=ow, eps=eps, io='f64')
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=ow, eps=eps, nthreads=2)
+  assert not info.any() and not c_info.any() and np.all(np.isfinite(dth))
+  per_traj = np.abs(dth - c_dth).reshape(B, -1).max(1) / np.abs(c_dth).reshape(B, -1).max(1)
+  assert per_traj.max() < 1e-9, per_traj.max()
+  assert rel_err(err, c_err) < 1e-11 and rel_err(eex, c_eex) < 1e-11
+
+
+def _per_sample_circle_sdfs(B, G, seed=1):
+  """SURVEY 8(d) per-sample mode: three circles per trajectory, centres ~ U(-3.5,3.5)^2, radii ~ U(0.4,1.0)."""
+  rs = np.random.RandomState(seed)
+  c = rs.uniform(-3.5, 3.5, (B, 3, 2)); r = rs.uniform(0.4, 1.0, (B, 3))
+  xs = np.linspace(-5.0, 5.0, G); ys = np.linspace(5.0, -5.0, G)
+  out = np.empty((B, 1, G, G), dtype=np.float32)
+  for b in range(B):
+    dx = xs[None, None, :] - c[b, :, 0, None, None]; dy = ys[None, :, None] - c[b, :, 1, None, None]
+    out[b, 0] = (np.sqrt(dx * dx + dy * dy) - r[b, :, None, None]).min(0)
+  return out
+
+
+def test_hip_c2_full_size_per_sample_sdf(be):
+  """BASELINE config 2 in the reference's API shape, sdfb (B,1,H,W) with one DISTINCT 256x256 grid per trajectory (B = 4096:
+  1 GiB of fp32 grids): every trajectory against oracle/gn_blocktri.c, a random subset against the dense numpy restatement,
+  and against the same trajectories run one grid at a time as a shared grid (the two SDF addressing modes must agree bit
+  for bit)."""
+  from oracle import blocktri as BT
+  B, n, G = 4096, 64, 256
+  p = PC.P2d(n)
+  th, start, goal, _ = _c2_inputs(B, n, G, seed=5, perturb=0.05)
+  th, start, goal = PC.rnd(th, 'f32'), PC.rnd(start, 'f32'), PC.rnd(goal, 'f32')
+  sdf32 = _per_sample_circle_sdfs(B, G)                      # float32: exactly what the kernel reads
+  dth, err, eex, info = be.step(p, th, start, goal, sdf32, io='f32')
+  assert np.all(info == 0) and np.all(np.isfinite(dth))
+  c_dth = np.empty_like(dth); c_err = np.empty(B); c_eex = np.empty(B)
+  for lo in range(0, B, 512):                                # the C oracle takes fp64 grids: 512 x 256 x 256 x 8 B = 256 MiB per chunk
+    sl = slice(lo, lo + 512)
+    c_dth[sl], c_err[sl], c_eex[sl], ci = BT.gn_step(p, th[sl], start[sl], goal[sl], sdf32[sl].astype(np.float64), nthreads=4)
+    assert not ci.any()
+  per_traj = np.abs(dth - c_dth).reshape(B, -1).max(1) / np.abs(c_dth).reshape(B, -1).max(1)
+  assert per_traj.max() < PC.TOL['f32'], per_traj.max()
+  assert rel_err(err, c_err) < PC.TOL_ERR['f32'] and rel_err(eex, c_eex) < PC.TOL_ERR['f32']
+  idx = np.random.RandomState(2).choice(B, 32, replace=False)
+  qc, ow, eps = p.static_covs(32)
+  r_dth, r_err, r_eex = O.plan_layer_forward(th[idx], start[idx], goal[idx], sdf32[idx].astype(np.float64), qc, ow, eps, p)
+  assert rel_err(dth[idx], r_dth) < PC.TOL['f32'] and rel_err(err[idx], r_err.reshape(-1)) < PC.TOL_ERR['f32']
+  for b in idx[:6]:                                          # shared-grid addressing of the same trajectory: identical bits
+    d1, e1, _, _ = be.step(p, th[b:b + 1], start[b:b + 1], goal[b:b + 1], sdf32[b:b + 1], io='f32')
+    assert np.array_equal(d1[0], dth[b]) and e1[0] == err[b]

@@ -125,6 +125,57 @@ def test_error_helpers_and_unweighted_errors(golden):
   assert abs(float(usg) - float(g['unw_sg'].item())) < 1e-12
 
 
+def test_unweighted_error_methods_one_by_one(golden):
+  """PlanLayer.start_goal_error / gp_error / obs_error called individually, as DiffGPMP2Planner.unweighted_errors_batch does in
+  the reference (diff_gpmp2_planner.py:229-237 -> plan_layer.py:374-388), against the reference's values (fixture g3_c1)."""
+  g = golden('g3_c1')
+  planner = make_planner(32, 1)
+  sdf = T(g['sdf'])[None, None]
+  planner.step(T(g['th_hist'][3]), T(g['start']), T(g['goal']), (sdf > 0).double(), sdf)
+  th = T(g['th_hist'][3])
+  pl = planner.plan_layer
+  usg, ugp, uobs = pl.start_goal_error(th), pl.gp_error(th), pl.obs_error(th, sdf)
+  assert usg.shape == (1, 1, 1) and ugp.shape == (1, 1, 1) and uobs.shape == (1, 1, 1)
+  assert abs(float(usg) - float(g['unw_sg'].item())) < 1e-12
+  assert rel_err(ugp.cpu().numpy(), g['unw_gp']) < 1e-11 and rel_err(uobs.cpu().numpy(), g['unw_obs']) < 1e-11
+  a, b, c = pl.unweighted_errors(th, sdf)
+  assert torch.equal(a, usg) and torch.equal(b, ugp) and torch.equal(c, uobs)
+  # float32 tensors and a batch: same helpers, same values to fp32 accuracy
+  g2 = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g2['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g2['circles']), torch.float32)[None, None].expand(B, 1, G, G)
+  th, st, go = T(g2['th_hist'][2], torch.float32), T(g2['start'], torch.float32), T(g2['goal'], torch.float32)
+  planner.step(th, st, go, None, sdf)
+  p = O.OracleParams(dof=2, total_time_step=n - 1)
+  r_sg, r_gp, r_obs = O.unweighted_errors_batch(th.double().cpu().numpy(), st.double().cpu().numpy(), go.double().cpu().numpy(),
+                                                sdf.double().cpu().numpy(), p.static_covs(B)[2], p)
+  pl = planner.plan_layer
+  assert rel_err(pl.gp_error(th).cpu().numpy(), r_gp) < 2e-6 and rel_err(pl.obs_error(th, sdf).cpu().numpy(), r_obs) < 2e-6
+  assert float(np.max(np.abs(pl.start_goal_error(th).double().cpu().numpy() - r_sg))) < 1e-6
+
+
+def test_rejects_mismatched_sdf_batch_and_double_backward(golden):
+  g = golden('g5_grads')
+  B, n, G = 4, 16, int(g['G'])
+  planner = make_planner(n, B)
+  sdf3 = T(O.circles_sdf(G, g['circles']))[None, None].repeat(3, 1, 1, 1)        # 3 grids for 4 trajectories
+  with pytest.raises(ValueError):
+    planner.step(T(g['th']), T(g['start']), T(g['goal']), None, sdf3)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  th = T(g['th']).requires_grad_(True)
+  dth, _, _, err_ext, _, _, _ = planner.step(th, T(g['start']), T(g['goal']), None, sdf)
+  (gth,) = torch.autograd.grad((dth ** 2).sum(), th, create_graph=True)
+  with pytest.raises(RuntimeError):                 # once_differentiable: no silent zero second-order terms
+    gth.sum().backward()
+  # an err_ext-only loss needs no adjoint solve (no dtheta cotangent is materialised) and still matches the reference
+  th2 = T(g['th']).requires_grad_(True)
+  sdfB = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1)
+  _, _, ee = planner.plan_layer(th2, T(g['start']), T(g['goal']), None, sdfB, T(g['qc']), T(g['ow']), T(g['eps']))
+  (T(g['gext']) * ee).sum().backward()
+  assert rel_err(th2.grad.cpu().numpy(), g['ge_th']) < 1e-10
+
+
 def test_rejects_cpu_tensors_and_bad_shapes():
   planner = make_planner(16, 1)
   th = torch.zeros(1, 16, 4, dtype=torch.float64)
