@@ -373,6 +373,7 @@ def main():
   prewarm_s = prewarm(step)
   for k in range(args.warmup): step(k)
   ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+  ev0.record(); ev1.record()                        # (creates the events outside the timed region: a first record costs ~40 us of host time)
   torch.cuda.synchronize()
   if dist is not None: dist.barrier()
   torch.cuda.synchronize()
@@ -383,11 +384,20 @@ def main():
   gathered = None
   if dist is not None:      # collect final trajectories (the only collective of the path), through the product's helper
     gathered = parallel.all_gather_trajectories(th_hist[-1], world * B)
+  else:
+    while not ev1.query(): pass                     # spin until the last launch is done: synchronize() then returns at once instead of after an interrupt wake-up
   torch.cuda.synchronize()
   if dist is not None: dist.barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
-  kernel_ms = ev0.elapsed_time(ev1) / args.steps      # average per-launch duration on the launch stream
+  kernel_ms = ev0.elapsed_time(ev1) / args.steps     # average per-launch duration over the timed region, HIP events on the launch stream
+  # Cross-check outside the timed region: every launch records its OWN begin / end (dgp_time_next_launch == hipExtLaunchKernelGGL
+  # events; rocprofv3's definition of a kernel's duration).  Not done inside the timed region: such launches dispatch ~5 us slower.
+  ktimer = _capi.KernelTimer(min(max(args.steps, 200), 1000))
+  for k in range(len(ktimer.pairs)):
+    ktimer.arm(); step(k)
+  torch.cuda.synchronize()
+  kdur = np.asarray(ktimer.durations_ms())
   if dist is not None:
     assert tuple(gathered.shape) == (world * B, n, d)
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -421,6 +431,8 @@ def main():
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
         'rccl_ranks': world if dist is not None else 0,
         'trajectory_steps_per_s': world * args.steps * B / elapsed,
+        'kernel_events': {'launches': int(kdur.size), 'mean_ms': float(kdur.mean()), 'median_ms': float(np.median(kdur)),
+                          'note': 'per-launch begin/end events (dgp_time_next_launch), a separate pass after the timed region'},
         'roofline': roofline_block(bytes_per_launch, kernel_ms * 1e3, kname, traffic_key='gn_step',
                                    note='HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'),
     }

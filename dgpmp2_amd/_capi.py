@@ -16,7 +16,7 @@ DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64 = 0, 1
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
-DGP_ABI_VERSION = 1
+DGP_ABI_VERSION = 2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
@@ -49,7 +49,7 @@ class CApi(object):
   """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'gn_step', 'gn_solve',
-             'eval_errors', 'gn_step_backward')
+             'eval_errors', 'gn_step_backward', 'time_next_launch')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -75,6 +75,7 @@ class CApi(object):
     self.gn_step_backward = f('gn_step_backward'); self.gn_step_backward.restype = C.c_int
     self.gn_step_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, i64,
                                       i32, vp, vp, vp, vp]
+    self.time_next_launch = f('time_next_launch'); self.time_next_launch.restype = C.c_int; self.time_next_launch.argtypes = [vp, vp]
     v = self.abi_version()
     if v != DGP_ABI_VERSION:
       raise ImportError('%s: ABI version %d, binding expects %d' % (path, v, DGP_ABI_VERSION))
@@ -82,6 +83,47 @@ class CApi(object):
   def check(self, rc):
     if rc != DGP_OK:
       raise DgpError(rc, (self.last_error() or b'').decode('utf-8', 'replace'))
+
+
+class KernelTimer(object):
+  """Per-kernel execution times through dgp_time_next_launch: a pool of HIP event pairs (created through the HIP runtime torch
+  has already loaded); `arm()` before a launch makes that launch record its own begin / end, `durations_ms()` reads them back
+  after a synchronisation.  Measurement aid for bench.py and the profiling tools -- not used by the planner."""
+
+  def __init__(self, n, api=None):
+    self.api = api if api is not None else get_api()
+    self.hip = C.CDLL('libamdhip64.so')
+    self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+    self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+    self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+    self.pairs = []
+    for _ in range(n):
+      a, b = C.c_void_p(), C.c_void_p()
+      if self.hip.hipEventCreate(C.byref(a)) != 0 or self.hip.hipEventCreate(C.byref(b)) != 0:
+        raise RuntimeError('hipEventCreate failed')
+      self.pairs.append((a, b))
+    self.used = 0
+
+  def arm(self):
+    a, b = self.pairs[self.used]; self.used += 1
+    self.api.check(self.api.time_next_launch(a, b))
+
+  def reset(self):
+    self.used = 0
+
+  def durations_ms(self):
+    out = []
+    for a, b in self.pairs[:self.used]:
+      ms = C.c_float()
+      rc = self.hip.hipEventElapsedTime(C.byref(ms), a, b)
+      if rc != 0: raise RuntimeError('hipEventElapsedTime failed (%d): synchronise before reading' % rc)
+      out.append(ms.value)
+    return out
+
+  def __del__(self):
+    for a, b in getattr(self, 'pairs', []):
+      self.hip.hipEventDestroy(a); self.hip.hipEventDestroy(b)
+    self.pairs = []
 
 
 _api = None

@@ -30,6 +30,14 @@ inline char* err_buf() {
   return buf;
 }
 
+// dgp_time_next_launch: the event pair the calling thread's next launch records its begin / end on (one variable per thread
+// across all translation units of the library)
+struct LaunchEvents { void* start; void* stop; };
+inline LaunchEvents& launch_events() {
+  static thread_local LaunchEvents ev = {nullptr, nullptr};
+  return ev;
+}
+
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -140,6 +148,9 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   p.qa = 12.0 * pow(p.dt, -3.0);                                        // gp_factor.py:66-68
   p.qb = -6.0 * pow(p.dt, -2.0);
   p.qc_ = 4.0 * pow(p.dt, -1.0);
+  p.e10 = p.dt * p.qa + p.qb;                                           // E = Phi2^T T, F = E Phi2 (QK_KRON kernels, gn_lane.h)
+  p.e11 = p.dt * p.qb + p.qc_;
+  p.f11 = p.dt * p.e10 + p.e11;
   p.w_s = 1.0 / pow(cfg->K_s, 2.0);                                     // plan_layer.py:64-65
   p.w_g = 1.0 / pow(cfg->K_g, 2.0);
   p.reg = cfg->reg;
@@ -188,6 +199,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
     if ((covs->qc_mode == DGP_QC_STATIC) != (covs->qc_inv == nullptr))
       return fail(DGP_EINVAL, "qc_inv must be NULL iff qc_mode == DGP_QC_STATIC");
     p.qc_mode = covs->qc_mode; p.qc = covs->qc_inv; p.obs_w = covs->obs_w; p.eps = covs->eps;
+    p.vec_qc = (covs->qc_inv && aligned16(covs->qc_inv)) ? 1 : 0;
   }
   return DGP_OK;
 }

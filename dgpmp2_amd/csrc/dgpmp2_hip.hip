@@ -13,8 +13,10 @@ hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dg
   const DgpShape sh = dgp_host::choose_shape(h, p.B);
   // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
   static const DgpLaunchFn table[2][2][dgp_dev::NUM_GROUPS] = {
-      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2}, {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2}},
-      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2}, {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2}}};
+      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3},
+       {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2, dgp_launch_2_f64_g3}},
+      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2, dgp_launch_3_f32_g3},
+       {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2, dgp_launch_3_f64_g3}}};
   const int f64 = h->cfg.io_dtype == DGP_F64 ? 1 : 0;
   return table[h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
 }
@@ -28,6 +30,13 @@ const char* dgp_last_error(void) { return dgp_host::err_buf(); }
 int dgp_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create(cfg, out); }
 void dgp_destroy(DgpHandle* h) { delete h; }
 int dgp_num_factor_rows(const DgpHandle* h) { return h ? h->M : fail(DGP_EINVAL, "null handle"); }
+
+int dgp_time_next_launch(void* start_event, void* stop_event) {
+  dgp_host::LaunchEvents& le = dgp_host::launch_events();
+  le.start = (start_event && stop_event) ? start_event : nullptr;
+  le.stop = (start_event && stop_event) ? stop_event : nullptr;
+  return DGP_OK;
+}
 
 int dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
   if (!h || batch <= 0) return fail(DGP_EINVAL, "null handle or non-positive batch");

@@ -26,7 +26,7 @@ struct GnGradParams {
   int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
 };
 
-template <int DOF, int LPT, int C, typename IO, bool QSTAT, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, int QK, typename Ctx>
 DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;
@@ -48,11 +48,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
     for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
   if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.g_dtheta, b, g0, traj_ok, vec, gbar);
+  LaneQ<D, C, QK> lq;              // generic covariances: Q^-1 of the lane's C + 1 GP factors, shared by the adjoint solve and the chain rule
+  load_lane_Q<DOF, C, IO>(p, b, g0, traj_ok, lq);
   // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
   if (gp.g_dtheta) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
-    bool ok = true;
-    gn_linear_solve<DOF, LPT, C, IO, true, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok);
+    SpdCheck<Ctx> ok = {&cx, 0};
+    gn_linear_solve<DOF, LPT, C, IO, true, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
   }
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
 
@@ -111,8 +113,9 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
     if (g < n - 1) {
       Sym<D> Q;
-      fixed_Qinv<DOF>(p, Q);
-      if (p.qc_mode != QC_STATIC) load_Qinv<DOF, IO>(p, b, g, Q);
+      if constexpr (QK == QK_STATIC) fixed_Qinv<DOF>(p, Q);
+      else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, lq.c[k], Q);
+      else Q = lq.q[k];
       double e[D], u[D], rho[D];
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {
@@ -171,8 +174,9 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g-1 -> g): this row's share is +(Q_{g-1} u_{g-1} + ebar Qfix e_{g-1})
     if (g > 0) {
       Sym<D> Q;
-      fixed_Qinv<DOF>(p, Q);
-      if (p.qc_mode != QC_STATIC) load_Qinv<DOF, IO>(p, b, g - 1, Q);
+      if constexpr (QK == QK_STATIC) fixed_Qinv<DOF>(p, Q);
+      else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], Q);
+      else Q = (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0];
       double e[D], u[D];
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {

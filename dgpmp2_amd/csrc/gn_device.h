@@ -1,6 +1,7 @@
 // gn_device.h -- device lane context and kernel entry points (HIP only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #ifndef DGP_HD
 #define DGP_HD __host__ __device__ __forceinline__
 #endif
@@ -47,6 +48,7 @@ struct DevCtx {
     return __hiloint2double(hi, lo);
   }
   __device__ __forceinline__ bool any(bool pred) const { return __any(pred ? 1 : 0) != 0; }
+  __device__ __forceinline__ uint64_t ballot(bool pred) const { return __ballot(pred ? 1 : 0); }      // v_cmp into an SGPR pair
   // XCD (accelerator complex die) this wavefront runs on, 0..7 on MI355X: HW_REG_XCC_ID (id 20), bits [3:0]
   __device__ __forceinline__ int xcc_id() const { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf); }
   // xcd_local: the target is only touched by wavefronts of THIS XCD during the kernel (a per-XCD partial buffer), so the
@@ -92,23 +94,23 @@ __device__ __forceinline__ void warm_kernarg() {
 #endif
 }
 
-// QSTAT: static covariances (p.qc_mode == QC_STATIC) -- the constant GP blocks are scalar operands (see gn_lane.h).
-template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT>
+// QK: kernel variant by covariance representation, dgp::QK_* (static: the constant GP blocks are scalar operands; see gn_lane.h).
+template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   warm_kernarg<(int)sizeof(dgp::GnParams)>();
   __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
   DevCtx cx;
   cx.lds_ = lds;
-  dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QSTAT>(p, cx);
+  dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
-template <int DOF, int LPT, int C, typename IO, bool QSTAT>
+template <int DOF, int LPT, int C, typename IO, int QK>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
   __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
   DevCtx cx;
   cx.lds_ = lds;
-  dgp::gn_backward_lane_program<DOF, LPT, C, IO, QSTAT>(p, g, cx);
+  dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
 }
 
 // every (LPT, C) of dgp_host::shape_supported
@@ -118,11 +120,15 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
 enum { MODE_BACKWARD = 3 };
 
 // The kernels are spread over translation units (gn_inst.hip, one per (dof, io dtype, group)) so that they build in
-// parallel.  Group of a launch: static-covariance STEP / SOLVE, the generic STEP / SOLVE plus EVAL, the two backward kernels.
-enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, NUM_GROUPS = 3 };
+// parallel.  Group of a launch: static-covariance STEP / SOLVE; the general-covariance STEP / SOLVE plus EVAL; the static and
+// general backward kernels; everything for per-state Q_c^-1 tensors (QK_KRON: STEP, SOLVE, backward).
+enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, GROUP_KRON = 3, NUM_GROUPS = 4 };
 inline int launch_group(int mode, const dgp::GnParams& p) {
+  if (mode == dgp::MODE_EVAL) return GROUP_GENERIC;
+  const int qk = dgp::kernel_variant(p);
+  if (qk == dgp::QK_KRON) return GROUP_KRON;
   if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
-  return (mode != dgp::MODE_EVAL && dgp::use_static_kernels(p)) ? GROUP_STATIC : GROUP_GENERIC;
+  return qk == dgp::QK_STATIC ? GROUP_STATIC : GROUP_GENERIC;
 }
 
 template <int DOF, typename IO, int GROUP>
@@ -131,25 +137,44 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
   const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
   const bool qstat = dgp::use_static_kernels(p);
   if (launch_group(mode, p) != GROUP) return hipErrorInvalidValue;
-#define DGP_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, p)
+  // dgp_time_next_launch(): this launch records its own begin / end on the caller's events (hipExtLaunchKernelGGL); one-shot
+  dgp_host::LaunchEvents& le = dgp_host::launch_events();
+  const hipEvent_t ev0 = (hipEvent_t)le.start, ev1 = (hipEvent_t)le.stop;
+  const bool timed = ev0 && ev1;
+  le.start = le.stop = nullptr;
+#define DGP_LAUNCH(K)                                                               \
+  do {                                                                              \
+    if (timed) hipExtLaunchKernelGGL(K, grid, block, 0, s, ev0, ev1, 0, p);         \
+    else hipLaunchKernelGGL(K, grid, block, 0, s, p);                               \
+  } while (0)
+#define DGP_LAUNCH_BWD(K)                                                           \
+  do {                                                                              \
+    if (timed) hipExtLaunchKernelGGL(K, grid, block, 0, s, ev0, ev1, 0, p, *g);     \
+    else hipLaunchKernelGGL(K, grid, block, 0, s, p, *g);                           \
+  } while (0)
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
     if constexpr (GROUP == GROUP_STATIC) {                                                                                 \
-      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, true>));                           \
-      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, true>));                                                 \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));                 \
+      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
-      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, false>));                          \
-      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, false>));                   \
-      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, false>));                                                 \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));                \
+      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));         \
+      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                       \
+    } else if constexpr (GROUP == GROUP_KRON) {                                                                            \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_KRON>));                   \
+      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));            \
+      else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_KRON>));                                             \
     } else {                                                                                                               \
-      if (qstat) hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, true>), grid, block, 0, s, p, *g);                 \
-      else hipLaunchKernelGGL((gn_backward_kernel<DOF, L, CC, IO, false>), grid, block, 0, s, p, *g);                      \
+      if (qstat) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_STATIC>));                                     \
+      else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_GENERAL>));                                          \
     }                                                                                                                      \
     return hipGetLastError();                                                                                              \
   }
   DGP_FOR_EACH_SHAPE(DGP_CASE)
 #undef DGP_CASE
 #undef DGP_LAUNCH
+#undef DGP_LAUNCH_BWD
   return hipErrorInvalidValue;
 }
 
@@ -160,6 +185,7 @@ typedef hipError_t (*DgpLaunchFn)(DgpShape, int, const dgp::GnParams&, const dgp
 #define DGP_DECL_INST(d, t) \
   hipError_t dgp_launch_##d##_##t##_g0(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
   hipError_t dgp_launch_##d##_##t##_g1(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
-  hipError_t dgp_launch_##d##_##t##_g2(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+  hipError_t dgp_launch_##d##_##t##_g2(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
+  hipError_t dgp_launch_##d##_##t##_g3(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
 DGP_DECL_INST(2, f32) DGP_DECL_INST(2, f64) DGP_DECL_INST(3, f32) DGP_DECL_INST(3, f64)
 #undef DGP_DECL_INST

@@ -1,5 +1,5 @@
 // gn_inst.hip -- kernel instantiations for ONE (dof, io dtype, kernel group), selected with
-//   -DDGP_INST_DOF=2|3 -DDGP_INST_F64=0|1 -DDGP_INST_GROUP=0|1|2      (groups: dgp_dev::GROUP_*)
+//   -DDGP_INST_DOF=2|3 -DDGP_INST_F64=0|1 -DDGP_INST_GROUP=0|1|2|3      (groups: dgp_dev::GROUP_*)
 #include "gn_device.h"
 
 #if DGP_INST_F64

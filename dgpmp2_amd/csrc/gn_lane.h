@@ -62,6 +62,12 @@ namespace dgp {
 enum { MODE_STEP = 0, MODE_SOLVE = 1, MODE_EVAL = 2 };
 enum { QC_STATIC = 0, QC_PERSTATE = 1, QC_QFULL = 2 };
 enum { FLAG_NONHOLONOMIC = 1u, FLAG_VEL_LIMITS = 2u };
+// Kernel variant by covariance representation (template parameter QK of the kernels; see Coupling):
+//   QK_STATIC : static covariances with a diagonal Q_c_inv (the reference's default planner) -- constant GP blocks as scalar operands
+//   QK_KRON   : per-state Q_c^-1 tensors (qc_mode PERSTATE: the learned modes diag_identity / qc_full) -- Q^-1 = T (x) C_k is never
+//               formed, a row keeps the symmetric dof x dof C_k only
+//   QK_GENERAL: per-state full Q^-1 (q_full) or a non-diagonal static Q_c_inv -- a row keeps its symmetric d x d Q_k^-1
+enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2 };
 
 // Kernel arguments (plain data, passed by value).
 struct GnParams {
@@ -73,7 +79,7 @@ struct GnParams {
   int32_t max_iters;
   int32_t vec_io;            // 1: th / dtheta / th_out / gradient rows are 16-byte aligned -> vector row accesses
   int32_t vec_mu;            // 1: start / goal rows too
-  int32_t pad_;
+  int32_t vec_qc;            // 1: the qc tensor is 16-byte aligned -> vector accesses of a factor's block
   const void *th, *start, *goal, *sdf, *qc, *obs_w, *eps;
   void *dtheta, *err, *err_ext;
   int32_t* info;
@@ -96,6 +102,8 @@ struct GnParams {
   double w_d, w_v, vmax[2];  // 1/K_d^2, 1/K_v^2, (v_x, v_y)
   double M, inv_M;           // plan_layer.py:43-45; 1 / M correctly rounded
   double tol_delta;
+  double e10, e11, f11;      // with Phi2 = [[1, dt],[0, 1]], T = [[qa, qb],[qb, qc]]:  E = Phi2^T T = [[qa, qb],[e10, e11]] (U = -E (x) C),
+                             // F = E Phi2 = [[qa, e10],[e10, f11]] (Phi^T Q Phi = F (x) C)      (QK_KRON kernels)
   // Static covariances (qc_mode == QC_STATIC): the three constant blocks every GP factor contributes, precomputed on the
   // host from (dt, Q_c_inv) so that the kernels read them as scalar (SGPR) operands instead of holding them in vector
   // registers.  d = 2 dof; symmetric blocks packed like Sym<d>, u_fix row-major d x d.
@@ -105,8 +113,9 @@ struct GnParams {
   double u_fix[36];          // U = -Phi^T Q^-1                        (block (i,i+1))
 };
 
-// The QSTAT kernel variants (see Coupling below) apply to static covariances with a diagonal Q_c_inv.
+// The QK_STATIC kernel variants (see Coupling below) apply to static covariances with a diagonal Q_c_inv.
 DGP_HD bool use_static_kernels(const GnParams& p) { return p.qc_mode == QC_STATIC && p.qc_diag != 0; }
+DGP_HD int kernel_variant(const GnParams& p) { return use_static_kernels(p) ? QK_STATIC : (p.qc_mode == QC_PERSTATE ? QK_KRON : QK_GENERAL); }
 
 // ---------------------------------------------------------------------------------------------------
 // tiny fixed-size linear algebra, fully unrolled so that everything lives in registers
@@ -144,10 +153,23 @@ DGP_HD double pivot_rcp(double v) {
 #endif
 }
 
-// A^-1 of an SPD matrix through LDL^T; ok=false when a pivot is <= 0 or NaN.  (Generic fallback; the kernels use the
+// Positive-definiteness tracker of one wavefront: `require(cond)` is evaluated where it stands -- one v_cmp into a scalar
+// lane mask (a ballot) and one scalar OR.  A plain `bool ok = ok && pivot > 0` is legal for the compiler to SINK into the
+// `if (p.info)` block at the very end of the kernel, and it did: every pivot and determinant of the whole solve then stayed
+// alive (in AGPRs and, for d = 6, in scratch) until the last instruction -- 6 us of serialised scratch reloads on the d = 6
+// kernel when the flags were requested, and register pressure in every kernel even when they were not.  A ballot is a
+// convergent operation and cannot be moved under a new control dependency.
+template <typename Ctx>
+struct SpdCheck {
+  Ctx* cx;
+  uint64_t bad;          // bit l: lane l met a non-positive (or NaN) pivot
+  DGP_HD void require(bool cond) { bad |= cx->ballot(!cond); }
+};
+
+// A^-1 of an SPD matrix through LDL^T; ok flags a pivot that is <= 0 or NaN.  (Generic fallback; the kernels use the
 // block forms below, whose dependency chains are much shorter.)
-template <int D>
-DGP_HD void sym_inverse_ldlt(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
+template <int D, typename OK>
+DGP_HD void sym_inverse_ldlt(const Sym<D>& A, Sym<D>& Ai, OK& ok) {
   double L[D][D];      // unit lower (strict part used)
   double dinv[D];
   double dd[D];
@@ -157,7 +179,7 @@ DGP_HD void sym_inverse_ldlt(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
 #pragma unroll
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * dd[k];
     dd[j] = v;
-    ok = ok && (v > 0.0);
+    ok.require(v > 0.0);
     dinv[j] = pivot_rcp(v);
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
@@ -194,13 +216,15 @@ DGP_HD void sym_inverse_ldlt(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
 }
 
 // Inverse of an SPD 2x2 / 3x3 block given as scalars (adjugate / determinant); ok tracks the leading minors.
-DGP_HD void inv2(double a, double b, double c, double& ia, double& ib, double& ic, bool& ok) {      // [[a,b],[b,c]]
+template <typename OK>
+DGP_HD void inv2(double a, double b, double c, double& ia, double& ib, double& ic, OK& ok) {      // [[a,b],[b,c]]
   const double det = a * c - b * b;
-  ok = ok && (a > 0.0) && (det > 0.0);
+  ok.require((a > 0.0) && (det > 0.0));
   const double r = pivot_rcp(det);
   ia = c * r; ib = -b * r; ic = a * r;
 }
-DGP_HD void inv3(const double (&m)[6], double (&o)[6], bool& ok) {      // packed upper: m00 m01 m02 m11 m12 m22
+template <typename OK>
+DGP_HD void inv3(const double (&m)[6], double (&o)[6], OK& ok) {      // packed upper: m00 m01 m02 m11 m12 m22
   const double c00 = m[3] * m[5] - m[4] * m[4];
   const double c01 = m[2] * m[4] - m[1] * m[5];
   const double c02 = m[1] * m[4] - m[2] * m[3];
@@ -208,7 +232,7 @@ DGP_HD void inv3(const double (&m)[6], double (&o)[6], bool& ok) {      // packe
   const double c12 = m[1] * m[2] - m[0] * m[4];
   const double c22 = m[0] * m[3] - m[1] * m[1];
   const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-  ok = ok && (m[0] > 0.0) && (c22 > 0.0) && (det > 0.0);
+  ok.require((m[0] > 0.0) && (c22 > 0.0) && (det > 0.0));
   const double r = pivot_rcp(det);
   o[0] = c00 * r; o[1] = c01 * r; o[2] = c02 * r; o[3] = c11 * r; o[4] = c12 * r; o[5] = c22 * r;
 }
@@ -216,8 +240,8 @@ DGP_HD void inv3(const double (&m)[6], double (&o)[6], bool& ok) {      // packe
 // A^-1 of an SPD dxd matrix by 2x2 block elimination with (d/2)x(d/2) blocks:
 //   A = [[P, Q],[Q^T, R]],  S = R - Q^T P^-1 Q,  A^-1 = [[P^-1 + Y S^-1 Y^T, -Y S^-1],[., S^-1]],  Y = P^-1 Q.
 // Two reciprocals and a dependency depth of ~12 operations instead of d sequential pivots; ok=false if not SPD.
-template <int D>
-DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
+template <int D, typename OK>
+DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, OK& ok) {
   if constexpr (D == 4) {
     double p0, p1, p2;
     inv2(A(0, 0), A(0, 1), A(1, 1), p0, p1, p2, ok);
@@ -276,8 +300,8 @@ DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, bool& ok) {
 }
 
 // x = A^-1 b through LDL^T
-template <int D>
-DGP_HD void sym_solve(const Sym<D>& A, const double (&b)[D], double (&x)[D], bool& ok) {
+template <int D, typename OK>
+DGP_HD void sym_solve(const Sym<D>& A, const double (&b)[D], double (&x)[D], OK& ok) {
   double L[D][D];
   double dd[D], dinv[D];
 #pragma unroll
@@ -286,7 +310,7 @@ DGP_HD void sym_solve(const Sym<D>& A, const double (&b)[D], double (&x)[D], boo
 #pragma unroll
     for (int k = 0; k < j; ++k) v -= L[j][k] * L[j][k] * dd[k];
     dd[j] = v;
-    ok = ok && (v > 0.0);
+    ok.require(v > 0.0);
     dinv[j] = pivot_rcp(v);
 #pragma unroll
     for (int i = j + 1; i < D; ++i) {
@@ -512,6 +536,16 @@ DGP_HD void fixed_Qinv(const GnParams& p, Sym<2 * DOF>& Q) {
       }
       Q(i, DOF + j) = p.qb * c;
     }
+}
+
+template <int D> DGP_HD void sym_times_vec_fwd(const Sym<D>& S, const double (&v)[D], double (&o)[D]) {   // o = S v
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += S(a, k) * v[k];
+    o[a] = t;
+  }
 }
 
 template <int D>
@@ -760,6 +794,272 @@ DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, 
 #pragma unroll
     for (int c = a; c < D; ++c)
       Dm(a, c) = gp_nz<D>(a, c) ? ((a == c) ? dbase + w : 0.0) + mN * p.a_fix[Sym<D>::idx(a, c)] + mP * p.q_fix[Sym<D>::idx(a, c)] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic covariances (per-state / q_full tensors, or a non-diagonal static Q_c_inv): Q^-1 of the C + 1 GP factors that touch
+// a lane's rows, fetched ONCE per launch -- all loads issued together, ahead of the SDF taps, as 16-byte vector accesses
+// where the factor's block is a multiple of 16 bytes (GnParams::vec_qc) -- and shared by the assembly, the elimination and
+// (backward kernel) the chain rule.  In the fused loop they are loop-invariant: loaded before the first GN iteration.
+//   q[k]: factor (g0+k -> g0+k+1), k = 0..C-1;   qm0: factor (g0-1 -> g0).
+// Rows / factors that do not exist read a clamped factor index of the SAME trajectory (finite data, so that the 0/1 masks
+// that multiply them cannot turn it into NaN; a NaN inside one trajectory's tensors stays inside that trajectory).
+// ---------------------------------------------------------------------------------------------------
+template <int D, int C, int QK> struct LaneQ;
+template <int D, int C> struct LaneQ<D, C, QK_GENERAL> { Sym<D> q[C]; Sym<D> qm0; };
+template <int D, int C> struct LaneQ<D, C, QK_STATIC> {};
+template <int D, int C> struct LaneQ<D, C, QK_KRON> { Sym<D / 2> c[C]; Sym<D / 2> cm0; };      // C_k = Q_c^-1 of the factor, read as a symmetric matrix
+
+// N consecutive elements starting at src: 16-byte vector loads when `vec` (host-checked alignment) and N is a whole number of
+// 16-byte cells, scalar loads otherwise.  Values stay in the I/O type (converted at first use).
+template <typename IO, int N>
+DGP_HD void ld_block(const IO* src, bool vec, IO (&v)[N]) {
+  constexpr int EPV = 16 / (int)sizeof(IO);
+  if constexpr ((N % EPV) == 0) {
+    if (vec) {
+      typedef IO V16 __attribute__((vector_size(16)));
+#pragma unroll
+      for (int k = 0; k < N / EPV; ++k) {
+        const V16 t = ((const V16*)src)[k];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) v[k * EPV + e] = t[e];
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = src[k];
+}
+
+template <int DOF, typename IO>
+DGP_HD void load_Qinv_block(const GnParams& p, int64_t b, int f, Sym<2 * DOF>& Q) {
+  constexpr int D = 2 * DOF;
+  const bool stat = (p.qc_mode == QC_STATIC), full = (p.qc_mode == QC_QFULL);
+  const bool vec = p.vec_qc != 0;
+  IO raw[D * D];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) raw[i] = (IO)0;
+  if (full) {                                      // wave-uniform: q_full, Q^-1 itself (d x d per factor)
+    ld_block<IO, D * D>((const IO*)p.qc + (b * (p.n - 1) + f) * (D * D), vec, raw);
+  } else if (!stat) {                              // per-state Q_c^-1 (dof x dof per factor)
+    IO c[DOF * DOF];
+    ld_block<IO, DOF * DOF>((const IO*)p.qc + (b * (p.n - 1) + f) * (DOF * DOF), vec, c);
+#pragma unroll
+    for (int i = 0; i < DOF * DOF; ++i) raw[i] = c[i];
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = i; j < D; ++j) {
+      const double coef = (j < DOF) ? p.qa : ((i >= DOF) ? p.qc_ : p.qb);      // blocks [[qa C, qb C],[qb C, qc C]] (gp_factor.py:65-73)
+      const double cij = stat ? p.qc_fix[(i % DOF) * DOF + (j % DOF)] : (double)raw[(i % DOF) * DOF + (j % DOF)];
+      Q(i, j) = full ? (double)raw[i * D + j] : coef * cij;
+    }
+}
+
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams& p, int64_t b, int g0, bool traj_ok, LaneQ<2 * DOF, C, QK_GENERAL>& L) {
+  const int64_t bb = traj_ok ? b : 0;
+  const int fmax = p.n - 2;                        // n >= 2 (host-enforced)
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_Qinv_block<DOF, IO>(p, bb, imin32(g0 + k, fmax), L.q[k]);
+  load_Qinv_block<DOF, IO>(p, bb, imin32(imax32(g0 - 1, 0), fmax), L.qm0);
+}
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_STATIC>&) {}
+
+// per-state C = Q_c^-1 (dof x dof) of factor f, upper triangle (qc_mode PERSTATE only: p.qc is the (B, n-1, dof, dof) tensor)
+template <int DOF, typename IO>
+DGP_HD void load_Qc_block(const GnParams& p, int64_t b, int f, Sym<DOF>& Cm) {
+  IO raw[DOF * DOF];
+  ld_block<IO, DOF * DOF>((const IO*)p.qc + (b * (p.n - 1) + f) * (DOF * DOF), p.vec_qc != 0, raw);
+#pragma unroll
+  for (int i = 0; i < DOF; ++i)
+#pragma unroll
+    for (int j = i; j < DOF; ++j) Cm(i, j) = (double)raw[i * DOF + j];
+}
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams& p, int64_t b, int g0, bool traj_ok, LaneQ<2 * DOF, C, QK_KRON>& L) {
+  const int64_t bb = traj_ok ? b : 0;
+  const int fmax = p.n - 2;
+#pragma unroll
+  for (int k = 0; k < C; ++k) load_Qc_block<DOF, IO>(p, bb, imin32(g0 + k, fmax), L.c[k]);
+  load_Qc_block<DOF, IO>(p, bb, imin32(imax32(g0 - 1, 0), fmax), L.cm0);
+}
+
+// (M (x) C) v for a 2 x 2 M = [[m00, m01],[m10, m11]] of scalars and a symmetric dof x dof C:  [C v_p, C v_v] mixed by M
+template <int DOF>
+DGP_HD void kron_apply(double m00, double m01, double m10, double m11, const Sym<DOF>& Cm, const double (&v)[2 * DOF], double (&o)[2 * DOF]) {
+  double wp[DOF], wv[DOF];
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {
+    double tp = 0.0, tv = 0.0;
+#pragma unroll
+    for (int c = 0; c < DOF; ++c) { tp += Cm(a, c) * v[c]; tv += Cm(a, c) * v[DOF + c]; }
+    wp[a] = tp; wv[a] = tv;
+  }
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {
+    o[a] = m00 * wp[a] + m01 * wv[a];
+    o[DOF + a] = m10 * wp[a] + m11 * wv[a];
+  }
+}
+// Q^-1 = T (x) C as a symmetric d x d matrix (gp_factor.py:65-73)
+template <int DOF>
+DGP_HD void kron_to_sym(const GnParams& p, const Sym<DOF>& Cm, Sym<2 * DOF>& Q) {
+#pragma unroll
+  for (int i = 0; i < DOF; ++i)
+#pragma unroll
+    for (int j = 0; j < DOF; ++j) {
+      if (j >= i) { Q(i, j) = p.qa * Cm(i, j); Q(DOF + i, DOF + j) = p.qc_ * Cm(i, j); }
+      Q(i, DOF + j) = p.qb * Cm(i, j);
+    }
+}
+
+// generic_rhs / generic_diag for QK_KRON: Cown = C of factor (g -> g+1), Cprev of (g-1 -> g)
+template <int DOF>
+DGP_HD void kron_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
+                     const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
+                     const Sym<DOF>& Cown, const Sym<DOF>& Cprev, double (&r)[2 * DOF], ErrAcc& acc) {
+  constexpr int D = 2 * DOF;
+  const int n = p.n;
+  const double dt = p.dt;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  double s2 = 0.0, ep[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    ep[a] = (is_start ? mu_s[a] : mu_g[a]) - x[a];
+    s2 += ep[a] * ep[a];
+  }
+  acc.e += 0.5 * w * s2; acc.eext += 0.5 * w * s2; acc.usg += (is_start || is_goal) ? 0.5 * s2 : 0.0;
+  double eo[D], em[D];
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {
+    eo[a] = xp[a] - (x[a] + dt * x[DOF + a]);              // e = x_{g+1} - Phi x_g (gp_factor.py:105)
+    eo[DOF + a] = xp[DOF + a] - x[DOF + a];
+    em[a] = x[a] - (xm[a] + dt * xm[DOF + a]);
+    em[DOF + a] = x[DOF + a] - xm[DOF + a];
+  }
+  double wo[D], wm[D];                                     // Q_own e_own, Q_prev e_prev
+  kron_apply<DOF>(p.qa, p.qb, p.qb, p.qc_, Cown, eo, wo);
+  kron_apply<DOF>(p.qa, p.qb, p.qb, p.qc_, Cprev, em, wm);
+  double q = 0.0, so = 0.0, qf = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    q += eo[a] * wo[a];
+    so += eo[a] * eo[a];
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) t += p.q_fix[Sym<D>::idx(a, c)] * eo[c];     // fixed GP weight of err_ext (plan_layer.py:318-321), scalar operands
+    qf += eo[a] * t;
+  }
+  acc.e += mN * (0.5 * q); acc.eext += mN * (0.5 * qf); acc.ugp += mN * (0.5 * so);
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {                          // eta_g = w (mu - x) + Phi^T Q_own e_own - Q_prev e_prev
+    r[a] = w * ep[a] + mN * wo[a] - mP * wm[a];
+    r[DOF + a] = w * ep[DOF + a] + mN * (dt * wo[a] + wo[DOF + a]) - mP * wm[DOF + a];
+  }
+}
+template <int DOF>
+DGP_HD void kron_diag(const GnParams& p, int g, bool valid, const Sym<DOF>& Cown, const Sym<DOF>& Cprev, Sym<2 * DOF>& Dm, double& m_next) {
+  const int n = p.n;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  m_next = mN;
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
+  // delta I + prior + mN (F (x) C_own) + mP (T (x) C_prev)
+#pragma unroll
+  for (int a = 0; a < DOF; ++a)
+#pragma unroll
+    for (int c = 0; c < DOF; ++c) {
+      const double co = mN * Cown(a, c), cp_ = mP * Cprev(a, c);
+      if (c >= a) {
+        Dm(a, c) = ((a == c) ? dbase + w : 0.0) + p.qa * co + p.qa * cp_;
+        Dm(DOF + a, DOF + c) = ((a == c) ? dbase + w : 0.0) + p.f11 * co + p.qc_ * cp_;
+      }
+      Dm(a, DOF + c) = p.e10 * co + p.qb * cp_;
+    }
+}
+
+// Row g of the generic path, the part that does NOT depend on the SDF lookup (runs while the taps are in flight): priors + both GP
+// factors -> eta (without the single-state factors) and the error partials.  Qown = Q^-1 of factor (g -> g+1), Qm of (g-1 -> g);
+// every GP term carries a 0/1 lane mask instead of a branch, exactly like static_rhs.
+template <int DOF>
+DGP_HD void generic_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
+                        const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
+                        const Sym<2 * DOF>& Qown, const Sym<2 * DOF>& Qm, double (&r)[2 * DOF], ErrAcc& acc) {
+  constexpr int D = 2 * DOF;
+  const int n = p.n;
+  const double dt = p.dt;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  double s2 = 0.0, ep[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    ep[a] = (is_start ? mu_s[a] : mu_g[a]) - x[a];
+    s2 += ep[a] * ep[a];
+  }
+  acc.e += 0.5 * w * s2; acc.eext += 0.5 * w * s2; acc.usg += (is_start || is_goal) ? 0.5 * s2 : 0.0;
+  double eo[D], em[D];
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {
+    eo[a] = xp[a] - (x[a] + dt * x[DOF + a]);              // e = x_{g+1} - Phi x_g (gp_factor.py:105)
+    eo[DOF + a] = xp[DOF + a] - x[DOF + a];
+    em[a] = x[a] - (xm[a] + dt * xm[DOF + a]);
+    em[DOF + a] = x[DOF + a] - xm[DOF + a];
+  }
+  double wo[D], wm[D];                                     // Qown e_own, Qm e_prev
+  sym_times_vec_fwd<D>(Qown, eo, wo);
+  sym_times_vec_fwd<D>(Qm, em, wm);
+  double q = 0.0, so = 0.0, qf = 0.0;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    q += eo[a] * wo[a];
+    so += eo[a] * eo[a];
+    double t = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) t += p.q_fix[Sym<D>::idx(a, c)] * eo[c];     // fixed GP weight of err_ext (plan_layer.py:318-321), scalar operands
+    qf += eo[a] * t;
+  }
+  acc.e += mN * (0.5 * q);
+  acc.eext += mN * (0.5 * ((p.qc_mode == QC_STATIC) ? q : qf));
+  acc.ugp += mN * (0.5 * so);
+  // eta_g = w (mu - x) + Phi^T Qown e_own - Qm e_prev ;   Phi^T v = [v_p ; dt v_p + v_v]
+#pragma unroll
+  for (int a = 0; a < DOF; ++a) {
+    r[a] = w * ep[a] + mN * wo[a] - mP * wm[a];
+    r[DOF + a] = w * ep[DOF + a] + mN * (dt * wo[a] + wo[DOF + a]) - mP * wm[DOF + a];
+  }
+}
+
+// diagonal block of row g without the single-state factors: delta I + prior + mN Phi^T Qown Phi + mP Qm
+template <int DOF>
+DGP_HD void generic_diag(const GnParams& p, int g, bool valid, const Sym<2 * DOF>& Qown, const Sym<2 * DOF>& Qm, Sym<2 * DOF>& Dm,
+                         double& m_next) {
+  constexpr int D = 2 * DOF;
+  const int n = p.n;
+  const double dt = p.dt;
+  const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
+  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  m_next = mN;
+  const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
+  const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
+  // A = Phi^T Q Phi:  A_pp = Q_pp,  A_pv = dt Q_pp + Q_pv,  A_vv = dt (dt Q_pp + Q_pv) + dt Q_vp + Q_vv
+#pragma unroll
+  for (int a = 0; a < DOF; ++a)
+#pragma unroll
+    for (int c = 0; c < DOF; ++c) {
+      const double apv = dt * Qown(a, c) + Qown(a, DOF + c);
+      if (c >= a) {
+        Dm(a, c) = ((a == c) ? dbase + w : 0.0) + mN * Qown(a, c) + mP * Qm(a, c);
+        Dm(DOF + a, DOF + c) = ((a == c) ? dbase + w : 0.0) + mN * (dt * apv + dt * Qown(DOF + a, c) + Qown(DOF + a, DOF + c)) + mP * Qm(DOF + a, DOF + c);
+      }
+      Dm(a, DOF + c) = mN * apv + mP * Qm(a, DOF + c);
+    }
 }
 
 // Per-lane inputs that do not depend on the elimination: the obstacle factors of the lane's C states (all SDF loads
@@ -1069,7 +1369,7 @@ struct Nbr {
 // So K = U_i + U_partner^T (one of the two terms is zero) and one elimination  D_i -= K D_p^-1 K^T,  r_i -= K D_p^-1 r_p
 // replaces the two half-empty ones of the generic round; no coupling survives.
 template <int D, int LPT, int S, typename Ctx>
-DGP_HD void pcr_last_round(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], bool& ok) {
+DGP_HD void pcr_last_round(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   const Nbr<LPT, S, Ctx> nb(cx, i);
   Sym<D> Di, DiP;
   sym_inverse<D>(Dm, Di, ok);
@@ -1115,7 +1415,7 @@ DGP_HD void pcr_last_round(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (
 
 // one PCR round at stride S
 template <int D, int LPT, int S, typename Ctx>
-DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], bool& ok) {
+DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   constexpr bool last = (2 * S >= LPT);
   if constexpr (last && LPT >= 2) { pcr_last_round<D, LPT, S>(cx, i, Dm, U, r, ok); return; }
   const Nbr<LPT, S, Ctx> nb(cx, i);
@@ -1220,7 +1520,7 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], boo
 }
 
 template <int D, int LPT, typename Ctx>
-DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], double (&x)[D], bool& ok) {
+DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], double (&x)[D], SpdCheck<Ctx>& ok) {
   if constexpr (LPT > 1) pcr_round<D, LPT, 1>(cx, i, Dm, U, r, ok);
   if constexpr (LPT > 2) pcr_round<D, LPT, 2>(cx, i, Dm, U, r, ok);
   if constexpr (LPT > 4) pcr_round<D, LPT, 4>(cx, i, Dm, U, r, ok);
@@ -1263,14 +1563,6 @@ DGP_HD double group_sum_to_first(Ctx& cx, double v) {
   }
 }
 
-template <int LPT, typename Ctx>
-DGP_HD int group_or(Ctx& cx, int v) {
-  const int lane = cx.lane();
-#pragma unroll
-  for (int m = LPT / 2; m >= 1; m >>= 1) v |= cx.fetch_i(v, lane ^ m);
-  return v;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // The coupling blocks U_k (block (k, k+1)) of the rows a lane owns, in two representations:
 //   generic (QSTAT = false): U_k = -m_k Phi^T Q_k with the row's symmetric Q_k^-1 (d(d+1)/2 values instead of d^2) and a
@@ -1279,13 +1571,18 @@ DGP_HD int group_or(Ctx& cx, int v) {
 //                            nothing but the masks is kept in vector registers, the block itself is a scalar operand and
 //                            its structural zeros (gp_nz) are skipped.
 // ---------------------------------------------------------------------------------------------------
-template <int D, int N, bool QSTAT> struct Coupling;
-template <int D, int N> struct Coupling<D, N, false> { Sym<D> q[N]; double m[N]; double dt; };
-template <int D, int N> struct Coupling<D, N, true> { double m[N]; };
+//   Kronecker (QK_KRON)    : per-state Q_c^-1 tensors.  Q_k^-1 = T (x) C_k, hence U_k = -m_k (E (x) C_k) and Phi^T Q_k^-1 Phi = F (x) C_k
+//                            with the 2 x 2 constants T, E, F (GnParams::qa.., e10, e11, f11; scalar operands): a row keeps the
+//                            symmetric dof x dof C_k (3 values for d = 4 instead of the 10 of Q_k^-1) and every product with U_k
+//                            is "C_k applied to the position and velocity halves, mixed by a constant 2 x 2" (kron_apply).
+template <int D, int N, int QK> struct Coupling;
+template <int D, int N> struct Coupling<D, N, QK_GENERAL> { Sym<D> q[N]; double m[N]; double dt; };
+template <int D, int N> struct Coupling<D, N, QK_STATIC> { double m[N]; };
+template <int D, int N> struct Coupling<D, N, QK_KRON> { Sym<D / 2> c[N]; double m[N]; };
 
 // G = S^-1 U_k
 template <int D, int N>
-DGP_HD void coup_SinvU(const GnParams&, const Coupling<D, N, false>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
+DGP_HD void coup_SinvU(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
   // S^-1 U = -m (S^-1 Phi^T) Q,   (S^-1 Phi^T)[a][c] = S^-1[a][c] + (c < dof ? dt S^-1[a][dof + c] : 0)
   constexpr int DOF = D / 2;
   double A[D][D];
@@ -1305,7 +1602,7 @@ DGP_HD void coup_SinvU(const GnParams&, const Coupling<D, N, false>& cp, int k, 
     }
 }
 template <int D, int N>
-DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
+DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, QK_STATIC>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
   Sym<D> Sm;
 #pragma unroll
   for (int i = 0; i < D * (D + 1) / 2; ++i) Sm.v[i] = cp.m[k] * Si.v[i];
@@ -1321,7 +1618,7 @@ DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, true>& cp, int k,
 }
 // S -= U_k^T B (symmetric result).  Static form: B is G_k = S_k^-1 U_k, which already carries the mask.
 template <int D, int N>
-DGP_HD void coup_sub_UtB_sym(const GnParams&, const Coupling<D, N, false>& cp, int k, Sym<D>& S, const Mat<D>& B) {
+DGP_HD void coup_sub_UtB_sym(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, Sym<D>& S, const Mat<D>& B) {
   // U^T B = -Q Phi B (B carries the mask):  S += Q (Phi B),  (Phi B)[a] = B[a] + dt B[dof + a] for a < dof
   constexpr int DOF = D / 2;
   double PB[D][D];
@@ -1340,7 +1637,7 @@ DGP_HD void coup_sub_UtB_sym(const GnParams&, const Coupling<D, N, false>& cp, i
     }
 }
 template <int D, int N>
-DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int, Sym<D>& S, const Mat<D>& B) {
+DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, QK_STATIC>&, int, Sym<D>& S, const Mat<D>& B) {
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -1353,7 +1650,7 @@ DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, true>&, int
 }
 // o -= U_k^T v
 template <int D, int N>
-DGP_HD void coup_sub_Ut_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
+DGP_HD void coup_sub_Ut_v(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, double (&o)[D], const double (&v)[D]) {
   // o -= U^T v = o + m Q (Phi v)
   constexpr int DOF = D / 2;
   double pv[D];
@@ -1368,7 +1665,7 @@ DGP_HD void coup_sub_Ut_v(const GnParams&, const Coupling<D, N, false>& cp, int 
   }
 }
 template <int D, int N>
-DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
+DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, QK_STATIC>& cp, int k, double (&o)[D], const double (&v)[D]) {
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double t = 0.0;
@@ -1379,7 +1676,7 @@ DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, true>& cp, int
 }
 // o -= U_k v
 template <int D, int N>
-DGP_HD void coup_sub_U_v(const GnParams&, const Coupling<D, N, false>& cp, int k, double (&o)[D], const double (&v)[D]) {
+DGP_HD void coup_sub_U_v(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, double (&o)[D], const double (&v)[D]) {
   // o -= U v = o + m Phi^T (Q v)
   constexpr int DOF = D / 2;
   double w[D];
@@ -1394,7 +1691,7 @@ DGP_HD void coup_sub_U_v(const GnParams&, const Coupling<D, N, false>& cp, int k
   for (int a = 0; a < D; ++a) o[a] += cp.m[k] * ((a < DOF) ? w[a] : cp.dt * w[a - DOF] + w[a]);
 }
 template <int D, int N>
-DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int k, double (&o)[D], const double (&v)[D]) {
+DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, QK_STATIC>& cp, int k, double (&o)[D], const double (&v)[D]) {
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double t = 0.0;
@@ -1405,7 +1702,7 @@ DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, true>& cp, int 
 }
 // O = sgn * A U_k   (sgn = +1 / -1)
 template <int D, int N>
-DGP_HD void coup_A_U(const GnParams&, const Coupling<D, N, false>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
+DGP_HD void coup_A_U(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
   // A U = -m (A Phi^T) Q,   (A Phi^T)[a][c] = A[a][c] + (c < dof ? dt A[a][dof + c] : 0)
   constexpr int DOF = D / 2;
   double AP[D][D];
@@ -1425,7 +1722,7 @@ DGP_HD void coup_A_U(const GnParams&, const Coupling<D, N, false>& cp, int k, co
     }
 }
 template <int D, int N>
-DGP_HD void coup_A_U(const GnParams& p, const Coupling<D, N, true>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
+DGP_HD void coup_A_U(const GnParams& p, const Coupling<D, N, QK_STATIC>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
   const double f = sgn * cp.m[k];
 #pragma unroll
   for (int a = 0; a < D; ++a)
@@ -1439,7 +1736,7 @@ DGP_HD void coup_A_U(const GnParams& p, const Coupling<D, N, true>& cp, int k, c
 }
 // the block itself, in vector registers (the separator row's coupling is PCR state)
 template <int D, int N>
-DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Mat<D>& U) {
+DGP_HD void coup_get(const GnParams&, const Coupling<D, N, QK_GENERAL>& cp, int k, Mat<D>& U) {
   constexpr int DOF = D / 2;
   const double nm = -cp.m[k];
 #pragma unroll
@@ -1451,11 +1748,78 @@ DGP_HD void coup_get(const GnParams&, const Coupling<D, N, false>& cp, int k, Ma
     }
 }
 template <int D, int N>
-DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, Mat<D>& U) {
+DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, QK_STATIC>& cp, int k, Mat<D>& U) {
 #pragma unroll
   for (int a = 0; a < D; ++a)
 #pragma unroll
     for (int c = 0; c < D; ++c) U.v[a][c] = gp_nz<D>(a, c) ? cp.m[k] * p.u_fix[a * D + c] : 0.0;
+}
+
+// ---- QK_KRON forms of the six products above (E = [[qa, qb],[e10, e11]]; U_k = -m_k (E (x) C_k), U_k^T = -m_k (E^T (x) C_k)) ----
+template <int D, int N>
+DGP_HD void coup_SinvU(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, const Sym<D>& Si, Mat<D>& G) {
+  // row a of S^-1 U = -m ( (E^T (x) C) S^-1[a,:]^T )^T
+  const double nm = -cp.m[k];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double row[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) row[c] = Si(a, c);
+    kron_apply<D / 2>(p.qa, p.e10, p.qb, p.e11, cp.c[k], row, o);
+#pragma unroll
+    for (int c = 0; c < D; ++c) G.v[a][c] = nm * o[c];
+  }
+}
+template <int D, int N>
+DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, Sym<D>& S, const Mat<D>& B) {
+  // S -= U^T B = S + (E^T (x) C) B   (B carries the mask), upper triangle only
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double col[D], o[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) col[a] = B.v[a][c];
+    kron_apply<D / 2>(p.qa, p.e10, p.qb, p.e11, cp.c[k], col, o);
+#pragma unroll
+    for (int a = 0; a <= c; ++a) S(a, c) += o[a];
+  }
+}
+template <int D, int N>
+DGP_HD void coup_sub_Ut_v(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, double (&o)[D], const double (&v)[D]) {
+  double t[D];
+  kron_apply<D / 2>(p.qa, p.e10, p.qb, p.e11, cp.c[k], v, t);            // (E^T (x) C) v
+#pragma unroll
+  for (int a = 0; a < D; ++a) o[a] += cp.m[k] * t[a];
+}
+template <int D, int N>
+DGP_HD void coup_sub_U_v(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, double (&o)[D], const double (&v)[D]) {
+  double t[D];
+  kron_apply<D / 2>(p.qa, p.qb, p.e10, p.e11, cp.c[k], v, t);            // (E (x) C) v
+#pragma unroll
+  for (int a = 0; a < D; ++a) o[a] += cp.m[k] * t[a];
+}
+template <int D, int N>
+DGP_HD void coup_A_U(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, const Mat<D>& A, double sgn, Mat<D>& O) {
+  const double f = -sgn * cp.m[k];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double o[D];
+    kron_apply<D / 2>(p.qa, p.e10, p.qb, p.e11, cp.c[k], A.v[a], o);     // row a of A (E (x) C)
+#pragma unroll
+    for (int c = 0; c < D; ++c) O.v[a][c] = f * o[c];
+  }
+}
+template <int D, int N>
+DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k, Mat<D>& U) {
+  constexpr int DOF = D / 2;
+  const double nm = -cp.m[k];
+#pragma unroll
+  for (int a = 0; a < DOF; ++a)
+#pragma unroll
+    for (int c = 0; c < DOF; ++c) {
+      const double v = nm * cp.c[k](a, c);
+      U.v[a][c] = p.qa * v; U.v[a][DOF + c] = p.qb * v;
+      U.v[DOF + a][c] = p.e10 * v; U.v[DOF + a][DOF + c] = p.e11 * v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1483,11 +1847,12 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, true>& cp, int k, M
 // ---------------------------------------------------------------------------------------------------
 // `before_pcr(acc)` is called once every factor of the lane has been evaluated (the error partials are complete) and before
 // the PCR rounds: MODE_STEP reduces and stores err / err_ext there, off the tail of the kernel.
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx, typename Hook>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
-                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
-                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok, Hook&& before_pcr) {
+                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
+                            const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
   constexpr int D = 2 * DOF;
+  constexpr bool QSTAT = (QK == QK_STATIC);
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
   constexpr int KL = (C > 1) ? C - 2 : 0;       // last interior row
   const int n = p.n;
@@ -1499,29 +1864,33 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 
   const int g0 = j * C;
   LaneFactors<C> lf;
-  double rgp[QSTAT ? C : 1][D];  // static path: prior + GP part of eta, computed while the SDF taps are in flight
+  double rgp[C][D];              // prior + GP part of eta, computed while the SDF taps are in flight
   {
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
     DGP_STAMP_NOWAIT(p, cx, 8);
-    if constexpr (QSTAT) {
-      // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
-      double mu_ga[D];
+    // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
+    double mu_ga[D];
 #pragma unroll
-      for (int a = 0; a < D; ++a) mu_ga[a] = mu_g[a];
-      lane_after_addresses<C, IO, D>(taps, mu_ga);
+    for (int a = 0; a < D; ++a) mu_ga[a] = mu_g[a];
+    lane_after_addresses<C, IO, D>(taps, mu_ga);
 #pragma unroll
-      for (int k = 0; k < C; ++k)
-        static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0],
-                        (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0], mu_s, mu_ga, rgp[k], acc);
-      // first components of every row's eta (each is the end of that row's dependency chain)
-      double anchor[2 * C];
-#pragma unroll
-      for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
-      DGP_STAMP_NOWAIT(p, cx, 9);
-      lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
-      DGP_STAMP_NOWAIT(p, cx, 10);
+    for (int k = 0; k < C; ++k) {
+      const double (&xm)[D] = (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0];
+      const double (&xp)[D] = (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0];
+      if constexpr (QK == QK_STATIC) static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, rgp[k], acc);
+      else if constexpr (QK == QK_KRON) kron_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, lq.c[k],
+                                                      (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], rgp[k], acc);
+      else generic_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, lq.q[k], (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0],
+                            rgp[k], acc);
     }
+    // first components of every row's eta (each is the end of that row's dependency chain)
+    double anchor[2 * C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
+    DGP_STAMP_NOWAIT(p, cx, 9);
+    lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
+    DGP_STAMP_NOWAIT(p, cx, 10);
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
@@ -1531,25 +1900,15 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     for (int k = 0; k < C; ++k)
 #pragma unroll
       for (int a = 0; a < D; ++a)
-        dx[k][a] = x[k][a] + x_prev[a] + x_next[a] + (DGP_PHASE_STOP == 2 ? lf.oc[k] + lf.ohx[k] + lf.ohy[k] + (QSTAT ? rgp[QSTAT ? k : 0][a] : 0.0) : 0.0);
+        dx[k][a] = x[k][a] + x_prev[a] + x_next[a] + (DGP_PHASE_STOP == 2 ? lf.oc[k] + lf.ohx[k] + lf.ohy[k] + rgp[k][a] : 0.0);
     return;
   }
 #endif
-  const bool stat = (p.qc_mode == QC_STATIC);
-  Sym<D> Qown, Qm;               // generic path: Q^-1 of the row's own GP factor (g -> g+1) / of the factor (g-1 -> g)
-  Sym<D> Qm0;                    // generic path: Q^-1 of the factor into the lane's FIRST row (kept for the recovery)
-  if (!QSTAT) {
-    fixed_Qinv<DOF>(p, Qown);    // static covariances on the generic path: built once; per-state modes: reloaded per row
-    fixed_Qinv<DOF>(p, Qm);
-    if (!stat && traj_ok && g0 > 0 && g0 < n) load_Qinv<DOF, IO>(p, b, g0 - 1, Qm);
-    Qm0 = Qm;
-  }
-
   // kept for the interior recovery (d.)
   Sym<D> Sinv[CI];
   double z[CI][D];
-  Coupling<D, C, QSTAT> cp;      // U_k of all C rows
-  if constexpr (!QSTAT) cp.dt = p.dt;
+  Coupling<D, C, QK> cp;         // U_k of all C rows
+  if constexpr (QK == QK_GENERAL) cp.dt = p.dt;
   double m_prev0 = 0.0;          // L_0 = -m_prev0 Qm0 Phi  (static path: m_prev0 * p.u_fix^T)
   // running quantities of the streamed elimination
   Mat<D> G, Pi, W0;
@@ -1557,22 +1916,21 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   double P0[D], Pl[D];
 
   // assemble one row (D_k, r_k; U_k goes into cp)
-  auto assemble = [&](int k, const double (&xm)[D], const double (&xp)[D], Sym<D>& Dk, double (&rk)[D]) {
+  auto assemble = [&](int k, Sym<D>& Dk, double (&rk)[D]) {
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
-    if constexpr (QSTAT) {
+    if constexpr (QK == QK_STATIC) {
       static_diag<DOF>(p, g, valid, Dk, cp.m[k]);
-#pragma unroll
-      for (int a = 0; a < D; ++a) rk[a] = rgp[k][a];
-      eval_state_local<DOF, true>(p, x[k], lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, acc);
+    } else if constexpr (QK == QK_KRON) {
+      kron_diag<DOF>(p, g, valid, lq.c[k], (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], Dk, cp.m[k]);
+      cp.c[k] = lq.c[k];
     } else {
-      if (!stat && valid && g < n - 1) load_Qinv<DOF, IO>(p, b, g, Qown);
-      Mat<D> Utmp;                                          // (eval_state's own U; the kept form is Q_k + mask)
-      eval_state<DOF, IO, true>(p, b, g, valid, x[k], xm, xp, mu_s, mu_g, Qown, Qm, lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k],
-                                Dk, Utmp, rk, acc);
-      cp.q[k] = Qown;
-      cp.m[k] = (valid && g < n - 1) ? 1.0 : 0.0;
+      generic_diag<DOF>(p, g, valid, lq.q[k], (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0], Dk, cp.m[k]);
+      cp.q[k] = lq.q[k];
     }
+#pragma unroll
+    for (int a = 0; a < D; ++a) rk[a] = rgp[k][a];
+    eval_state_local<DOF, true>(p, x[k], lf.ow[k], lf.oc[k], lf.ohx[k], lf.ohy[k], Dk, rk, acc);
     if (RHS_OVERRIDE) {
 #pragma unroll
       for (int a = 0; a < D; ++a) rk[a] = valid ? rhs[k][a] : 0.0;
@@ -1583,7 +1941,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
   for (int k = 0; k < C - 1; ++k) {
     Sym<D> Dk; double rk[D];
-    assemble(k, (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0], x[k + 1], Dk, rk);
+    assemble(k, Dk, rk);
     if (k == 0) {
       // left spike L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
       const bool has_prev = traj_ok && g0 > 0 && g0 < n;
@@ -1635,11 +1993,10 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       else { coup_A_U<D, C>(p, cp, k, Mk, -1.0, T); Pi = T; }            // Pi_{k+1} = -Pi_k G_k
     }
     if (k == KL) sym_times_vec<D>(Sinv[k], z[k], Pl);      // P_{C-2} = S^-1 z_{C-2}   (x_{C-2} = P - (..) x_ps - G x_s)
-    if (!QSTAT && !stat) Qm = Qown;
   }
   // ---- c. separator row -> reduced system row
   Sym<D> Ds; Mat<D> Us; double rs[D];
-  assemble(C - 1, (C > 1) ? x[C > 1 ? C - 2 : 0] : x_prev, x_next, Ds, rs);
+  assemble(C - 1, Ds, rs);
   if (C == 1 || !QSTAT) coup_get<D, C>(p, cp, C - 1, Us);
   if (C > 1) {
     coup_sub_UtB_sym<D, C>(p, cp, KL, Ds, G);             // D_s -= U_{C-2}^T W_{C-2},  W_{C-2} = G_{C-2}
@@ -1746,16 +2103,23 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
         w[a] = m_prev0 * t;
       }
     } else {
-      // L_0 x_ps = -m_prev0 Qm0 (Phi x_ps)
+      // L_0 x_ps = -m_prev0 Q_{g0-1} (Phi x_ps)
       double pv[D];
 #pragma unroll
       for (int a = 0; a < D; ++a) pv[a] = (a < DOF) ? xps[a] + p.dt * xps[DOF + a] : xps[a];
+      if constexpr (QK == QK_KRON) {
+        double t[D];
+        kron_apply<DOF>(p.qa, p.qb, p.qb, p.qc_, lq.cm0, pv, t);
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double t = 0.0;
+        for (int a = 0; a < D; ++a) w[a] = -m_prev0 * t[a];
+      } else {
 #pragma unroll
-        for (int c = 0; c < D; ++c) t += Qm0(a, c) * pv[c];
-        w[a] = -m_prev0 * t;
+        for (int a = 0; a < D; ++a) {
+          double t = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; ++c) t += lq.qm0(a, c) * pv[c];
+          w[a] = -m_prev0 * t;
+        }
       }
     }
 #pragma unroll
@@ -1783,11 +2147,11 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   }
 }
 
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, bool QSTAT, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, typename Ctx>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
-                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[C][2 * DOF],
-                            double (&dx)[C][2 * DOF], ErrAcc& acc, bool& ok) {
-  gn_linear_solve<DOF, LPT, C, IO, RHS_OVERRIDE, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, rhs, dx, acc, ok, [](const ErrAcc&) {});
+                            const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
+                            const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok) {
+  gn_linear_solve<DOF, LPT, C, IO, RHS_OVERRIDE, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, rhs, dx, acc, ok, [](const ErrAcc&) {});
 }
 
 // errors only (no assembly): sums over the lane's C rows
@@ -1893,7 +2257,7 @@ DGP_HD void load_rows_through_lds(Ctx& cx, const void* in, int64_t wave_first_el
 // ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
-template <int DOF, int LPT, int C, typename IO, int MODE, bool QSTAT, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, int MODE, int QK, typename Ctx>
 DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;                 // trajectories per wavefront
@@ -1912,6 +2276,8 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];
+  LaneQ<D, C, QK> lq;                           // generic covariances: Q^-1 of the lane's C + 1 GP factors, loaded once (loop-invariant in MODE_SOLVE)
+  if constexpr (MODE != MODE_EVAL) load_lane_Q<DOF, C, IO>(p, b, j * C, traj_ok, lq);
   // wave-uniform: the wavefront's th rows are one contiguous, fully populated block -> full-line loads via LDS (-0.3 us)
   bool block_load = false;
   if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32 && MODE == MODE_STEP)
@@ -1945,14 +2311,13 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int iters_max = (MODE == MODE_SOLVE) ? p.max_iters : 1;
   bool active = traj_ok;
   int my_iters = 0;
-  int bad = 0;
+  SpdCheck<Ctx> ok = {&cx, 0};            // accumulates over the GN iterations of MODE_SOLVE
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
-    bool ok = true;
     double e = 0.0, ee = 0.0;
-    gn_linear_solve<DOF, LPT, C, IO, false, QSTAT>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, [&](const ErrAcc& a) {
+    gn_linear_solve<DOF, LPT, C, IO, false, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
       e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
       if (MODE == MODE_STEP && traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, div_M(p, e));
@@ -1960,7 +2325,6 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       }
     });
     DGP_STAMP_NOWAIT(p, cx, 4);
-    bad |= (traj_ok && !ok) ? 1 : 0;
     if (MODE == MODE_STEP) {
       // wave-uniform: the wavefront's dtheta rows are one contiguous, fully populated block -> full-line stores via LDS
       bool block_store = false;
@@ -1999,9 +2363,10 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     }
   }
   DGP_STAMP_NOWAIT(p, cx, 5);
-  if (p.info) {                                        // (wave-uniform: the reduction is skipped when nobody asked)
-    bad = group_or<LPT>(cx, bad);
-    if (traj_ok && j == 0) p.info[b] = bad;
+  if (p.info) {                                        // (wave-uniform)
+    const int base = lane & ~(LPT - 1);                // first lane of this trajectory's group
+    const uint64_t grp = (LPT == 64) ? ok.bad : ((ok.bad >> base) & ((uint64_t(1) << (LPT & 63)) - 1));
+    if (traj_ok && j == 0) p.info[b] = grp != 0 ? 1 : 0;
   }
   DGP_STAMP(p, cx, 6);
   if (MODE == MODE_SOLVE) {

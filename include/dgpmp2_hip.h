@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGP_ABI_VERSION 1
+#define DGP_ABI_VERSION 2
 
 /* status codes */
 #define DGP_OK              0
@@ -164,6 +164,13 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          void* g_th, void* g_start, void* g_goal,
                          void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                          void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);
+
+/* Measurement aid (no counterpart in the reference): the NEXT kernel launched by the calling thread through any entry point
+ * above records its own begin and end on the two HIP events (hipEvent_t, created with timing enabled, cast to void*), the way
+ * hipExtLaunchKernelGGL does -- hipEventElapsedTime(start, stop) is then that kernel's execution time, the quantity
+ * rocprofv3 --kernel-trace reports, with no marker packets between back-to-back launches.  One-shot: consumed by that launch.
+ * Passing NULL for either event cancels a pending request. */
+int dgp_time_next_launch(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

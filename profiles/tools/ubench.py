@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Steady-clock kernel timing of one C-ABI entry point on a chosen workload (tuning loop; honours DGP_LIB_PATH for a
+profiles/tools/devbuild.py library and DGP_FORCE_SHAPE).  Two numbers per case: `period_us` = HIP events around `reps`
+back-to-back launches / reps (kernel + inter-kernel gap), `kernel_us` = mean of per-kernel begin/end events
+(dgp_time_next_launch; what rocprofv3 reports as the kernel's duration).
+
+  python profiles/tools/ubench.py --what step,solve,bwd,bwd_sdf8 [--covs static|perstate|qfull] [--dof 2|3] [--sdf shared|persample]
+                                  [--B 4096] [--n 64] [--G 256] [--io f32|f64] [--flags vel|nonhol] [--reps 1000] [--tag text]
+"""
+import argparse, ctypes, json, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from bench import make_inputs, make_per_sample_sdfs, algorithmic_bytes_per_trajectory, prewarm
+from dgpmp2_amd import _capi
+from dgpmp2_amd.gpmp2.plan_layer import solver_config
+
+
+def measure(launch, reps, timer, warm=0.3):
+  prewarm(launch, warm, 100)
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  torch.cuda.synchronize(); e0.record()
+  for k in range(reps): launch(k)
+  e1.record(); torch.cuda.synchronize()
+  period = e0.elapsed_time(e1) / reps * 1e3
+  timer.reset()
+  nk = min(reps, len(timer.pairs))
+  for k in range(nk):
+    timer.arm(); launch(k)
+  torch.cuda.synchronize()
+  d = np.asarray(timer.durations_ms()) * 1e3
+  return round(period, 2), round(float(d.mean()), 2), round(float(np.median(d)), 2)
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--what', default='step')
+  ap.add_argument('--covs', default='static'); ap.add_argument('--dof', type=int, default=2); ap.add_argument('--sdf', default='shared')
+  ap.add_argument('--B', type=int, default=4096); ap.add_argument('--n', type=int, default=64); ap.add_argument('--G', type=int, default=0)
+  ap.add_argument('--io', default='f32'); ap.add_argument('--flags', default=''); ap.add_argument('--reps', type=int, default=1000)
+  ap.add_argument('--iters', type=int, default=10); ap.add_argument('--tag', default=''); ap.add_argument('--info', type=int, default=1)
+  a = ap.parse_args()
+  dev = torch.device('cuda:0')
+  dt = torch.float32 if a.io == 'f32' else torch.float64
+  B, n, dof = a.B, a.n, a.dof
+  d = 2 * dof
+  G = a.G or (512 if dof == 3 else 256)
+  kw = {}
+  if 'vel' in a.flags: kw.update(use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0)
+  if 'nonhol' in a.flags or (dof == 3 and a.flags == ''): kw.update(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)
+  th0, start, goal, sdf = [t.to(dt) for t in make_inputs(B, n, G, dev, dof=dof)]
+  if a.sdf == 'persample':
+    sdf = make_per_sample_sdfs(B, G, dev).to(dt); stride = G * G
+  else:
+    stride = 0
+  s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=dt, **kw))
+  sa = s.sdf_arg(sdf.data_ptr(), G, G, stride)
+  st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  P = lambda t: None if t is None else t.data_ptr()
+  covs, keep = None, []
+  if a.covs != 'static':
+    if a.covs == 'perstate':
+      qc = torch.eye(dof, device=dev, dtype=dt).expand(B, n - 1, dof, dof).contiguous(); mode = _capi.DGP_QC_PERSTATE
+    else:
+      from oracle import gpmp2_oracle as O
+      p = O.OracleParams(dof=dof, total_time_step=n - 1)
+      Q = O.calc_Q_inv_batch(np.broadcast_to(np.eye(dof), (1, n - 1, dof, dof)).copy(), p.dt)
+      qc = torch.from_numpy(Q).to(dt).to(dev).expand(B, n - 1, d, d).contiguous(); mode = _capi.DGP_QC_QFULL
+    ow = torch.full((B, n), 1e4, device=dev, dtype=dt); ep = torch.full((B, n), float(kw.get('epsilon_dist', 0.4)), device=dev, dtype=dt)
+    keep = [qc, ow, ep]
+    covs = s.covs_arg(mode, qc.data_ptr(), ow.data_ptr(), ep.data_ptr())
+  dth = torch.empty_like(th0); err = torch.empty(B, device=dev, dtype=dt); eex = torch.empty_like(err)
+  info = torch.zeros(B, dtype=torch.int32, device=dev) if a.info else None
+  ths = [th0]
+  for _ in range(3):
+    s.gn_step(B, P(ths[-1]), P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st); ths.append(ths[-1] + dth)
+  torch.cuda.synchronize()
+  assert bool(torch.isfinite(ths[-1]).all())
+  tp = [t.data_ptr() for t in ths]
+  timer = _capi.KernelTimer(min(a.reps, 1000))
+  out = dict(tag=a.tag, lib=os.path.basename(_capi.LIB_PATH), B=B, n=n, dof=dof, io=a.io, covs=a.covs, sdf=a.sdf, flags=a.flags, shape=list(s.launch_shape(B)))
+  for what in a.what.split(','):
+    if what == 'step':
+      f = lambda k: s.gn_step(B, tp[k % 4], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
+      by = algorithmic_bytes_per_trajectory(n, d, io_bytes=4 if a.io == 'f32' else 8, cov_tensors=(a.covs == 'perstate')) * B
+    elif what == 'solve':
+      tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev); eh = torch.empty(B, a.iters, device=dev, dtype=dt)
+      eeh = torch.empty_like(eh)
+      f = lambda k: s.gn_solve(B, tp[0], P(start), P(goal), sa, covs, a.iters, 0.0, P(tho), P(it), P(eh), P(eeh), None, P(info), st)
+    elif what == 'eval':
+      f = lambda k: s.eval_errors(B, tp[k % 4], P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st)
+    elif what.startswith('bwd'):
+      g = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
+      ge = torch.ones(B, device=dev, dtype=dt)
+      gq = torch.empty_like(keep[0]) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
+      gp = torch.empty(B, n, device=dev, dtype=dt) if covs else None
+      copies = 8 if what == 'bwd_sdf8' else 1
+      gs = None
+      if what != 'bwd':
+        gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=dt)
+      s.gn_step(B, tp[3], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
+      f = lambda k: s.gn_step_backward(B, tp[3], P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
+                                       P(gq), P(gw), P(gp), st, g_sdf_copies=copies)
+    else:
+      raise SystemExit('unknown --what ' + what)
+    reps = a.reps if what != 'solve' else max(20, a.reps // a.iters)
+    period, kmean, kmed = measure(f, reps, timer)
+    out[what] = dict(period_us=period, kernel_us=kmean, kernel_med_us=kmed)
+    if what == 'step': out[what]['alg_GBs'] = round(by / (kmean * 1e-6) / 1e9, 1)
+    if what == 'solve': out[what]['us_per_iter'] = round(kmean / a.iters, 2)
+  print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+  main()

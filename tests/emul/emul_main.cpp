@@ -79,6 +79,14 @@ struct HostCtx {
     pthread_barrier_wait(&ws->bar);
     return r != 0;
   }
+  uint64_t ballot(bool pred) {      // bit l = pred of lane l
+    ws->islot[lane_] = pred ? 1 : 0;
+    pthread_barrier_wait(&ws->bar);
+    uint64_t r = 0;
+    for (int k = 0; k < 64; ++k) r |= (uint64_t)(ws->islot[k] & 1) << k;
+    pthread_barrier_wait(&ws->bar);
+    return r;
+  }
   int xcc_id() const { return wave_ & 7; }          // the emulator spreads "wavefronts" over 8 pretend XCDs
   template <typename T>
   void atomic_add(T* p, T v, bool = false) {
@@ -94,19 +102,22 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
   for (int l = 0; l < 64; ++l) {
     th.emplace_back([&, l]() {
       HostCtx cx{&ws, l, wave};
-      // same dispatch as dgp_dev::launch_typed: static covariances run the QSTAT specialisation
-      const bool qstat = dgp::use_static_kernels(p);
+      // same dispatch as dgp_dev::launch_typed: the kernel variant follows the covariance representation
+      const int qk = dgp::kernel_variant(p);
       if (mode == dgp::MODE_STEP) {
-        if (qstat) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, true>(p, cx);
-        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, false>(p, cx);
+        if (qk == dgp::QK_STATIC) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_STATIC>(p, cx);
+        else if (qk == dgp::QK_KRON) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_KRON>(p, cx);
+        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_GENERAL>(p, cx);
       } else if (mode == dgp::MODE_SOLVE) {
-        if (qstat) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, true>(p, cx);
-        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, false>(p, cx);
+        if (qk == dgp::QK_STATIC) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>(p, cx);
+        else if (qk == dgp::QK_KRON) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_KRON>(p, cx);
+        else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>(p, cx);
       } else if (mode == dgp::MODE_EVAL) {
-        dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL, false>(p, cx);
+        dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>(p, cx);
       } else {
-        if (qstat) dgp::gn_backward_lane_program<DOF, LPT, C, IO, true>(p, *g, cx);
-        else dgp::gn_backward_lane_program<DOF, LPT, C, IO, false>(p, *g, cx);
+        if (qk == dgp::QK_STATIC) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC>(p, *g, cx);
+        else if (qk == dgp::QK_KRON) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_KRON>(p, *g, cx);
+        else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_GENERAL>(p, *g, cx);
       }
     });
   }
@@ -144,6 +155,8 @@ const char* emul_last_error(void) { return dgp_host::err_buf(); }
 int emul_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create(cfg, out); }
 void emul_destroy(DgpHandle* h) { delete h; }
 int emul_num_factor_rows(const DgpHandle* h) { return h ? h->M : DGP_EINVAL; }
+
+int emul_time_next_launch(void*, void*) { return DGP_OK; }      // nothing to time: the emulator runs on the host
 
 int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
   if (!h || batch <= 0) return DGP_EINVAL;
