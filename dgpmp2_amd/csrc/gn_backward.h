@@ -26,6 +26,56 @@ struct GnGradParams {
   int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Scatter-add of the SDF gradient.  An atomic instruction costs the memory pipeline one pass per DISTINCT cache line among
+// its 64 lane addresses, not per lane (profiles/tools/atomic_probe.hip: 1024 wavefronts x 16 instructions take 51 us with 64
+// scattered pixels per instruction, 27 us when lanes 2m, 2m+1 hit adjacent pixels; atomic scope makes no difference).  The two
+// taps of a state in one grid row ARE adjacent pixels, so the taps are redistributed through LDS: lane s writes its pair
+// {(i_x1, v_x1), (i_x2, v_x2)} of a row, and lane L of the half h re-reads entry L of lanes 32h .. 32h+31 -- lanes 2m, 2m+1 then
+// carry the two adjacent pixels of lane 32h + m's state.  Same number of atomic instructions, half the line passes.
+//
+// Partial copies of a shared grid (g_sdf_copies > 1): XCD-local (workgroup-scope) atomics are only sound when no two XCDs
+// share a copy -- gfx950 has at most 8 XCDs (XCC_ID 0..7), so with >= 8 copies every copy belongs to ONE XCD; with a multiple of
+// 8 the wavefronts of an XCD spread over copies xcc, xcc + 8, ... (same-pixel updates serialise over copies / 8 lines of that
+// L2 instead of one).  Fewer than 8 copies still spread the contention, but two non-coherent L2s may then target one copy ->
+// device-scope atomics.
+// ---------------------------------------------------------------------------------------------------
+template <typename IO> struct __attribute__((aligned(2 * sizeof(IO) >= 8 ? 2 * sizeof(IO) : 8))) TapEntry { int32_t idx; IO val; };
+
+template <int LPT, int C, typename IO, typename Ctx>
+DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx, const int32_t (&tap_i)[C][4], const IO (&tap_v)[C][4]) {
+  constexpr int TPW = 64 / LPT;
+  typedef TapEntry<IO> E;
+  const int lane = cx.lane();
+  const bool local = gp.g_sdf_copies >= kMaxXcds;
+  IO* base = (IO*)gp.g_sdf;
+  if (gp.g_sdf_copies > 1) {
+    const int xcc = cx.xcc_id();
+    const int per_xcd = gp.g_sdf_copies / kMaxXcds;
+    const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? xcc + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;
+    base += (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
+  }
+  E* l = (E*)cx.lds();
+#pragma unroll
+  for (int k = 0; k < C; ++k)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      E e0, e1;
+      e0.idx = tap_i[k][2 * r]; e0.val = tap_v[k][2 * r];
+      e1.idx = tap_i[k][2 * r + 1]; e1.val = tap_v[k][2 * r + 1];
+      l[2 * lane] = e0; l[2 * lane + 1] = e1;
+      cx.lds_sync();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const E e = l[h * 64 + lane];
+        const int src = h * 32 + (lane >> 1);                                  // the lane whose state this tap belongs to
+        const int64_t bs = (int64_t)cx.wave() * TPW + (src / LPT);             // ... and its trajectory (per-sample grids)
+        if (e.idx >= 0) cx.atomic_add(base + bs * gp.g_sdf_bstride + e.idx, e.val, local);
+      }
+      cx.lds_sync();
+    }
+}
+
 template <int DOF, int LPT, int C, typename IO, int QK, typename Ctx>
 DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, Ctx& cx) {
   constexpr int D = 2 * DOF;
@@ -80,6 +130,14 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
   LaneTaps<C, IO> taps;
   lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
+  // SDF-gradient contributions of the lane's states: element offset inside the grid (-1: none -- hinge inactive or no such
+  // row) and value for the four taps (x1,y1), (x2,y1), (x1,y2), (x2,y2)
+  int32_t tap_i[C][4];
+  IO tap_v[C][4];
+#pragma unroll
+  for (int k = 0; k < C; ++k)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { tap_i[k][t] = -1; tap_v[k][t] = (IO)0; }
 
 #pragma unroll
   for (int k = 0; k < C; ++k) {
@@ -214,18 +272,12 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         gx[1] += al * (-tp.cross * ir * ir) - ga * hy;
         g_eps = ga;
         g_w = u * rho;
-        if (gp.g_sdf) {
-          IO* gs = (IO*)gp.g_sdf + b * gp.g_sdf_bstride;
-          // XCD-local (workgroup-scope) atomics are only sound when no two XCDs share a copy: gfx950 has at most 8 XCDs
-          // (XCC_ID 0..7), so with >= 8 copies xcc_id % copies is unique per XCD; fewer copies still spread the same-address
-          // contention but two non-coherent L2s may then target one copy -> device-scope atomics
-          const bool local = gp.g_sdf_copies >= kMaxXcds;
-          if (gp.g_sdf_copies > 1) gs += (int64_t)(cx.xcc_id() % gp.g_sdf_copies) * ((int64_t)p.sdf_rows * p.sdf_cols);
+        if (gp.g_sdf) {               // recorded here, scattered after the row loop (sdf_scatter_pairs below)
           const double wa = tp.wjc * tp.wja, wb = tp.wjd * tp.wja, wc = tp.wjc * tp.wjb, wd = tp.wjd * tp.wjb;
-          cx.atomic_add(gs + tp.i11, (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa), local);
-          cx.atomic_add(gs + tp.i21, (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb), local);
-          cx.atomic_add(gs + tp.i12, (IO)(al * (-tp.wjb * ir) + be * (-tp.wjc * ir) - ga * wc), local);
-          cx.atomic_add(gs + tp.i22, (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd), local);
+          tap_i[k][0] = (int32_t)tp.i11; tap_v[k][0] = (IO)(al * (-tp.wja * ir) + be * (tp.wjc * ir) - ga * wa);
+          tap_i[k][1] = (int32_t)tp.i21; tap_v[k][1] = (IO)(al * (tp.wja * ir) + be * (tp.wjd * ir) - ga * wb);
+          tap_i[k][2] = (int32_t)tp.i12; tap_v[k][2] = (IO)(al * (-tp.wjb * ir) + be * (-tp.wjc * ir) - ga * wc);
+          tap_i[k][3] = (int32_t)tp.i22; tap_v[k][3] = (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd);
         }
       }
       if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
@@ -265,6 +317,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
     if (gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gx);
   }
+  if (gp.g_sdf) sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);      // wave-uniform
 }
 
 }  // namespace dgp

@@ -107,7 +107,9 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
 template <int DOF, int LPT, int C, typename IO, int QK>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
-  __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
+  constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
+  constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
+  __shared__ __attribute__((aligned(16))) char lds[kPairBytes > kRowBytes ? kPairBytes : kRowBytes];
   DevCtx cx;
   cx.lds_ = lds;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);

@@ -1116,7 +1116,19 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
     // grids have fewer than 2^31 elements (host-checked): 32-bit element offsets
     const int32_t xb = imin32(t.oa[k].x1, (int32_t)W - 2);
     const int32_t r1 = t.oa[k].y1 * (int32_t)W + xb, r2 = t.oa[k].y2 * (int32_t)W + xb;
+#if defined(DGP_TAPS_NT) && defined(__HIP_DEVICE_COMPILE__)
+    // experiment (profiles/tools/devbuild.py -DDGP_TAPS_NT): non-temporal tap loads -- per-sample grids are read once per launch
+    TapPair<IO> p1, p2;
+    if constexpr (sizeof(IO) == 4) {
+      typedef uint64_t u64a4 __attribute__((aligned(4)));
+      const uint64_t w1 = __builtin_nontemporal_load((const u64a4*)(grid + r1)), w2 = __builtin_nontemporal_load((const u64a4*)(grid + r2));
+      __builtin_memcpy(&p1, &w1, 8); __builtin_memcpy(&p2, &w2, 8);
+    } else {
+      p1 = *(const TapPair<IO>*)(grid + r1); p2 = *(const TapPair<IO>*)(grid + r2);
+    }
+#else
     const TapPair<IO> p1 = *(const TapPair<IO>*)(grid + r1), p2 = *(const TapPair<IO>*)(grid + r2);
+#endif
     t.d11[k] = p1.a; t.d21[k] = p1.b; t.d12[k] = p2.a; t.d22[k] = p2.b;
     t.first1[k] = (t.oa[k].x1 == xb); t.first2[k] = (t.oa[k].x2 == xb);
   }

@@ -50,7 +50,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
 
 
 _ALL_STATIC_COVS = _capi.DgpCovs(_capi.DGP_QC_STATIC, None, None, None)
-_SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2
+_SDF_GRAD_COPIES = 16     # MI355X has 8 XCDs, each with its own L2: two partial grids per XCD (XCD-local atomics, summed afterwards)
 
 
 def _stream():

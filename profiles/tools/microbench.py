@@ -51,6 +51,9 @@ def run(B, n, G, dtype, reps, percov=False):
   gs8 = torch.zeros(8, 1, G, G, device=dev, dtype=dtype)
   out['gn_step_backward_xcd_partial_sdf_grad_us'] = timed(lambda: s.gn_step_backward(B, P(th0), P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo),
                                                                                      P(gs8), 0, PP(gq), PP(gw), PP(gp), st, g_sdf_copies=8), reps)
+  gs16 = torch.zeros(16, 1, G, G, device=dev, dtype=dtype)
+  out['gn_step_backward_16_partial_sdf_grads_us'] = timed(lambda: s.gn_step_backward(B, P(th0), P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo),
+                                                                                      P(gs16), 0, PP(gq), PP(gw), PP(gp), st, g_sdf_copies=16), reps)
   out['gn_step_backward_no_sdf_grad_us'] = timed(lambda: s.gn_step_backward(B, P(th0), P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo),
                                                                             None, 0, PP(gq), PP(gw), PP(gp), st), reps)
   return {k: (round(v, 2) if isinstance(v, float) else v) for k, v in out.items()}

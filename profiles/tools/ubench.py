@@ -39,7 +39,7 @@ def main():
   ap.add_argument('--covs', default='static'); ap.add_argument('--dof', type=int, default=2); ap.add_argument('--sdf', default='shared')
   ap.add_argument('--B', type=int, default=4096); ap.add_argument('--n', type=int, default=64); ap.add_argument('--G', type=int, default=0)
   ap.add_argument('--io', default='f32'); ap.add_argument('--flags', default=''); ap.add_argument('--reps', type=int, default=1000)
-  ap.add_argument('--iters', type=int, default=10); ap.add_argument('--tag', default=''); ap.add_argument('--info', type=int, default=1)
+  ap.add_argument('--iters', type=int, default=10); ap.add_argument('--tag', default=''); ap.add_argument('--info', type=int, default=1); ap.add_argument('--grids', type=int, default=1, help='per-sample SDF: number of distinct 1 GiB grid sets cycled through (>= 5: the touched lines no longer fit the 256 MiB Infinity Cache)'); ap.add_argument('--th', type=int, default=3, help='GN iterations behind the timed trajectory (0: straight-line init)')
   a = ap.parse_args()
   dev = torch.device('cuda:0')
   dt = torch.float32 if a.io == 'f32' else torch.float64
@@ -50,12 +50,14 @@ def main():
   if 'vel' in a.flags: kw.update(use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0)
   if 'nonhol' in a.flags or (dof == 3 and a.flags == ''): kw.update(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)
   th0, start, goal, sdf = [t.to(dt) for t in make_inputs(B, n, G, dev, dof=dof)]
+  sdfs = [sdf]
   if a.sdf == 'persample':
-    sdf = make_per_sample_sdfs(B, G, dev).to(dt); stride = G * G
+    sdfs = [make_per_sample_sdfs(B, G, dev, seed=1 + i).to(dt) for i in range(a.grids)]; sdf = sdfs[0]; stride = G * G
   else:
     stride = 0
   s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=dt, **kw))
   sa = s.sdf_arg(sdf.data_ptr(), G, G, stride)
+  sas = [s.sdf_arg(t.data_ptr(), G, G, stride) for t in sdfs]
   st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
   P = lambda t: None if t is None else t.data_ptr()
   covs, keep = None, []
@@ -79,10 +81,10 @@ def main():
   assert bool(torch.isfinite(ths[-1]).all())
   tp = [t.data_ptr() for t in ths]
   timer = _capi.KernelTimer(min(a.reps, 1000))
-  out = dict(tag=a.tag, lib=os.path.basename(_capi.LIB_PATH), B=B, n=n, dof=dof, io=a.io, covs=a.covs, sdf=a.sdf, flags=a.flags, shape=list(s.launch_shape(B)))
+  out = dict(grids=a.grids, tag=a.tag, lib=os.path.basename(_capi.LIB_PATH), B=B, n=n, dof=dof, io=a.io, covs=a.covs, sdf=a.sdf, flags=a.flags, shape=list(s.launch_shape(B)))
   for what in a.what.split(','):
     if what == 'step':
-      f = lambda k: s.gn_step(B, tp[k % 4], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
+      f = lambda k: s.gn_step(B, tp[k % 4], P(start), P(goal), sas[k % len(sas)], covs, P(dth), P(err), P(eex), P(info), st)
       by = algorithmic_bytes_per_trajectory(n, d, io_bytes=4 if a.io == 'f32' else 8, cov_tensors=(a.covs == 'perstate')) * B
     elif what == 'solve':
       tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev); eh = torch.empty(B, a.iters, device=dev, dtype=dt)
@@ -95,12 +97,12 @@ def main():
       ge = torch.ones(B, device=dev, dtype=dt)
       gq = torch.empty_like(keep[0]) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
       gp = torch.empty(B, n, device=dev, dtype=dt) if covs else None
-      copies = 8 if what == 'bwd_sdf8' else 1
+      copies = int(what[7:]) if what.startswith('bwd_sdf') and what[7:] else 1
       gs = None
       if what != 'bwd':
         gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=dt)
-      s.gn_step(B, tp[3], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
-      f = lambda k: s.gn_step_backward(B, tp[3], P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
+      s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
+      f = lambda k: s.gn_step_backward(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
                                        P(gq), P(gw), P(gp), st, g_sdf_copies=copies)
     else:
       raise SystemExit('unknown --what ' + what)

@@ -371,6 +371,10 @@ def case_shared_sdf_gradient_partial_copies(be, golden, io):
   r3 = be.backward(p, th, st, go, sdf, dth, gbar, None, io=io, sdf_copies=3)
   assert r3['sdf'].shape[0] == 3
   assert rel_err(r3['sdf'].sum(0, keepdims=True), r1['sdf']) < (1e-11 if io == 'f64' else 2e-5)
+  # more copies than XCDs (what PlanLayer uses: 16): every XCD spreads its wavefronts over copies xcc, xcc + 8
+  r16 = be.backward(p, th, st, go, sdf, dth, gbar, None, io=io, sdf_copies=16)
+  assert rel_err(r16['sdf'].sum(0, keepdims=True), r1['sdf']) < (1e-11 if io == 'f64' else 2e-5)
+  if be.kind == 'hip' and reps > 8: assert (np.abs(r16['sdf']).reshape(16, -1).max(1) > 0).sum() >= 9
 
 
 def case_tiny_and_odd_sizes(be, golden, io):
