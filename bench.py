@@ -254,8 +254,9 @@ def extra_workloads(device, stream, reps=1500):
     d = 2 * dof
     th0, start, goal, sdf_shared = make_inputs(B, n, G, device, seed=0, dof=dof)
     s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=torch.float32, **cfg_kw))
-    grid = sdf_shared if sdf is None else sdf
-    sa = s.sdf_arg(grid.data_ptr(), G, G, sdf_stride)
+    grids = [sdf_shared] if sdf is None else sdf
+    sas = [s.sdf_arg(g_.data_ptr(), G, G, sdf_stride) for g_ in grids]
+    sa = sas[0]
     dth = torch.empty_like(th0); err = torch.empty(B, device=device); eex = torch.empty(B, device=device)
     info = torch.zeros(B, dtype=torch.int32, device=device)
     cv, keep = None, []
@@ -272,7 +273,7 @@ def extra_workloads(device, stream, reps=1500):
     assert int(info.abs().max()) == 0 and bool(torch.isfinite(ths[-1]).all()), tag
     ptrs = [t.data_ptr() for t in ths]
     sp, gp, dp, ep_, xp, ip = start.data_ptr(), goal.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr()
-    us = time_launches(lambda k: s.gn_step(B, ptrs[k % 4], sp, gp, sa, cv, dp, ep_, xp, ip, stream), reps)
+    us = time_launches(lambda k: s.gn_step(B, ptrs[k % 4], sp, gp, sas[k % len(sas)], cv, dp, ep_, xp, ip, stream), reps)
     by = algorithmic_bytes_per_trajectory(n, d, cov_tensors=covs) * B
     lpt, c = s.launch_shape(B)
     kname = 'gn_kernel<%d,%d,%d,float,0,%s>' % (dof, lpt, c, 'false' if covs else 'true')
@@ -286,9 +287,10 @@ def extra_workloads(device, stream, reps=1500):
       note='BASELINE configs[3]: non-holonomic (x,y,theta) robot, 6-dim state, batch=4096, 64 states, 512x512 shared SDF')
   run('learned_covariances', 2, GRID, {}, covs=True, traffic_key='learned_covariances',
       note='configs[1] with per-state qc_inv (B,n-1,2,2), obs_w, eps tensors streamed (the learned mode; generic kernels)')
-  ps = make_per_sample_sdfs(B, GRID, device)
+  ps = [make_per_sample_sdfs(B, GRID, device, seed=1 + i) for i in range(6)]
   run('per_sample_sdf', 2, GRID, {}, sdf=ps, sdf_stride=GRID * GRID, traffic_key='per_sample_sdf',
-      note='configs[1] with one 256x256 SDF PER trajectory (the reference API shape sdfb (B,1,H,W); 1 GiB of grids, 4 taps per state read)')
+      note='configs[1] with one 256x256 SDF PER trajectory (the reference API shape sdfb (B,1,H,W)): 1 GiB of grids per batch, six '
+           'different batches of grids cycled so that the tap lines come from HBM, not from the 256 MiB Infinity Cache')
   del ps
   return out
 
