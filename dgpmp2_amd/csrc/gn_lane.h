@@ -1425,68 +1425,66 @@ DGP_HD void pcr_last_round(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (
   }
 }
 
-// one PCR round at stride S
+// one PCR round at stride S.  Owner-computes form: what row i contributes to its RIGHT neighbour's update,
+//     W_i = U_i^T D_i^-1 U_i (symmetric)   and   v_i = U_i^T D_i^-1 r_i,
+// only involves row i's own data, so lane i forms them (through G_i = D_i^-1 U_i and y_i = D_i^-1 r_i, which its LEFT
+// neighbour needs anyway) and ships d(d+1)/2 + d values to the right instead of D^-1, U, r (d(d+1)/2 + d^2 + d) for the
+// receiver to multiply out.  From the right a lane fetches D_R^-1, y_R, G_R:
+//     D_i' = D_i - W_L - (U_i D_R^-1) U_i^T ;   r_i' = r_i - v_L - U_i y_R ;   U_i' = -U_i G_R.
+// Same flop count as eliminating with the fetched rows, 29 % fewer cross-lane moves (d = 4: 44 instead of 60 values per round),
+// and no fetched left row (U_L, D_L^-1) or U_L^T D_L^-1 product alive next to the lane's own state.
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   constexpr bool last = (2 * S >= LPT);
   if constexpr (last && LPT >= 2) { pcr_last_round<D, LPT, S>(cx, i, Dm, U, r, ok); return; }
-  const Nbr<LPT, S, Ctx> nb(cx, i);
+  typedef Nbr<LPT, S, Ctx> NB;
+  const NB nb(cx, i);
+  const bool has_l = (i >= S);
   Sym<D> Di;
   sym_inverse<D>(Dm, Di, ok);
-  const bool has_l = (i >= S);
-  double rn[D];
-  // ---- left neighbour
-  {
-    Sym<D> DiL;
-    Mat<D> UL;
-    double rL[D];
+  Mat<D> G;                       // G = D^-1 U
+  double y[D];                    // y = D^-1 r
 #pragma unroll
-    for (int k = 0; k < D * (D + 1) / 2; ++k) DiL.v[k] = nb.lo(Di.v[k]);
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      rL[a] = nb.lo(r[a]);
+    for (int k = 0; k < D; ++k) t += Di(a, k) * r[k];
+    y[a] = t;
 #pragma unroll
-      for (int c = 0; c < D; ++c) {
-        const double u = nb.lo(U.v[a][c]);
-        UL.v[a][c] = (Nbr<LPT, S, Ctx>::kDpp || has_l) ? u : 0.0;     // a DPP row shift already yields 0 where there is no left neighbour
-      }
-    }
-    // T2 = UL^T DiL
-    double T2[D][D];
+    for (int c = 0; c < D; ++c) {
+      double g = 0.0;
 #pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-      for (int c = 0; c < D; ++c) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) t += UL.v[k][a] * DiL(k, c);
-        T2[a][c] = t;
-      }
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-      double t = r[a];
-#pragma unroll
-      for (int k = 0; k < D; ++k) t -= T2[a][k] * rL[k];
-      rn[a] = t;
-#pragma unroll
-      for (int c = a; c < D; ++c) {
-        double w = Dm(a, c);
-#pragma unroll
-        for (int k = 0; k < D; ++k) w -= T2[a][k] * UL.v[k][c];
-        Dm(a, c) = w;
-      }
+      for (int k = 0; k < D; ++k) g += Di(a, k) * U.v[k][c];
+      G.v[a][c] = g;
     }
   }
-  // ---- right neighbour
+  // ---- left neighbour: its W and v (a DPP row shift already yields 0 where there is no left neighbour)
+  double rn[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) v += U.v[k][a] * y[k];
+    const double vL = nb.lo(v);
+    rn[a] = r[a] - ((NB::kDpp || has_l) ? vL : 0.0);
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) w += U.v[k][a] * G.v[k][c];
+      const double wL = nb.lo(w);
+      Dm(a, c) -= (NB::kDpp || has_l) ? wL : 0.0;
+    }
+  }
+  // ---- right neighbour (U_i == 0 where there is none, so whatever was fetched there is multiplied away)
   {
     Sym<D> DiR;
-    double rR[D];
+    double yR[D];
 #pragma unroll
     for (int k = 0; k < D * (D + 1) / 2; ++k) DiR.v[k] = nb.hi(Di.v[k]);
 #pragma unroll
-    for (int a = 0; a < D; ++a) rR[a] = nb.hi(r[a]);
-    // T = U DiR
-    double T[D][D];
+    for (int a = 0; a < D; ++a) yR[a] = nb.hi(y[a]);
+    double T[D][D];               // T = U D_R^-1
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -1500,7 +1498,7 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], Spd
     for (int a = 0; a < D; ++a) {
       double t = rn[a];
 #pragma unroll
-      for (int k = 0; k < D; ++k) t -= T[a][k] * rR[k];
+      for (int k = 0; k < D; ++k) t -= U.v[a][k] * yR[k];
       rn[a] = t;
 #pragma unroll
       for (int c = a; c < D; ++c) {
@@ -1510,22 +1508,21 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], Spd
         Dm(a, c) = w;
       }
     }
-    if (!last) {
-      Mat<D> UR;
+    Mat<D> GR, Un;
 #pragma unroll
-      for (int a = 0; a < D; ++a)
+    for (int a = 0; a < D; ++a)
 #pragma unroll
-        for (int c = 0; c < D; ++c) UR.v[a][c] = nb.hi(U.v[a][c]);
+      for (int c = 0; c < D; ++c) GR.v[a][c] = nb.hi(G.v[a][c]);
 #pragma unroll
-      for (int a = 0; a < D; ++a)
+    for (int a = 0; a < D; ++a)
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-          double t = 0.0;
+      for (int c = 0; c < D; ++c) {
+        double t = 0.0;
 #pragma unroll
-          for (int k = 0; k < D; ++k) t -= T[a][k] * UR.v[k][c];
-          U.v[a][c] = t;
-        }
-    }
+        for (int k = 0; k < D; ++k) t -= U.v[a][k] * GR.v[k][c];
+        Un.v[a][c] = t;
+      }
+    U = Un;
   }
 #pragma unroll
   for (int a = 0; a < D; ++a) r[a] = rn[a];
