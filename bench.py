@@ -276,7 +276,7 @@ def extra_workloads(device, stream, reps=1500):
     us = time_launches(lambda k: s.gn_step(B, ptrs[k % 4], sp, gp, sas[k % len(sas)], cv, dp, ep_, xp, ip, stream), reps)
     by = algorithmic_bytes_per_trajectory(n, d, cov_tensors=covs) * B
     lpt, c = s.launch_shape(B)
-    kname = 'gn_kernel<%d,%d,%d,float,0,%s>' % (dof, lpt, c, 'false' if covs else 'true')
+    kname = 'gn_kernel<%d,%d,%d,float,0,%d>' % (dof, lpt, c, 2 if covs else 1)      # <dof, LPT, C, io, MODE_STEP, QK: 1 static, 2 per-state Kronecker>
     out[tag] = {'workload': note, 'kernel_avg_us': us, 'gn_steps_per_s': 1e6 / us,
                 'roofline': roofline_block(by, us, kname, traffic_key=traffic_key)}
     del keep
@@ -419,7 +419,7 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_trajectory(n, d) * B
     lpt, cc = solver.launch_shape(B)
     waves = (B + (64 // lpt) - 1) // (64 // lpt)
-    kname = 'gn_kernel<%d,%d,%d,float,0,true>' % (DOF, lpt, cc)
+    kname = 'gn_kernel<%d,%d,%d,float,0,1>' % (DOF, lpt, cc)      # <dof, LPT, C, io, MODE_STEP, QK_STATIC>
     ks = kernel_stats().get(kname)
     out = {
         'metric': 'Gauss-Newton steps/sec (whole node), batch=4096 x 64 states, 2D point robot',

@@ -104,7 +104,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   if (gp.g_dtheta) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     SpdCheck<Ctx> ok = {&cx, 0};
-    gn_linear_solve<DOF, LPT, C, IO, true, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
+    gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
   }
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
 

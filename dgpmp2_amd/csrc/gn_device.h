@@ -13,7 +13,9 @@ namespace dgp_dev {
 // crossbar is used, no LDS memory is touched).
 struct DevCtx {
   char* lds_;      // the workgroup's (= wavefront's) LDS staging block, dgp::WaveStore<...>::kLdsBytes
+  char* stash_;    // dgp::SinvStash block (d = 6 kernels), or null
   __device__ __forceinline__ char* lds() const { return lds_; }
+  __device__ __forceinline__ char* stash() const { return stash_; }
   __device__ __forceinline__ void lds_sync() const { __syncthreads(); }      // one wavefront per workgroup
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
@@ -98,9 +100,16 @@ __device__ __forceinline__ void warm_kernarg() {
 template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   warm_kernarg<(int)sizeof(dgp::GnParams)>();
-  __shared__ __attribute__((aligned(16))) char lds[dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes];
+  // STEP: staging block of the full-line th / dtheta accesses; SOLVE: the fp64 trajectory rows parked between iterations
+  // (+ an S_k^-1 stash where SinvStashBlocks asks for one -- currently only the backward kernel does: in STEP mode it would ALIAS
+  // the staging block, th being loaded before the sweep and dtheta stored after the recovery; in SOLVE mode follow the trajectory)
+  constexpr int kRows = (MODE == dgp::MODE_SOLVE) ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
+  constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;
+  constexpr int kLds = (MODE == dgp::MODE_SOLVE) ? kRows + kStash : (kRows > kStash ? kRows : kStash);
+  __shared__ __attribute__((aligned(16))) char lds[kLds];
   DevCtx cx;
   cx.lds_ = lds;
+  cx.stash_ = (MODE == dgp::MODE_SOLVE) ? lds + kRows : lds;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
@@ -109,9 +118,12 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
   constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
-  __shared__ __attribute__((aligned(16))) char lds[kPairBytes > kRowBytes ? kPairBytes : kRowBytes];
+  constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
+  constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
+  __shared__ __attribute__((aligned(16))) char lds[kMax > kStash ? kMax : kStash];
   DevCtx cx;
   cx.lds_ = lds;
+  cx.stash_ = lds;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
 }
 

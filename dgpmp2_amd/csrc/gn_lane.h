@@ -1832,6 +1832,51 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LDS stash of the interior rows' S_k^-1 (d = 6 backward kernel).  Between the forward sweep and the interior recovery the PCR
+// rounds need every register; for d = 6 the 3 x 21 doubles of S_k^-1 do not fit next to them.  They can be parked in LDS: lane-private
+// slots of 11 x 16 bytes per block, lane stride a multiple of 16 bytes whose dword count / 4 is odd -> conflict-free 128-bit accesses.
+// NS = number of blocks the kernel's LDS budget allows (0: no stash; the rest stays in registers).
+// ---------------------------------------------------------------------------------------------------
+// how many S_k^-1 blocks a kernel parks in LDS.  Measured on d = 6, (16,4), B = 4096: the backward kernel (whose chain rule
+// follows the adjoint solve and needs every register again) 91.3 -> 71.2 us with all three blocks stashed; the step kernel is
+// indifferent (30.2 -> 30.1 us) and the fused loop LOSES (34.2 -> 38.7 us per iteration with two blocks) -- so only the backward does.
+enum { MODE_BACKWARD_SOLVE = 3 };
+template <int D, int C, int MODE> struct SinvStashBlocks {
+  static constexpr int kInterior = (C > 1) ? C - 1 : 0;
+  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : 0;
+  static constexpr int value = kWant < kInterior ? kWant : kInterior;
+};
+template <int D, int NS> struct SinvStash {
+  static constexpr int kBlock = ((D * (D + 1) / 2 * 8 + 15) / 16) * 16;                 // bytes per block, padded to 16
+  static constexpr int kQuads = (NS * kBlock) / 16;
+  static constexpr int kStride = NS == 0 ? 0 : ((kQuads % 2) ? kQuads : kQuads + 1) * 16;   // lane stride in bytes
+  static constexpr int kBytes = 64 * kStride;
+};
+template <int D, int NS, typename Ctx>
+DGP_HD void stash_put(Ctx& cx, int slot, const Sym<D>& S) {
+  typedef double V2 __attribute__((vector_size(16)));
+  char* l = cx.stash() + cx.lane() * SinvStash<D, NS>::kStride + slot * SinvStash<D, NS>::kBlock;
+  constexpr int N = D * (D + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < (N + 1) / 2; ++i) {
+    V2 t; t[0] = S.v[2 * i]; t[1] = (2 * i + 1 < N) ? S.v[2 * i + 1 < N ? 2 * i + 1 : 0] : 0.0;
+    *(V2*)(l + i * 16) = t;
+  }
+}
+template <int D, int NS, typename Ctx>
+DGP_HD void stash_get(Ctx& cx, int slot, Sym<D>& S) {
+  typedef double V2 __attribute__((vector_size(16)));
+  const char* l = cx.stash() + cx.lane() * SinvStash<D, NS>::kStride + slot * SinvStash<D, NS>::kBlock;
+  constexpr int N = D * (D + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < (N + 1) / 2; ++i) {
+    const V2 t = *(const V2*)(l + i * 16);
+    S.v[2 * i] = t[0];
+    if (2 * i + 1 < N) S.v[2 * i + 1 < N ? 2 * i + 1 : 0] = t[1];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // One Gauss-Newton linear solve for the C rows owned by this lane (rows j*C .. j*C+C-1 of trajectory b).
 //
 //  a. forward block elimination of the lane's C-1 INTERIOR rows (all but its last), carrying the right-hand side
@@ -1856,7 +1901,7 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k
 // ---------------------------------------------------------------------------------------------------
 // `before_pcr(acc)` is called once every factor of the lane has been evaluated (the error partials are complete) and before
 // the PCR rounds: MODE_STEP reduces and stores err / err_ext there, off the tail of the kernel.
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, typename Ctx, typename Hook>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
@@ -2002,6 +2047,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       else { coup_A_U<D, C>(p, cp, k, Mk, -1.0, T); Pi = T; }            // Pi_{k+1} = -Pi_k G_k
     }
     if (k == KL) sym_times_vec<D>(Sinv[k], z[k], Pl);      // P_{C-2} = S^-1 z_{C-2}   (x_{C-2} = P - (..) x_ps - G x_s)
+    if constexpr (NS > 0) { if (k < NS) stash_put<D, NS>(cx, k, Sinv[k]); }      // parked in LDS until the recovery (d.)
   }
   // ---- c. separator row -> reduced system row
   Sym<D> Ds; Mat<D> Us; double rs[D];
@@ -2136,7 +2182,12 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
     for (int k = 1; k < C - 1; ++k) {
       double t[D];
-      sym_times_vec<D>(Sinv[k - 1], w, t);
+      if constexpr (NS > 0) {
+        if (k - 1 < NS) { Sym<D> Sk; stash_get<D, NS>(cx, k - 1, Sk); sym_times_vec<D>(Sk, w, t); }
+        else sym_times_vec<D>(Sinv[k - 1], w, t);
+      } else {
+        sym_times_vec<D>(Sinv[k - 1], w, t);
+      }
 #pragma unroll
       for (int a = 0; a < D; ++a) w[a] = 0.0;
       coup_sub_Ut_v<D, C>(p, cp, k - 1, w, t);                         // w_k = -U_{k-1}^T (S_{k-1}^-1 w_{k-1})
@@ -2149,18 +2200,23 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
     for (int k = C - 2; k >= 0; --k) {
       coup_sub_U_v<D, C>(p, cp, k, q[k], xn);                          // q_k - U_k x_{k+1}
-      sym_times_vec<D>(Sinv[k], q[k], xn);
+      if constexpr (NS > 0) {
+        if (k < NS) { Sym<D> Sk; stash_get<D, NS>(cx, k, Sk); sym_times_vec<D>(Sk, q[k], xn); }
+        else sym_times_vec<D>(Sinv[k], q[k], xn);
+      } else {
+        sym_times_vec<D>(Sinv[k], q[k], xn);
+      }
 #pragma unroll
       for (int a = 0; a < D; ++a) dx[k][a] = xn[a];
     }
   }
 }
 
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, typename Ctx>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok) {
-  gn_linear_solve<DOF, LPT, C, IO, RHS_OVERRIDE, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, rhs, dx, acc, ok, [](const ErrAcc&) {});
+  gn_linear_solve<DOF, LPT, C, IO, RHS_OVERRIDE, QK, NS>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, rhs, dx, acc, ok, [](const ErrAcc&) {});
 }
 
 // errors only (no assembly): sums over the lane's C rows
@@ -2263,6 +2319,30 @@ DGP_HD void load_rows_through_lds(Ctx& cx, const void* in, int64_t wave_first_el
   cx.lds_sync();      // the staging block is reused by the output stores
 }
 
+// MODE_SOLVE keeps the trajectory (the lane's C fp64 state rows) in the wavefront's LDS block between the uses at the two ends
+// of an iteration -- factor evaluation at the start, th += dtheta at the end -- instead of in 2 C d vector registers across the
+// whole elimination + PCR, where every register is contended (lane-private slots, padded lane stride: conflict-free 128-bit accesses).
+template <int C, int D, typename Ctx>
+DGP_HD void lds_put_rows(Ctx& cx, const double (&v)[C][D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  char* l = cx.lds() + cx.lane() * WaveStore<double, C, D>::kStride;
+#pragma unroll
+  for (int i = 0; i < C * D / 2; ++i) {
+    V2 t; t[0] = v[(2 * i) / D][(2 * i) % D]; t[1] = v[(2 * i + 1) / D][(2 * i + 1) % D];
+    *(V2*)(l + i * 16) = t;
+  }
+}
+template <int C, int D, typename Ctx>
+DGP_HD void lds_get_rows(Ctx& cx, double (&v)[C][D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  const char* l = cx.lds() + cx.lane() * WaveStore<double, C, D>::kStride;
+#pragma unroll
+  for (int i = 0; i < C * D / 2; ++i) {
+    const V2 t = *(const V2*)(l + i * 16);
+    v[(2 * i) / D][(2 * i) % D] = t[0]; v[(2 * i + 1) / D][(2 * i + 1) % D] = t[1];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
@@ -2321,16 +2401,25 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   bool active = traj_ok;
   int my_iters = 0;
   SpdCheck<Ctx> ok = {&cx, 0};            // accumulates over the GN iterations of MODE_SOLVE
+  if constexpr (MODE == MODE_SOLVE) lds_put_rows<C, D>(cx, x);
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
-    double e = 0.0, ee = 0.0;
-    gn_linear_solve<DOF, LPT, C, IO, false, QK>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
-      e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
+    if constexpr (MODE == MODE_SOLVE) {   // the state comes from LDS, the means from memory (L2 hits): nothing of them stays in registers
+      lds_get_rows<C, D>(cx, x);
+      ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
+      ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
+    }
+    gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
+      const double e = group_sum_to_first<LPT>(cx, a.e), ee = group_sum_to_first<LPT>(cx, a.eext);
       if (MODE == MODE_STEP && traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, div_M(p, e));
         if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
+      }
+      if (MODE == MODE_SOLVE && active && j == 0) {        // err / err_ext at the iteration's input trajectory (planner.step's err_old)
+        if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));
+        if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, div_M(p, ee));
       }
     });
     DGP_STAMP_NOWAIT(p, cx, 4);
@@ -2357,14 +2446,13 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         for (int a = 0; a < D; ++a) s2 += (traj_ok && j * C + k < n) ? dx[k][a] * dx[k][a] : 0.0;
       s2 = group_sum<LPT>(cx, s2);
       if (active) {
-        if (j == 0) {
-          if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));
-          if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, div_M(p, ee));
-        }
+        double xc[C][D];
+        lds_get_rows<C, D>(cx, xc);
 #pragma unroll
         for (int k = 0; k < C; ++k)
 #pragma unroll
-          for (int a = 0; a < D; ++a) x[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;      // th_new = th_curr + dtheta (:144)
+          for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;     // th_new = th_curr + dtheta (:144)
+        lds_put_rows<C, D>(cx, xc);
         my_iters = it + 1;
         if (sqrt(s2) < p.tol_delta) active = false;                                    // planner_utils.py:4
       }
@@ -2379,6 +2467,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   }
   DGP_STAMP(p, cx, 6);
   if (MODE == MODE_SOLVE) {
+    lds_get_rows<C, D>(cx, x);
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int g = j * C + k;

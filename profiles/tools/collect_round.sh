@@ -1,15 +1,34 @@
 #!/bin/bash
 # One gpurun call that produces every artefact profiles/ keeps for a round (run from the repo root on the GPU box):
-#   bench JSON, rocprofv3 kernel-trace/stats of the bench command, PMC passes, launch-shape sweep.
+#   GPU test log, bench JSON (the driver's invocation and the default one), rocprofv3 kernel-trace/stats of the driver's bench
+#   command, PMC passes per workload, launch-shape sweep, entry-point microbenchmarks.  Large rocpd databases are reduced to text
+#   on the box and deleted (gpurun copies back at most 64 MiB).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/round
-mkdir -p "$O"
+rm -rf "$O" "$R/gpurun_out/pmc"; mkdir -p "$O"
 cd "$R"
-timeout 600 python bench.py 2>/dev/null | grep -a '^{' > "$O/bench.json"
+(timeout 1500 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
+timeout 600 python bench.py --steps 20 --warmup 5 2>/dev/null | grep -a '^{' > "$O/bench_driver_invocation.json"
+timeout 600 python bench.py 2>/dev/null | grep -a '^{' > "$O/bench_default.json"
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d "$O" -o trace -- python "$R/bench.py" --steps 4000 --warmup 1000 --no-cpu-baseline > "$O/trace.log" 2>&1
+# the driver's command with --no-extras: the extra workload blocks launch the SAME kernel symbol on other inputs (per-sample grids,
+# velocity limits), so only this trace gives the headline workload's own average; the full command's trace is kept next to it
+timeout 900 rocprofv3 --kernel-trace --stats -d "$O/trace" -o trace -- python "$R/bench.py" --steps 20 --warmup 5 --no-extras > "$O/trace.log" 2>&1
+for db in $(find "$O/trace" -name '*_results.db'); do python "$R/profiles/tools/summarize_rocpd.py" "$db" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-extras" > "$O/kernel_trace.txt" 2>&1; done
+rm -rf "$O/trace"
+timeout 900 rocprofv3 --kernel-trace --stats -d "$O/trace" -o trace -- python "$R/bench.py" --steps 20 --warmup 5 > "$O/trace_full.log" 2>&1
+for db in $(find "$O/trace" -name '*_results.db'); do python "$R/profiles/tools/summarize_rocpd.py" "$db" "rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5" > "$O/kernel_trace_full.txt" 2>&1; done
+rm -rf "$O/trace"
 cd "$R"
 bash profiles/tools/pmc_traffic.sh > "$O/pmc.log" 2>&1
-timeout 600 python profiles/tools/shape_sweep.py 2>/dev/null > "$O/shape_sweep.jsonl"
-ls -la "$O" "$R/gpurun_out/pmc"
+cp gpurun_out/pmc/report.txt "$O/pmc_counters.txt"; cp gpurun_out/pmc/traffic.json "$O/traffic.json"
+timeout 900 python profiles/tools/shape_sweep.py 2>/dev/null > "$O/shape_sweep.jsonl"
+timeout 600 python profiles/tools/microbench.py 2>/dev/null | grep -a '^{' > "$O/microbench.jsonl"
+U="python profiles/tools/ubench.py"
+( $U --what step,solve,eval,bwd,bwd_sdf8,bwd_sdf16; $U --what step,solve,bwd,bwd_sdf16 --covs perstate; $U --what step,solve,bwd --covs qfull; $U --what step,solve,bwd --dof 3;
+  $U --what step --flags vel; $U --what step,bwd,bwd_sdf --sdf persample --grids 6; $U --what step --sdf persample --grids 1; $U --what bwd,bwd_sdf8,bwd_sdf16 --th 0 --tag straight_line_init;
+  $U --what step,bwd --io f64 ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
+./dgpmp2_amd/lib/atomic_probe > "$O/atomic_probe.txt" 2>&1
+./dgpmp2_amd/lib/mfma_probe > "$O/mfma_probe.txt" 2>&1
+ls -la "$O"; du -sh "$R/gpurun_out"

@@ -20,7 +20,7 @@ struct WaveShared {
   pthread_barrier_t bar;
   double slot[64];
   int islot[64];
-  alignas(16) char lds[64 * (4 * 6 * 8 + 16)];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64)
+  alignas(16) char lds[64 * (4 * 6 * 8 + 16) + 64 * 544];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64) + dgp::SinvStash
 };
 
 pthread_mutex_t g_atomic_mutex = PTHREAD_MUTEX_INITIALIZER;
@@ -31,6 +31,7 @@ struct HostCtx {
   int lane() const { return lane_; }
   int wave() const { return wave_; }
   char* lds() { return ws->lds; }
+  char* stash() { return ws->lds + 64 * (4 * 6 * 8 + 16); }
   void lds_sync() { pthread_barrier_wait(&ws->bar); }
   double fetch(double v, int src) {
     ws->slot[lane_] = v;
