@@ -310,12 +310,15 @@ def planner_api_rate(device, reps=300):
                              batch_size=B, use_cuda=True)
   th0, start, goal, sdf = make_inputs(B, n, GRID, device)
   sdfb = sdf.expand(B, 1, GRID, GRID)
+  best = float('inf')
   with torch.no_grad():
-    for _ in range(50): planner.step(th0, start, goal, None, sdfb)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps): planner.step(th0, start, goal, None, sdfb)
-    torch.cuda.synchronize()
-  us = (time.perf_counter() - t0) / reps * 1e6
+    for _ in range(200): planner.step(th0, start, goal, None, sdfb)
+    for _ in range(3):                               # best of three batches: a single batch picks up host jitter (GC, CPU clock ramp)
+      torch.cuda.synchronize(); t0 = time.perf_counter()
+      for _ in range(reps): planner.step(th0, start, goal, None, sdfb)
+      torch.cuda.synchronize()
+      best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+  us = best
   return {'us_per_call': us, 'gn_steps_per_s': 1e6 / us, 'note': 'DiffGPMP2Planner.step() under torch.no_grad(), B=4096, wall time per call '
           '(host-side Python + ctypes + one kernel launch); the headline `value` is the C-ABI launch rate'}
 

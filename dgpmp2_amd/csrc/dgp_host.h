@@ -56,13 +56,12 @@ inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || 
 // T = per-wavefront time in us when every wavefront has a SIMD to itself (B = 256 column of the grid); a launch with more
 // wavefronts than the chip has SIMDs (1024) runs them in turns and each then costs ~1.25 T (shared LDS crossbar / L2).
 // More states per lane (larger C) means less arithmetic per trajectory (the local elimination is O(C) per lane while
-// every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6 has its own table (T6), from the
-// B = 4096, n = 64 sweep of the d = 6 kernels (profiles/r02_shape_sweep.txt): (64,1) 110 us over 4 turns, (32,2) 45.8 us over
-// 2, (16,4) 29.0 us in one; the unmeasured entries scale the d = 4 table by the measured ratio of their C column.
+// every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6 has its own table (T6), every entry from the
+// round-2 sweep of the d = 6 kernels (profiles/r02_shape_sweep.txt: kernel time / turns at B = 4096, n = 16, 32, 64).
 inline DgpShape choose_shape(const DgpHandle* h, int B) {
   if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
   static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
-  static const double T6[3][3] = {{5.7, 10.2, 29.0}, {11.0, 18.3, 39.0}, {21.7, 31.5, 62.7}};  // d = 6
+  static const double T6[3][3] = {{11.0, 14.2, 24.4}, {13.4, 17.1, 26.6}, {19.9, 26.1, 33.9}};  // d = 6
   const int n = h->cfg.num_states;
   DgpShape best{64, 4};
   double best_cost = 1e300;
