@@ -62,6 +62,20 @@ def _require_cuda(t, name):
     raise RuntimeError('dgpmp2_amd: `%s` must be a CUDA/ROCm tensor (got device %s); this build has no CPU path' % (name, t.device))
 
 
+class _NoGuard(object):
+  def __enter__(self): return self
+  def __exit__(self, *a): return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _on_device(dev):
+  """Context in which the CURRENT device is `dev` (a launch goes to the current device's stream).  The usual case -- the tensors
+  already live on the current device -- costs one integer compare instead of torch.cuda.device()'s get / set / restore."""
+  return _NO_GUARD if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+
 def _same_device(ref, **named):
   """Every tensor argument must live on the device of `thb`: the kernel receives raw addresses."""
   for name, t in named.items():
@@ -73,7 +87,8 @@ class _GNStep(torch.autograd.Function):
   """dtheta, err, err_ext = GN step; backward through dgp_gn_step_backward (adjoint block-tridiagonal solve)."""
 
   @staticmethod
-  def forward(ctx, layer, static, th, start, goal, sdf, qc, ow, eps):
+  def launch(layer, static, th, start, goal, sdf, qc, ow, eps):
+    """The forward launch itself (no autograd bookkeeping): -> dth, err, eex, and what the backward needs to keep alive."""
     B = th.shape[0]
     solver = layer._solver(th.dtype)
     _same_device(th, startb=start, goalb=goal, sdfb=sdf, qc_inv_trajb=qc, obscov_inv_trajb=ow, eps_trajb=eps)
@@ -84,17 +99,22 @@ class _GNStep(torch.autograd.Function):
     err = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
     eex = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
     info = torch.empty(B, dtype=torch.int32, device=th.device)
-    with torch.cuda.device(th.device):      # the launch goes to the CURRENT device's stream: make that the tensors' device
+    with _on_device(th.device):             # the launch goes to the CURRENT device's stream: make that the tensors' device
       solver.gn_step(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, dth.data_ptr(), err.data_ptr(), eex.data_ptr(),
                      info.data_ptr(), _stream())
-    layer.last_info = info
+    object.__setattr__(layer, 'last_info', info)      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
+    return dth, err, eex, (thc, stc, goc), (sdf_keep, cov_keep)
+
+  @staticmethod
+  def forward(ctx, layer, static, th, start, goal, sdf, qc, ow, eps):
+    dth, err, eex, (thc, stc, goc), keep = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
     ctx.layer = layer
     ctx.static = static
     ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)
-    ctx.keep = (sdf_keep, cov_keep)
+    ctx.keep = keep
     ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
     ctx.set_materialize_grads(False)              # an unused output arrives as None: no adjoint solve for an err_ext-only loss
     return dth, err, eex
@@ -123,7 +143,7 @@ class _GNStep(torch.autograd.Function):
     g_ow = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[6] and covs.obs_w) else None
     g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[7] and covs.eps) else None
     p = lambda t: None if t is None else t.data_ptr()
-    with torch.cuda.device(th.device):
+    with _on_device(th.device):
       solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
                               p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream(),
                               g_sdf_copies=copies)
@@ -258,8 +278,12 @@ class PlanLayer(nn.Module):
     # like the reference (plan_layer.py:88-94) remember means / covariances for the error_* helpers below
     static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
     det = lambda t, st: None if (t is None or st) else t.detach()
-    self._last = (startb.detach(), goalb.detach(), det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
-                  det(eps_trajb, static[2]))
+    object.__setattr__(self, '_last', (startb.detach(), goalb.detach(), det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
+                                       det(eps_trajb, static[2])))
+    needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad
+                                                  for t in (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb))
+    if not needs_graph:        # planning / validation loops: no autograd node, one launch
+      return _GNStep.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:3]
     return _GNStep.apply(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
 
   def _eval(self, thb, sdfb, startb, goalb, qc, ow, eps):
@@ -272,7 +296,7 @@ class PlanLayer(nn.Module):
     want = [sdfb is not None, sdfb is not None, True, True, sdfb is not None]
     outs = [torch.empty(B, 1, 1, dtype=thb.dtype, device=thb.device) if w else None for w in want]
     thc, stc, goc = thb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
-    with torch.cuda.device(thb.device):
+    with _on_device(thb.device):
       solver.eval_errors(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, *[None if o is None else o.data_ptr() for o in outs],
                          stream=_stream())
     return outs
