@@ -80,19 +80,17 @@ struct WavesPerSimd { static constexpr int value = DGP_FORCE_WPS ? DGP_FORCE_WPS
 // other and the first global loads, and the later loads hit the scalar cache.  Results are discarded.
 // (The loads target one fixed, clobbered SGPR and are waited for inside the same asm statement: scalar loads may return
 // out of order, so a discarded load must never be outstanding while the compiler reuses its destination register.)
-template <int OFF, int END>
+template <int LINES>
 __device__ __forceinline__ void warm_kernarg_lines(const void* ka) {
-  if constexpr (OFF < END) {
-    asm volatile("s_load_dword s90, %0, %1" :: "s"(ka), "n"(OFF) : "s90");
-    warm_kernarg_lines<OFF + 64, END>(ka);
-  } else {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "s90", "memory");
-  }
+  // ONE asm statement: the loads and their wait cannot be separated by anything the compiler schedules (a scalar load still
+  // in flight would clobber whatever the compiler put into s90 in between)
+  asm volatile(".set dgp_ka_off, 0\n\t.rept %1\n\ts_load_dword s90, %0, dgp_ka_off\n\t.set dgp_ka_off, dgp_ka_off + 64\n\t.endr\n\t"
+               "s_waitcnt lgkmcnt(0)" :: "s"(ka), "n"(LINES) : "s90", "memory");
 }
 template <int BYTES>
 __device__ __forceinline__ void warm_kernarg() {
 #if defined(__HIP_DEVICE_COMPILE__)
-  warm_kernarg_lines<0, BYTES>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+  warm_kernarg_lines<(BYTES + 63) / 64>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
 #endif
 }
 

@@ -2401,25 +2401,24 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   bool active = traj_ok;
   int my_iters = 0;
   SpdCheck<Ctx> ok = {&cx, 0};            // accumulates over the GN iterations of MODE_SOLVE
-  if constexpr (MODE == MODE_SOLVE) lds_put_rows<C, D>(cx, x);
+  // MODE_SOLVE, d = 4: the trajectory is parked in LDS between the two ends of an iteration (lds_put_rows).  NOT for d = 6: with the
+  // state parked, hipcc 7.0 produced d = 6 fused-loop kernels -- <3,64,2,double,SOLVE,per-state>, <3,64,4,double,SOLVE,general>; the
+  // ones that spill hundreds of SGPR lane masks into VGPR lanes -- that return garbage, non-deterministically, although the LDS
+  // contents are intact (checked in-kernel against a register copy).  Found by tests/stress_random_configs.py, which now drives
+  // the fused loop; the d = 6 fused kernels therefore keep their state in registers, as in round 1.
+  constexpr bool kPark = (MODE == MODE_SOLVE) && (D == 4);
+  if constexpr (kPark) lds_put_rows<C, D>(cx, x);
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
-    if constexpr (MODE == MODE_SOLVE) {   // the state comes from LDS, the means from memory (L2 hits): nothing of them stays in registers
-      lds_get_rows<C, D>(cx, x);
-      ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
-      ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
-    }
+    if constexpr (kPark) lds_get_rows<C, D>(cx, x);       // the state comes back from LDS
+    double e = 0.0, ee = 0.0;
     gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
-      const double e = group_sum_to_first<LPT>(cx, a.e), ee = group_sum_to_first<LPT>(cx, a.eext);
+      e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
       if (MODE == MODE_STEP && traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, div_M(p, e));
         if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
-      }
-      if (MODE == MODE_SOLVE && active && j == 0) {        // err / err_ext at the iteration's input trajectory (planner.step's err_old)
-        if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));
-        if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, div_M(p, ee));
       }
     });
     DGP_STAMP_NOWAIT(p, cx, 4);
@@ -2446,13 +2445,26 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         for (int a = 0; a < D; ++a) s2 += (traj_ok && j * C + k < n) ? dx[k][a] * dx[k][a] : 0.0;
       s2 = group_sum<LPT>(cx, s2);
       if (active) {
-        double xc[C][D];
-        lds_get_rows<C, D>(cx, xc);
+        // (the history stores stay HERE, behind the solve: issued from the before_pcr hook, hipcc 7.0 built a
+        //  <3,16,1,double,SOLVE,general> kernel that stores through a wild address -- tests/stress_random_configs.py)
+        if (j == 0) {
+          if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));
+          if (p.errext_hist) st<IO>(p.errext_hist, b * (int64_t)p.max_iters + it, div_M(p, ee));
+        }
+        if constexpr (kPark) {
+          double xc[C][D];
+          lds_get_rows<C, D>(cx, xc);
 #pragma unroll
-        for (int k = 0; k < C; ++k)
+          for (int k = 0; k < C; ++k)
 #pragma unroll
-          for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;     // th_new = th_curr + dtheta (:144)
-        lds_put_rows<C, D>(cx, xc);
+            for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;   // th_new = th_curr + dtheta (:144)
+          lds_put_rows<C, D>(cx, xc);
+        } else {
+#pragma unroll
+          for (int k = 0; k < C; ++k)
+#pragma unroll
+            for (int a = 0; a < D; ++a) x[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;
+        }
         my_iters = it + 1;
         if (sqrt(s2) < p.tol_delta) active = false;                                    // planner_utils.py:4
       }
@@ -2467,7 +2479,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   }
   DGP_STAMP(p, cx, 6);
   if (MODE == MODE_SOLVE) {
-    lds_get_rows<C, D>(cx, x);
+    if constexpr (kPark) lds_get_rows<C, D>(cx, x);
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int g = j * C + k;

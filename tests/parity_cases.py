@@ -423,3 +423,38 @@ def case_static_qc_variants(be, golden, io):
 ALL_CASES.append(case_static_qc_variants)
 ALL_CASES.append(case_tiny_and_odd_sizes)
 ALL_CASES.append(case_shared_sdf_gradient_partial_copies)
+
+
+def case_solve_with_covariances(be, golden, io):
+  """The fused GN loop (dgp_gn_solve) with per-state covariance tensors -- the Kronecker kernels (qc_inv (B,n-1,dof,dof)) and the
+  general ones (q_full, (B,n-1,d,d)) -- and per-state obstacle weights / epsilons: equals the same number of chained dgp_gn_step
+  calls (themselves checked against the oracle and the reference's fixtures), iteration by iteration; d = 4 and d = 6."""
+  if io != 'f64': return
+  rs = np.random.RandomState(17)
+  for dof, n, B, G in ((2, 16, 5, 64), (2, 64, 3, 96), (3, 12, 3, 48)):
+    d = 2 * dof
+    kw = dict(non_holonomic=True, K_d=0.05, epsilon_dist=0.2) if dof == 3 else {}
+    p = O.OracleParams(dof=dof, total_time_step=n - 1, **kw)
+    start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+    start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+    th0 = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + rs.randn(B, n, d) * 0.05
+    sdf = O.circles_sdf(G, O.C2_CIRCLES)[None, None]
+    a = rs.randn(B, n - 1, dof, dof) * 0.3
+    qc = a @ np.swapaxes(a, -1, -2) + 0.5 * np.eye(dof)
+    ow = rs.uniform(0.25, 1.75, (B, n)) * 1e4; eps = rs.uniform(0.2, 0.5, (B, n))
+    for q_full in (False, True):
+      q = O.calc_Q_inv_batch(qc, p.dt) if q_full else qc
+      iters = 4
+      tho, its, eh, eeh, ef, info = be.solve(p, th0, start, goal, sdf, iters, 0.0, qc=q, ow=ow, eps=eps, q_full=q_full, io='f64')
+      assert np.all(its == iters) and np.all(info == 0)
+      cur = th0.copy()
+      for k in range(iters):
+        dth, err, eex, _ = be.step(p, cur, start, goal, sdf, qc=q, ow=ow, eps=eps, q_full=q_full, io='f64')
+        assert rel_err(err, eh[:, k]) < 1e-9 and rel_err(eex, eeh[:, k]) < 1e-9, (dof, n, q_full, k)
+        cur = cur + dth
+      assert rel_err(cur, tho) < 1e-9, (dof, n, q_full, rel_err(cur, tho))
+      e_fin = be.eval_errors(p, tho, start, goal, sdf, qc=q, ow=ow, eps=eps, q_full=q_full, io='f64')[0]
+      assert rel_err(ef, e_fin) < 1e-10
+
+
+ALL_CASES.append(case_solve_with_covariances)

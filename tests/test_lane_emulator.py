@@ -33,6 +33,7 @@ def test_emul_sdf_grad_copies(be, golden): PC.case_shared_sdf_gradient_partial_c
 def test_emul_static_qc_variants(be, golden): PC.case_static_qc_variants(be, golden, 'f64')
 def test_emul_unaligned(be, golden): PC.case_unaligned_buffers(be, golden, 'f64')
 def test_emul_unaligned_f32(be, golden): PC.case_unaligned_buffers(be, golden, 'f32')
+def test_emul_solve_with_covariances(be, golden): PC.case_solve_with_covariances(be, golden, 'f64')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)
