@@ -276,7 +276,7 @@ def extra_workloads(device, stream, reps=1500):
     us = time_launches(lambda k: s.gn_step(B, ptrs[k % 4], sp, gp, sas[k % len(sas)], cv, dp, ep_, xp, ip, stream), reps)
     by = algorithmic_bytes_per_trajectory(n, d, cov_tensors=covs) * B
     lpt, c = s.launch_shape(B)
-    kname = 'gn_kernel<%d,%d,%d,float,0,%d>' % (dof, lpt, c, 2 if covs else 1)      # <dof, LPT, C, io, MODE_STEP, QK: 1 static, 2 per-state Kronecker>
+    kname = 'gn_kernel<%d,%d,%d,float,0,%d>' % (dof, lpt, c, 2 if covs else s.step_kernel_variant(B))      # <dof, LPT, C, io, MODE_STEP, QK: 1 static, 2 per-state Kronecker, 3 Woodbury>
     out[tag] = {'workload': note, 'kernel_avg_us': us, 'gn_steps_per_s': 1e6 / us,
                 'roofline': roofline_block(by, us, kname, traffic_key=traffic_key)}
     del keep
@@ -422,7 +422,7 @@ def main():
     bytes_per_launch = algorithmic_bytes_per_trajectory(n, d) * B
     lpt, cc = solver.launch_shape(B)
     waves = (B + (64 // lpt) - 1) // (64 // lpt)
-    kname = 'gn_kernel<%d,%d,%d,float,0,1>' % (DOF, lpt, cc)      # <dof, LPT, C, io, MODE_STEP, QK_STATIC>
+    kname = 'gn_kernel<%d,%d,%d,float,0,%d>' % (DOF, lpt, cc, solver.step_kernel_variant(B))      # <dof, LPT, C, io, MODE_STEP, QK: 1 block elimination, 3 Woodbury>
     ks = kernel_stats().get(kname)
     out = {
         'metric': 'Gauss-Newton steps/sec (whole node), batch=4096 x 64 states, 2D point robot',

@@ -48,7 +48,7 @@ class DgpError(RuntimeError):
 class CApi(object):
   """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
 
-  SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'gn_step', 'gn_solve',
+  SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
              'eval_errors', 'gn_step_backward', 'time_next_launch')
 
   def __init__(self, path, prefix='dgp_'):
@@ -66,6 +66,7 @@ class CApi(object):
     self.num_factor_rows = f('num_factor_rows'); self.num_factor_rows.restype = C.c_int; self.num_factor_rows.argtypes = [vp]
     self.launch_shape = f('launch_shape'); self.launch_shape.restype = C.c_int
     self.launch_shape.argtypes = [vp, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    self.step_kernel_variant = f('step_kernel_variant'); self.step_kernel_variant.restype = C.c_int; self.step_kernel_variant.argtypes = [vp, i32]
     self.gn_step = f('gn_step'); self.gn_step.restype = C.c_int
     self.gn_step.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp]
     self.gn_solve = f('gn_solve'); self.gn_solve.restype = C.c_int
@@ -182,6 +183,12 @@ class Solver(object):
     l, c = C.c_int32(), C.c_int32()
     self.api.check(self.api.launch_shape(self.handle, int(batch), C.byref(l), C.byref(c)))
     return l.value, c.value
+
+  def step_kernel_variant(self, batch):
+    """Kernel variant a static-covariance step of this batch launches: 1 block elimination, 3 Woodbury interior elimination, 0 general."""
+    v = self.api.step_kernel_variant(self.handle, int(batch))
+    if v < 0: self.api.check(v)
+    return v
 
   @staticmethod
   def sdf_arg(ptr, rows, cols, batch_stride):

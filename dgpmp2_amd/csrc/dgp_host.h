@@ -78,6 +78,15 @@ inline DgpShape choose_shape(const DgpHandle* h, int B) {
   return best;
 }
 
+// dgp_step_kernel_variant: the dgp::QK_* variant a static-covariance step of this batch size launches (mirrors launch_typed)
+inline int step_kernel_variant(const DgpHandle* h, int B) {
+  dgp::GnParams p = h->base;
+  p.qc_mode = dgp::QC_STATIC;
+  const DgpShape sh = choose_shape(h, B);
+  if (!dgp::use_static_kernels(p)) return dgp::QK_GENERAL;
+  return dgp::wb_applies(p, sh.lpt, sh.c) ? dgp::QK_WB : dgp::QK_STATIC;
+}
+
 // The constant blocks of a GP factor under the configured (static) Q_c_inv: Q^-1 exactly as dgp::fixed_Qinv builds it,
 // U = -Phi^T Q^-1 (block (i,i+1) of Lambda) and Phi^T Q^-1 Phi (the factor's share of block (i,i)); Phi = [[I, dt I],[0, I]].
 inline void fill_static_blocks(dgp::GnParams& p, int dof) {
@@ -163,6 +172,8 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   p.M = (double)h->M;
   p.inv_M = 1.0 / p.M;
   fill_static_blocks(p, dof);
+  dgp::wb_fill_table(p, dof);                                           // constants of the Woodbury kernels (gn_woodbury.h); wb_ok says whether they apply
+  if (const char* nw = getenv("DGP_NO_WOODBURY")) { if (nw[0] == '1') p.wb_ok = 0; }      // tuning / A-B aid: keep the block elimination
   *out = h;
   return DGP_OK;
 }

@@ -46,6 +46,11 @@ int dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c
   return DGP_OK;
 }
 
+int dgp_step_kernel_variant(const DgpHandle* h, int32_t batch) {
+  if (!h || batch <= 0) return fail(DGP_EINVAL, "null handle or non-positive batch");
+  return dgp_host::step_kernel_variant(h, batch);
+}
+
 int dgp_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                 const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void* stream) {
   dgp::GnParams p;

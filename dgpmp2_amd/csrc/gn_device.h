@@ -14,8 +14,14 @@ namespace dgp_dev {
 struct DevCtx {
   char* lds_;      // the workgroup's (= wavefront's) LDS staging block, dgp::WaveStore<...>::kLdsBytes
   char* stash_;    // dgp::SinvStash block (d = 6 kernels), or null
+  char* wb_;       // LDS copy of the Woodbury constant table (QK_WB kernels), dgp::kWbLdsBytes
   __device__ __forceinline__ char* lds() const { return lds_; }
   __device__ __forceinline__ char* stash() const { return stash_; }
+  __device__ __forceinline__ char* wb_lds() const { return wb_; }
+  // the table inside the kernel-argument segment (GnParams is the first argument of every kernel)
+  __device__ __forceinline__ const double* wb_source(const dgp::GnParams&) const {
+    return (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(dgp::GnParams, wb_tab));
+  }
   __device__ __forceinline__ void lds_sync() const { __syncthreads(); }      // one wavefront per workgroup
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
@@ -97,23 +103,26 @@ __device__ __forceinline__ void warm_kernarg() {
 // QK: kernel variant by covariance representation, dgp::QK_* (static: the constant GP blocks are scalar operands; see gn_lane.h).
 template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
-  warm_kernarg<(int)sizeof(dgp::GnParams)>();
+  warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();      // (the Woodbury table behind it is read with vector loads)
   // STEP: staging block of the full-line th / dtheta accesses; SOLVE: the fp64 trajectory rows parked between iterations
   // (+ an S_k^-1 stash where SinvStashBlocks asks for one -- currently only the backward kernel does: in STEP mode it would ALIAS
   // the staging block, th being loaded before the sweep and dtheta stored after the recovery; in SOLVE mode follow the trajectory)
   constexpr int kRows = (MODE == dgp::MODE_SOLVE) ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;
   constexpr int kLds = (MODE == dgp::MODE_SOLVE) ? kRows + kStash : (kRows > kStash ? kRows : kStash);
-  __shared__ __attribute__((aligned(16))) char lds[kLds];
+  constexpr int kWb = (QK == dgp::QK_WB) ? dgp::kWbLdsBytes : 0;
+  __shared__ __attribute__((aligned(16))) char lds[kLds + kWb];
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = (MODE == dgp::MODE_SOLVE) ? lds + kRows : lds;
+  cx.wb_ = lds + kLds;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
 template <int DOF, int LPT, int C, typename IO, int QK>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
-  warm_kernarg<(int)(sizeof(dgp::GnParams) + sizeof(dgp::GnGradParams))>();
+  warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();
+  warm_kernarg_lines<((int)sizeof(dgp::GnGradParams) + 63) / 64>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(dgp::GnParams));
   constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
@@ -122,6 +131,7 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = lds;
+  cx.wb_ = nullptr;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
 }
 
@@ -167,6 +177,13 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
     if constexpr (GROUP == GROUP_STATIC) {                                                                                 \
+      if constexpr (CC == 4) {                                                                                             \
+        if (dgp::wb_applies(p, L, CC)) {                                                                                   \
+          if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WB>));                 \
+          else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WB>));                                       \
+          return hipGetLastError();                                                                                        \
+        }                                                                                                                  \
+      }                                                                                                                    \
       if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));                 \
       else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \

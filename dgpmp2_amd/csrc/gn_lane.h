@@ -30,6 +30,8 @@
 #pragma once
 #include <stdint.h>
 #include <math.h>
+#include <stddef.h>
+#include <type_traits>
 
 #ifndef DGP_HD
 #define DGP_HD __host__ __device__ __forceinline__
@@ -67,7 +69,16 @@ enum { FLAG_NONHOLONOMIC = 1u, FLAG_VEL_LIMITS = 2u };
 //   QK_KRON   : per-state Q_c^-1 tensors (qc_mode PERSTATE: the learned modes diag_identity / qc_full) -- Q^-1 = T (x) C_k is never
 //               formed, a row keeps the symmetric dof x dof C_k only
 //   QK_GENERAL: per-state full Q^-1 (q_full) or a non-diagonal static Q_c_inv -- a row keeps its symmetric d x d Q_k^-1
-enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2 };
+//   QK_WB     : QK_STATIC with Q_c_inv = c I, no velocity-limit factors, C = 4 and n == LPT * C -- the three interior rows of a lane are
+//               eliminated through the Woodbury identity on a constant interior block (gn_woodbury.h)
+enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2, QK_WB = 3 };
+
+// Layout of the QK_WB constant table (GnParams::wb_tab; doubles, per version -- 0: every lane but the first of a trajectory, 1: the first):
+//   K6 (6 x 6, row-major; index (k * 2 + pv) of interior row k, pv = 0 position / 1 velocity), K6 Cp (6 x 2), K6 Cs (6 x 2),
+//   Cp^T K6 Cp (packed symmetric 2 x 2 + pad), Cp^T K6 Cs (2 x 2), Cs^T K6 Cs (packed + pad)
+enum { WB_K6 = 0, WB_KCP = 36, WB_KCS = 48, WB_GPP = 60, WB_GPS = 64, WB_GSS = 68, WB_TYPE_DOUBLES = 72, WB_TYPES = 2 };
+constexpr int kWbTypeStrideBytes = WB_TYPE_DOUBLES * 8 + 16;      // LDS copy: the second version starts 16 bytes (4 banks) off a multiple of 64 banks
+constexpr int kWbLdsBytes = WB_TYPES * kWbTypeStrideBytes;
 
 // Kernel arguments (plain data, passed by value).
 struct GnParams {
@@ -111,7 +122,17 @@ struct GnParams {
   double q_fix[21];          // Q^-1                                   (gp_factor.py:65-73)
   double a_fix[21];          // Phi^T Q^-1 Phi                         (block (i,i) share of factor i -> i+1)
   double u_fix[36];          // U = -Phi^T Q^-1                        (block (i,i+1))
+  // QK_WB kernels (gn_woodbury.h): sqrt of the fixed obstacle / non-holonomic weights, validity of the table, the table (LAST: the
+  // kernels read it with vector loads, not through the scalar cache, and warm_kernarg stops in front of it)
+  double obs_w_sqrt, w_d_sqrt;
+  int32_t wb_ok, pad3_;
+  double wb_tab[WB_TYPES * WB_TYPE_DOUBLES];
 };
+// The table is read as 16-byte cells.  NO alignment attribute on the member: it raises the alignment of the whole by-value kernel
+// argument to 16, hipcc 7.0 then lowers the argument loads of EVERY kernel differently, and the <3,64,2,double,STEP,per-state>
+// kernel built that way writes through a wild address (same source without the attribute: identical code to the previous round's,
+// exact results).  The offset is a multiple of 16 as it stands; the kernel-argument segment itself is 64-byte aligned.
+static_assert(offsetof(GnParams, wb_tab) % 16 == 0, "wb_tab must start on a 16-byte boundary of the kernel-argument segment");
 
 // The QK_STATIC kernel variants (see Coupling below) apply to static covariances with a diagonal Q_c_inv.
 DGP_HD bool use_static_kernels(const GnParams& p) { return p.qc_mode == QC_STATIC && p.qc_diag != 0; }
@@ -242,7 +263,9 @@ DGP_HD void inv3(const double (&m)[6], double (&o)[6], OK& ok) {      // packed 
 // Two reciprocals and a dependency depth of ~12 operations instead of d sequential pivots; ok=false if not SPD.
 template <int D, typename OK>
 DGP_HD void sym_inverse(const Sym<D>& A, Sym<D>& Ai, OK& ok) {
-  if constexpr (D == 4) {
+  if constexpr (D == 3) {
+    inv3(A.v, Ai.v, ok);
+  } else if constexpr (D == 4) {
     double p0, p1, p2;
     inv2(A(0, 0), A(0, 1), A(1, 1), p0, p1, p2, ok);
     // Y = P^-1 Q (2x2), Q = A[0:2, 2:4]
@@ -808,6 +831,7 @@ DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, 
 template <int D, int C, int QK> struct LaneQ;
 template <int D, int C> struct LaneQ<D, C, QK_GENERAL> { Sym<D> q[C]; Sym<D> qm0; };
 template <int D, int C> struct LaneQ<D, C, QK_STATIC> {};
+template <int D, int C> struct LaneQ<D, C, QK_WB> {};
 template <int D, int C> struct LaneQ<D, C, QK_KRON> { Sym<D / 2> c[C]; Sym<D / 2> cm0; };      // C_k = Q_c^-1 of the factor, read as a symmetric matrix
 
 // N consecutive elements starting at src: 16-byte vector loads when `vec` (host-checked alignment) and N is a whole number of
@@ -867,6 +891,8 @@ DGP_HD void load_lane_Q(const GnParams& p, int64_t b, int g0, bool traj_ok, Lane
 }
 template <int DOF, int C, typename IO>
 DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_STATIC>&) {}
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_WB>&) {}
 
 // per-state C = Q_c^-1 (dof x dof) of factor f, upper triangle (qc_mode PERSTATE only: p.qc is the (B, n-1, dof, dof) tensor)
 template <int DOF, typename IO>
@@ -1528,14 +1554,146 @@ DGP_HD void pcr_round(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], Spd
   for (int a = 0; a < D; ++a) r[a] = rn[a];
 }
 
-template <int D, int LPT, typename Ctx>
+// Scheduling fence: nothing is moved across it by the instruction scheduler (no instruction is emitted).  The d = 6 kernels
+// use it between the stages of a PCR round and between the phases of the Woodbury elimination: left alone, the scheduler
+// interleaves the stages of these ~2000-instruction straight-line blocks, every block of every stage is live at once, and the
+// working set lands in AGPRs (1000 parking moves) and scratch.
+DGP_HD void sched_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// pcr_round in a register-lean order (same arithmetic, same results as pcr_round): stage by stage, each block dies before the
+// next one is born -- peak 117 doubles for d = 6 (D, U, r, D^-1, y, D_R^-1, y_R) instead of ~200:
+//   1. D^-1, y = D^-1 r                       2. fetch D_R^-1, y_R;  row by row: T_a = U_a D_R^-1,  r_a -= U_a y_R,  D_a. -= T_a U^T
+//   3. G = D^-1 U (D^-1 dies)                 4. v = U^T y -> right neighbour's r (y dies)
+//   5. column by column: W_.c = U^T G_.c -> right neighbour's D;  fetch G_R,.c (G_.c dies);  U'_.c = -U G_R,.c
+template <int D, int LPT, int S, typename Ctx>
+DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
+  typedef Nbr<LPT, S, Ctx> NB;
+  const NB nb(cx, i);
+  const bool has_l = (i >= S);
+  Sym<D> Di;
+  double y[D];
+  sched_fence();
+  sym_inverse<D>(Dm, Di, ok);
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) t += Di(a, k) * r[k];
+    y[a] = t;
+  }
+  sched_fence();
+  {
+    Sym<D> DiR;
+    double yR[D];
+#pragma unroll
+    for (int k = 0; k < D * (D + 1) / 2; ++k) DiR.v[k] = nb.hi(Di.v[k]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) yR[a] = nb.hi(y[a]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double Ta[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) t += U.v[a][k] * DiR(k, c);
+        Ta[c] = t;
+      }
+      double t = r[a];
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= U.v[a][k] * yR[k];
+      r[a] = t;
+#pragma unroll
+      for (int c = a; c < D; ++c) {
+        double w = Dm(a, c);
+#pragma unroll
+        for (int k = 0; k < D; ++k) w -= Ta[k] * U.v[c][k];
+        Dm(a, c) = w;
+      }
+    }
+  }
+  sched_fence();
+  Mat<D> G;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double g = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) g += Di(a, k) * U.v[k][c];
+      G.v[a][c] = g;
+    }
+  sched_fence();
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) v += U.v[k][a] * y[k];
+    const double vL = nb.lo(v);
+    r[a] -= (NB::kDpp || has_l) ? vL : 0.0;
+  }
+  sched_fence();
+  Mat<D> Un;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+#pragma unroll
+    for (int a = 0; a <= c; ++a) {
+      double w = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) w += U.v[k][a] * G.v[k][c];
+      const double wL = nb.lo(w);
+      Dm(a, c) -= (NB::kDpp || has_l) ? wL : 0.0;
+    }
+    double GRc[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) GRc[k] = nb.hi(G.v[k][c]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) t -= U.v[a][k] * GRc[k];
+      Un.v[a][c] = t;
+    }
+    if (c % 2 == 1) sched_fence();
+  }
+  U = Un;
+  sched_fence();
+}
+
+// which dimension gets the register-lean round (tuning aid: -DDGP_PCR_LEAN_ALL=1 / -DDGP_PCR_LEAN_NONE=1)
+#if defined(DGP_PCR_LEAN_ALL)
+#define DGP_PCR_LEAN_D(D) true
+#elif defined(DGP_PCR_LEAN_NONE)
+#define DGP_PCR_LEAN_D(D) false
+#else
+#define DGP_PCR_LEAN_D(D) ((D) == 6)
+#endif
+template <int D, int LPT, int S, bool LEAN, typename Ctx>
+DGP_HD void pcr_round_any(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
+  constexpr bool last = (2 * S >= LPT);
+  // Only the rounds whose exchanges are DPP row shifts (LPT = 16; LPT = 32 from stride 2 on).  With the lean order on the ds_bpermute
+  // rounds of LPT = 64, hipcc 7.0 built a <3,64,2,double,STEP,general> kernel that returns wrong results (4e-2 off; the same source
+  // is exact on the CPU wavefront emulator, every other shape is exact on the GPU) -- found by tests/stress_random_configs.py.
+  // And not in the general-covariance kernels (LEAN = false there): <3,16,4,double,STEP,general> -- 355 spilled VGPRs, 1.4 KB of scratch
+  // per lane -- came out wrong (O(1) errors) with the lean rounds, again only on the GPU (tests/test_hip_every_kernel.py pins every
+  // instantiation against the C oracle since).
+  if constexpr (LEAN && DGP_PCR_LEAN_D(D) && !last && Nbr<LPT, S, Ctx>::kDpp && LPT != 64) pcr_round_lean<D, LPT, S>(cx, i, Dm, U, r, ok);
+  else pcr_round<D, LPT, S>(cx, i, Dm, U, r, ok);
+}
+
+template <int D, int LPT, bool LEAN, typename Ctx>
 DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], double (&x)[D], SpdCheck<Ctx>& ok) {
-  if constexpr (LPT > 1) pcr_round<D, LPT, 1>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 2) pcr_round<D, LPT, 2>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 4) pcr_round<D, LPT, 4>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 8) pcr_round<D, LPT, 8>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 16) pcr_round<D, LPT, 16>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 32) pcr_round<D, LPT, 32>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 1) pcr_round_any<D, LPT, 1, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 2) pcr_round_any<D, LPT, 2, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 4) pcr_round_any<D, LPT, 4, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 8) pcr_round_any<D, LPT, 8, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 16) pcr_round_any<D, LPT, 16, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LEAN && DGP_PCR_LEAN_D(D) && LPT != 64) sched_fence();
   Sym<D> Di;
   sym_inverse<D>(Dm, Di, ok);                   // (block inverse: two reciprocals deep, against d sequential pivots of a solve)
   sym_times_vec<D>(Di, r, x);
@@ -2130,7 +2288,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   DGP_STAMP_NOWAIT(p, cx, 3);
   before_pcr(acc);
   double xs[D];
-  pcr_solve<D, LPT>(cx, j, Ds, Us, rs, xs, ok);
+  pcr_solve<D, LPT, (QK != QK_GENERAL)>(cx, j, Ds, Us, rs, xs, ok);
 #pragma unroll
   for (int a = 0; a < D; ++a) dx[C - 1][a] = xs[a];
 #if defined(DGP_PHASE_STOP)
@@ -2343,6 +2501,10 @@ DGP_HD void lds_get_rows(Ctx& cx, double (&v)[C][D]) {
   }
 }
 
+}  // namespace dgp
+#include "gn_woodbury.h"
+namespace dgp {
+
 // ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
@@ -2363,6 +2525,10 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
                "s"(p.sdf_bstride), "s"(p.eps), "s"(p.obs_w));
 #endif
 
+  // constants of the Woodbury elimination (host-checked: C == 4, n == LPT * C): loads issued ahead of the th rows, committed to LDS behind them
+  struct NoStage {};
+  typename std::conditional<QK == QK_WB, WbStaged, NoStage>::type wbv;
+  if constexpr (QK == QK_WB) wb_stage_issue(p, cx, wbv);
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];
   LaneQ<D, C, QK> lq;                           // generic covariances: Q^-1 of the lane's C + 1 GP factors, loaded once (loop-invariant in MODE_SOLVE)
@@ -2379,6 +2545,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   }
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
+  if constexpr (QK == QK_WB) wb_stage_commit(cx, wbv);
   DGP_STAMP(p, cx, 1);
 
   if (MODE == MODE_EVAL) {
@@ -2414,13 +2581,29 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     double dx[C][D];
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);       // the state comes back from LDS
     double e = 0.0, ee = 0.0;
-    gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
+    auto before_pcr = [&](const ErrAcc& a) {
       e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
       if (MODE == MODE_STEP && traj_ok && j == 0) {
         if (p.err) st<IO>(p.err, b, div_M(p, e));
         if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
       }
-    });
+    };
+    if constexpr (QK == QK_WB) {
+      static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
+      gn_linear_solve_wb<DOF, LPT, IO, false>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, before_pcr);
+    } else {
+#if defined(DGP_BISECT_LAMBDA)
+      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
+        e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
+        if (MODE == MODE_STEP && traj_ok && j == 0) {
+          if (p.err) st<IO>(p.err, b, div_M(p, e));
+          if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
+        }
+      });
+#else
+      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, before_pcr);
+#endif
+    }
     DGP_STAMP_NOWAIT(p, cx, 4);
     if (MODE == MODE_STEP) {
       // wave-uniform: the wavefront's dtheta rows are one contiguous, fully populated block -> full-line stores via LDS

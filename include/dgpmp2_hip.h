@@ -109,6 +109,13 @@ int  dgp_num_factor_rows(const DgpHandle* h);
  * lane (reporting / tuning aid; the environment variable DGP_FORCE_SHAPE="LPT,C" read by dgp_create pins it). */
 int  dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lanes_per_trajectory, int32_t* states_per_lane);
 
+/* Kernel variant dgp_gn_step / dgp_gn_solve launch for a batch of `batch` trajectories WITH STATIC covariances (covs == NULL):
+ * 1 = block elimination with the constant GP blocks as scalar operands, 3 = interior rows eliminated through the Woodbury identity
+ * on the constant GP block (Q_c_inv = c I, no velocity-limit factors, num_states == 4 * lanes per trajectory; gn_woodbury.h),
+ * 0 = the general kernels (non-diagonal Q_c_inv).  Per-state covariance tensors select their own kernels per call.  Reporting
+ * only (bench.py names the kernel whose instruction counts it quotes); DGP_NO_WOODBURY=1 at dgp_create keeps variant 1. */
+int  dgp_step_kernel_variant(const DgpHandle* h, int32_t batch);
+
 /* One batched Gauss-Newton step == PlanLayer.forward (plan_layer.py:87-99):
  * factor evaluation (gp_factor.py:100-110, prior_factor.py:15-18, obstacle_factor.py:35-40 ->
  * obstacle_cost.py:29-38 -> sdf_utils.py:38-107, custom_factors/), assembly of the block-tridiagonal

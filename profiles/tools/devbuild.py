@@ -25,6 +25,7 @@ def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('units', nargs='+')
   ap.add_argument('-D', action='append', default=[])
+  ap.add_argument('--flag', action='append', default=[], help='extra hipcc argument, e.g. --flag=-mllvm --flag=-amdgpu-spill-sgpr-to-vgpr=false')
   ap.add_argument('-o', default='libdgpmp2_dev.so')
   ap.add_argument('--show', default=',16,4,')
   a = ap.parse_args()
@@ -32,7 +33,7 @@ def main():
   work = os.path.join('/tmp', 'dgp_dev_' + a.o.replace('.', '_'))
   shutil.rmtree(work, ignore_errors=True); os.makedirs(work)
   hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-  base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-save-temps=obj'] + ['-D' + d for d in a.D]
+  base = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', '-save-temps=obj'] + ['-D' + d for d in a.D] + a.flag
   jobs = []
   for u in a.units:
     dof, t, g = u.split('_')
@@ -48,7 +49,7 @@ def main():
       if u not in a.units:
         f.write('hipError_t dgp_launch_%s(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t) { return hipErrorInvalidValue; }\n' % u)
   d = os.path.join(work, 'stubs'); os.makedirs(d)
-  jobs.append(base[:-1] + [stub, '-o', os.path.join(d, 'stubs.o')])
+  jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', stub, '-o', os.path.join(d, 'stubs.o')])
   procs = [subprocess.Popen(j) for j in jobs]
   rcs = [p.wait() for p in procs]
   if any(rcs): raise SystemExit('hipcc failed: %s' % rcs)

@@ -68,6 +68,15 @@ def parse(path):
       if m:
         kernels[meta_for][{'NumVgprs': 'vgpr', 'NumAgprs': 'agpr', 'TotalNumVgprs': 'vgpr_total', 'ScratchSize': 'scratch_bytes_per_lane',
                            'Occupancy': 'waves_per_simd', 'NumSgprs': 'sgpr', 'LDSByteSize': 'lds_bytes', 'codeLenInByte': 'code_bytes'}[m.group(1)]] = int(m.group(2))
+  # register spill counts from the code-object metadata at the end of the file (.sgpr_spill_count: SGPRs -- lane masks of selects and
+  # ballots -- spilled into VGPR lanes; hipcc 7.0 has produced wrong code in d = 6 kernels that do a lot of it)
+  text = open(path, errors='replace').read()
+  for blk in text.split('  - .agpr_count:')[1:]:
+    nm = re.search(r'\.name:\s+(\S+)', blk)
+    if not nm or nm.group(1) not in kernels: continue
+    for key, field in (('sgpr_spill', 'sgpr_spill_count'), ('vgpr_spill', 'vgpr_spill_count')):
+      m = re.search(r'\.%s:\s+(\d+)' % field, blk)
+      if m: kernels[nm.group(1)][key] = int(m.group(1))
   return {short_name(n): v for n, v in kernels.items()}
 
 

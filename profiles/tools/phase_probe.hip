@@ -7,6 +7,9 @@
 #if PROBE_STOP > 0
 #define DGP_PHASE_STOP PROBE_STOP
 #endif
+#ifndef PROBE_QK
+#define PROBE_QK 1      // dgp::QK_STATIC; -DPROBE_QK=3: the Woodbury kernel (dgp::QK_WB)
+#endif
 #include "gn_device.h"
 #include <vector>
 #include <random>
@@ -55,7 +58,7 @@ int main(int argc, char** argv) {
   int launch_no = 0;
   auto launch = [&]() {
     p.th = d_th + (size_t)(launch_no++ % 10) * th.size();
-    hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, p);
+    hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, PROBE_QK>), grid, block, 0, 0, p);
   };
   for (int i = 0; i < 2000; ++i) launch();        // clocks up
   hipDeviceSynchronize();
@@ -70,7 +73,7 @@ int main(int argc, char** argv) {
     hipStream_t cs; hipStreamCreate(&cs);
     hipGraph_t graph; hipGraphExec_t exec;
     hipStreamBeginCapture(cs, hipStreamCaptureModeGlobal);
-    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, cs, p);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, PROBE_QK>), grid, block, 0, cs, p);
     hipStreamEndCapture(cs, &graph);
     hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     for (int i = 0; i < 5; ++i) hipGraphLaunch(exec, cs);
@@ -90,7 +93,7 @@ int main(int argc, char** argv) {
     p0.err_hist = d_s0; p1.err_hist = d_s1;
     for (int i = 0; i < 400; ++i) {
       const dgp::GnParams& q = (i == 200) ? p0 : ((i == 201) ? p1 : p);
-      hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, true>), grid, block, 0, 0, q);
+      hipLaunchKernelGGL((dgp_dev::gn_kernel<2, 16, 4, float, dgp::MODE_STEP, PROBE_QK>), grid, block, 0, 0, q);
     }
     hipDeviceSynchronize();
     std::vector<unsigned long long> s0((size_t)waves * 16), s1((size_t)waves * 16);

@@ -21,6 +21,7 @@ struct WaveShared {
   double slot[64];
   int islot[64];
   alignas(16) char lds[64 * (4 * 6 * 8 + 16) + 64 * 544];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64) + dgp::SinvStash
+  alignas(16) char wb[dgp::kWbLdsBytes];                        // LDS copy of the Woodbury constant table
 };
 
 pthread_mutex_t g_atomic_mutex = PTHREAD_MUTEX_INITIALIZER;
@@ -32,6 +33,8 @@ struct HostCtx {
   int wave() const { return wave_; }
   char* lds() { return ws->lds; }
   char* stash() { return ws->lds + 64 * (4 * 6 * 8 + 16); }
+  char* wb_lds() { return ws->wb; }
+  const double* wb_source(const dgp::GnParams& p) const { return p.wb_tab; }
   void lds_sync() { pthread_barrier_wait(&ws->bar); }
   double fetch(double v, int src) {
     ws->slot[lane_] = v;
@@ -105,6 +108,13 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
       HostCtx cx{&ws, l, wave};
       // same dispatch as dgp_dev::launch_typed: the kernel variant follows the covariance representation
       const int qk = dgp::kernel_variant(p);
+      if constexpr (C == 4) {      // the Woodbury kernels, chosen exactly as dgp_dev::launch_typed does
+        if ((mode == dgp::MODE_STEP || mode == dgp::MODE_SOLVE) && qk == dgp::QK_STATIC && dgp::wb_applies(p, LPT, C)) {
+          if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_WB>(p, cx);
+          else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_WB>(p, cx);
+          return;
+        }
+      }
       if (mode == dgp::MODE_STEP) {
         if (qk == dgp::QK_STATIC) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_STATIC>(p, cx);
         else if (qk == dgp::QK_KRON) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_KRON>(p, cx);
@@ -165,6 +175,11 @@ int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* 
   if (lpt) *lpt = sh.lpt;
   if (c) *c = sh.c;
   return DGP_OK;
+}
+
+int emul_step_kernel_variant(const DgpHandle* h, int32_t batch) {
+  if (!h || batch <= 0) return DGP_EINVAL;
+  return dgp_host::step_kernel_variant(h, batch);
 }
 
 int emul_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,

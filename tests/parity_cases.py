@@ -458,3 +458,61 @@ def case_solve_with_covariances(be, golden, io):
 
 
 ALL_CASES.append(case_solve_with_covariances)
+
+
+def case_woodbury_kernels(be, golden, io, shapes=('16,4', '32,4', '64,4'), nb=3):
+  """The QK_WB kernels (gn_woodbury.h: interior rows eliminated through the Woodbury identity on the constant GP block) against the
+  oracle, for every shape they are built for (n == LPT * 4), both robots, static and per-state obstacle weights, the single step and the
+  fused loop -- and against the block-elimination kernels on the same inputs (DGP_NO_WOODBURY=1): both within tolerance of the oracle,
+  NOT bit-identical (which proves the Woodbury kernels are the ones that ran)."""
+  import os
+  rs = np.random.RandomState(5)
+  saved = {k: os.environ.get(k) for k in ('DGP_FORCE_SHAPE', 'DGP_NO_WOODBURY')}
+  try:
+    for shape in shapes:
+      lpt = int(shape.split(',')[0])
+      n = lpt * 4
+      os.environ['DGP_FORCE_SHAPE'] = shape
+      for dof, kw in ((2, {}), (2, dict(Q_c_inv=2.5 * np.eye(2), cost_sigma=0.05, K_s=0.1, reg=1e-2)),      # (reg = 1e-3 at n = 256: cond 4e7, every solver 2-3e-9 off the dense oracle)
+                      (3, dict(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)), (3, dict(reg=0.1))):
+        p = O.OracleParams(dof=dof, total_time_step=n - 1, **kw)
+        sp = rs.uniform(-4, 4, (nb, 1, 2)); gp = rs.uniform(-4, 4, (nb, 1, 2))
+        if dof == 3:
+          sp = np.concatenate([sp, np.zeros((nb, 1, 1))], -1); gp = np.concatenate([gp, np.full((nb, 1, 1), np.pi / 2)], -1)
+        start = np.concatenate([sp, np.zeros((nb, 1, dof))], -1); goal = np.concatenate([gp, np.zeros((nb, 1, dof))], -1)
+        th = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + 0.03 * rs.randn(nb, n, 2 * dof)
+        sdf = O.circles_sdf(96, O.C2_CIRCLES)[None, None]
+        os.environ['DGP_NO_WOODBURY'] = '0'
+        tag = 'woodbury %s dof %d %s' % (shape, dof, sorted(kw))
+        d_wb, e_wb, x_wb = check_step(be, p, th, start, goal, sdf, io, tag=tag)
+        os.environ['DGP_NO_WOODBURY'] = '1'
+        d_be, e_be, x_be = check_step(be, p, th, start, goal, sdf, io, tag=tag + ' (block elimination)')
+        os.environ['DGP_NO_WOODBURY'] = '0'
+        assert rel_err(d_wb, d_be) < 2 * TOL[io], (tag, rel_err(d_wb, d_be))
+        if io == 'f64': assert not np.array_equal(d_wb, d_be), tag + ': identical bits -- the Woodbury kernel did not run'
+        if dof == 2 and not kw:      # per-state obstacle weights / epsilons with static GP covariances (sqrt of the weight on the device)
+          ow = rs.uniform(0.5, 2.0, (nb, n, 1, 1)) / p.cost_sigma ** 2
+          eps = rs.uniform(0.3, 0.5, (nb, n, 1, 1))
+          check_step(be, p, th, start, goal, sdf, io, ow=ow, eps=eps, tag=tag + ' tensor weights')
+      # fused loop: dgp_gn_solve == chained steps (the same kernels in MODE_SOLVE)
+      p = P2d(n)
+      sp = rs.uniform(-4, 4, (nb, 1, 2)); gp = rs.uniform(-4, 4, (nb, 1, 2))
+      start = np.concatenate([sp, np.zeros((nb, 1, 2))], -1); goal = np.concatenate([gp, np.zeros((nb, 1, 2))], -1)
+      th = O.straight_line_trajb(sp, gp, 10.0, n - 1, 2)
+      sdf = O.circles_sdf(96, O.C2_CIRCLES)[None, None]
+      th_r, start_r, goal_r, sdf_r = rnd(th, io), rnd(start, io), rnd(goal, io), rnd(sdf, io)
+      tho, its, eh, eeh, ef, info = be.solve(p, th_r, start_r, goal_r, sdf_r, 4, 0.0, io=io)
+      cur = th_r.copy()
+      for k in range(4):
+        d, e, x, inf = be.step(p, cur, start_r, goal_r, sdf_r, io=io)
+        assert rel_err(eh[:, k], e) < (1e-9 if io == 'f64' else 2e-4), (shape, k, rel_err(eh[:, k], e))
+        cur = rnd(cur + d, io) if io == 'f64' else cur + d
+      if io == 'f64': assert rel_err(tho, cur) < 1e-9, (shape, rel_err(tho, cur))
+      assert np.all(its == 4) and np.all(info == 0)
+  finally:
+    for k, v in saved.items():
+      if v is None: os.environ.pop(k, None)
+      else: os.environ[k] = v
+
+
+ALL_CASES.append(case_woodbury_kernels)

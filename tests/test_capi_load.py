@@ -95,3 +95,21 @@ def test_launch_shape_choice(api):
   s6 = _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]]))
   assert s6.launch_shape(4096) == (16, 4)                   # d = 6, BASELINE configs[3]: 29.0 us against 45.8 us with (32,2)
   assert s6.launch_shape(32768) == (16, 4)
+
+
+def test_step_kernel_variant_choice(api, monkeypatch):
+  """dgp_step_kernel_variant (host logic): the Woodbury kernels (3) exactly where gn_woodbury.h applies -- Q_c_inv = c I, no velocity
+  limits, four states per lane and every row present -- the block elimination (1) elsewhere, the general kernels (0) for a
+  non-diagonal Q_c_inv; DGP_NO_WOODBURY=1 keeps the block elimination."""
+  monkeypatch.delenv('DGP_NO_WOODBURY', raising=False)
+  monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
+  assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(4096) == 3            # BASELINE configs[1]
+  assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(256) == 1             # (32,2) at small batches
+  assert _capi.Solver(_cfg(num_states=63)).step_kernel_variant(4096) == 1            # a missing row
+  assert _capi.Solver(_cfg(num_states=256)).step_kernel_variant(8) == 3
+  assert _capi.Solver(_cfg(num_states=64, use_vel_limits=True, K_v=0.01)).step_kernel_variant(4096) == 1
+  assert _capi.Solver(_cfg(num_states=64, Q_c_inv=[[1, 0], [0, 2]])).step_kernel_variant(4096) == 1
+  assert _capi.Solver(_cfg(num_states=64, Q_c_inv=[[1, 0.1], [0.1, 1]])).step_kernel_variant(4096) == 0
+  assert _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], non_holonomic=True, K_d=0.01)).step_kernel_variant(4096) == 3
+  monkeypatch.setenv('DGP_NO_WOODBURY', '1')
+  assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(4096) == 1

@@ -1,0 +1,86 @@
+"""GPU (-m gpu): EVERY forward kernel instantiation of the library -- 2 robots x 2 I/O types x 9 launch shapes x 4 covariance
+representations (static diagonal Q_c_inv: block elimination or Woodbury; static non-diagonal: general; per-state tensors: Kronecker;
+q_full: general) x {single step, fused loop} -- on a small batch against oracle/gn_blocktri.c, with the trajectory length that fills
+the shape exactly (n = LPT * C: full-line row I/O, the Woodbury kernels) and a ragged one (padding rows, scalar row I/O).
+
+Why this exists: hipcc 7.0 has miscompiled several of the largest d = 6 kernels (wrong results or wild stores, while the same source
+is exact on the CPU wavefront emulator and in every other instantiation).  Which instantiation breaks changes with
+unrelated edits, so the sampled stress run (tests/stress_random_configs.py) is not enough: this test pins every one, every round.
+A failure names the kernel's template arguments."""
+import os
+import numpy as np
+import pytest
+import harness
+import parity_cases as PC
+from oracle import gpmp2_oracle as O, blocktri as BT
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(l, c) for l in (16, 32, 64) for c in (1, 2, 4)]
+COVS = ['static', 'static_full', 'perstate', 'qfull']
+
+
+@pytest.fixture(scope='module')
+def be():
+  import torch
+  assert torch.cuda.is_available(), 'the -m gpu tests need a GPU'
+  return harness.Backend('hip')
+
+
+def _inputs(rs, dof, n, B, cov, io):
+  d = 2 * dof
+  kw = {}
+  if dof == 3: kw.update(non_holonomic=True, K_d=0.1)
+  if cov == 'static_full':
+    A = rs.randn(dof, dof) * 0.3
+    kw['Q_c_inv'] = np.eye(dof) + A @ A.T
+  p = O.OracleParams(dof=dof, total_time_step=n - 1, reg=0.1, epsilon_dist=0.3, **kw)
+  H, W = 24, 40
+  yy, xx = np.meshgrid(np.linspace(5, -5, H), np.linspace(-5, 5, W), indexing='ij')
+  cs = rs.uniform(-3, 3, (3, 2)); rr = rs.uniform(0.4, 1.2, 3)
+  sdf = np.min(np.sqrt((xx[None] - cs[:, 0, None, None]) ** 2 + (yy[None] - cs[:, 1, None, None]) ** 2) - rr[:, None, None], axis=0)[None, None]
+  start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+  start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+  if dof == 3: goal[:, 0, 2] = rs.uniform(-np.pi, np.pi, B)
+  th = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + rs.randn(B, n, d) * 0.03
+  qc = ow = eps = None; q_full = False
+  if cov in ('perstate', 'qfull'):
+    ow = rs.uniform(50, 2e4, (B, n)); eps = rs.uniform(0.1, 0.6, (B, n))
+    if cov == 'perstate':
+      A = rs.randn(B, n - 1, dof, dof) * 0.2; qc = np.eye(dof) + A @ np.swapaxes(A, -1, -2)
+    else:
+      A = rs.randn(B, n - 1, d, d) * 0.2; qc = (np.eye(d) + A @ np.swapaxes(A, -1, -2)) * 1.5; q_full = True
+  r = lambda a: None if a is None else PC.rnd(a, io)
+  return p, r(th), r(start), r(goal), r(sdf), r(qc), r(ow), r(eps), q_full
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_forward_kernel_vs_c_oracle(be, dof, io, monkeypatch):
+  rs = np.random.RandomState(100 * dof + (io == 'f32'))
+  bad = []
+  for lpt, c in SHAPES:
+    monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+    for cov in COVS:
+      for n in (lpt * c, max(2, lpt * c - 3)):
+        B = 64 // lpt + 1                      # one full wavefront and a partially filled one
+        p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, cov, io)
+        sh = (B, n, 1, 1)
+        okw = dict(qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh), q_full=q_full)
+        kw = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
+        tag = 'dof %d %s shape (%d,%d) n %d cov %s' % (dof, io, lpt, c, n, cov)
+        # ---- single step
+        dth, err, eex, info = be.step(p, th, start, goal, sdf, **kw)
+        c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, **okw)
+        e = PC.rel_err_per_traj(dth, c_dth) if np.all(np.isfinite(dth)) else np.inf
+        ee = PC.rel_err(err, c_err) if np.all(np.isfinite(err)) else np.inf
+        if not (e < PC.TOL[io] and ee < 10 * PC.TOL_ERR[io] and not info.any()): bad.append((tag, 'step', e, ee))
+        # ---- fused loop: three iterations == three chained oracle steps (fp64 I/O; fp32 I/O is held to the fp32 tolerance)
+        tho, its, eh, eeh, ef, sinfo = be.solve(p, th, start, goal, sdf, 3, 0.0, **kw)
+        cur = th.copy()
+        for k in range(3):
+          d_k, e_k, _, _ = BT.gn_step(p, cur, start, goal, sdf, **okw)
+          cur = cur + d_k
+        es = PC.rel_err(tho, cur) if np.all(np.isfinite(tho)) else np.inf
+        if not (es < (1e-7 if io == 'f64' else 1e-5) and not sinfo.any() and np.all(its == 3)): bad.append((tag, 'fused loop', es))
+  assert not bad, '%d kernel instantiations differ from the C oracle:\n' % len(bad) + '\n'.join(map(str, bad))

@@ -94,3 +94,12 @@ def test_force_shape_rejects_unsupported(force_shape):
 def test_emul_backward_shapes(be, golden, force_shape, shape):
   force_shape(shape)
   PC.case_backward_golden(be, golden, 'f64')
+
+
+def test_emul_woodbury_kernels(be, golden):
+  """gn_woodbury.h on the emulator: the smallest shape in full, the two larger ones with one robot each (64 threads per wavefront)."""
+  PC.case_woodbury_kernels(be, golden, 'f64', shapes=('16,4',), nb=2)
+
+
+def test_emul_woodbury_kernels_f32_and_wide_shapes(be, golden):
+  PC.case_woodbury_kernels(be, golden, 'f32', shapes=('32,4',), nb=1)
