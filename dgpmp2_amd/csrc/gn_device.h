@@ -127,11 +127,13 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
-  __shared__ __attribute__((aligned(16))) char lds[kMax > kStash ? kMax : kStash];
+  constexpr int kAll = kMax > kStash ? kMax : kStash;
+  constexpr int kWb = (QK == dgp::QK_WB) ? dgp::kWbLdsBytes : 0;
+  __shared__ __attribute__((aligned(16))) char lds[kAll + kWb];
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = lds;
-  cx.wb_ = nullptr;
+  cx.wb_ = lds + kAll;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
 }
 
@@ -195,6 +197,12 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));            \
       else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_KRON>));                                             \
     } else {                                                                                                               \
+      if constexpr (CC == 4) {                                                                                             \
+        if (qstat && dgp::wb_applies(p, L, CC)) {                                                                          \
+          DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB>));                                                \
+          return hipGetLastError();                                                                                        \
+        }                                                                                                                  \
+      }                                                                                                                    \
       if (qstat) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_STATIC>));                                     \
       else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_GENERAL>));                                          \
     }                                                                                                                      \

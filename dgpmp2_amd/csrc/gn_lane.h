@@ -2528,7 +2528,6 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   // constants of the Woodbury elimination (host-checked: C == 4, n == LPT * C): loads issued ahead of the th rows, committed to LDS behind them
   struct NoStage {};
   typename std::conditional<QK == QK_WB, WbStaged, NoStage>::type wbv;
-  if constexpr (QK == QK_WB) wb_stage_issue(p, cx, wbv);
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];
   LaneQ<D, C, QK> lq;                           // generic covariances: Q^-1 of the lane's C + 1 GP factors, loaded once (loop-invariant in MODE_SOLVE)
@@ -2545,7 +2544,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   }
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
-  if constexpr (QK == QK_WB) wb_stage_commit(cx, wbv);
+  if constexpr (QK == QK_WB) wb_stage_issue(p, cx, wbv);
   DGP_STAMP(p, cx, 1);
 
   if (MODE == MODE_EVAL) {
@@ -2590,7 +2589,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     };
     if constexpr (QK == QK_WB) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, false>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, before_pcr);
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {

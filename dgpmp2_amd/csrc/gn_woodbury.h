@@ -119,9 +119,10 @@ DGP_HD bool wb_applies(const GnParams& p, int lpt, int c) { return p.wb_ok != 0 
 // ---- device / emulator ---------------------------------------------------------------------------------
 // Every wavefront copies the table from the kernel arguments into its LDS block (72 16-byte cells; the second version is
 // shifted by 16 bytes so that the two addresses a 16-lane group reads from hit different banks).  Two steps: the loads are
-// ISSUED at kernel entry, ahead of the th rows (a first version waited for them on the spot: two exposed kernel-argument
-// round trips in front of everything else ate the whole gain), and COMMITTED to LDS once the th rows have arrived -- vector
-// loads return in order, so by then the table cells are there too.  Lane l carries cells l and 64 + (l & 7) (duplicates
+// ISSUED behind the start / goal rows and ahead of the SDF taps, and COMMITTED to LDS inside the first solve once the taps have
+// arrived -- vector loads return in order, so by then the table cells are there too and nothing waits for them.  (A first
+// version loaded and stored on the spot at kernel entry: two exposed kernel-argument round trips in front of everything else
+// ate the whole gain; issued at entry and committed behind the th rows they still cost 0.16 us of the load phase.)  Lane l carries cells l and 64 + (l & 7) (duplicates
 // write the same value to the same address: no branch).
 struct WbStaged { double c0 __attribute__((vector_size(16))); double c1 __attribute__((vector_size(16))); };
 template <typename Ctx>
@@ -161,6 +162,8 @@ struct WbF {
 //          (forward substitutions instead of products with an explicit inverse: R (R - 1) / 2 instead of R^2 operations per column,
 //          and a factorisation of ~R^3 / 6 operations instead of the ~200 of the 6 x 6 block inverse);
 //   R = 3: S^-1 explicitly (one reciprocal; three dependent pivots would cost more than they save):  Y = B,  Z = S^-1 B.
+// Z is produced one column at a time (zcol) where it is consumed: for R = 6 it is a row scaling of Y, and keeping Z_p, Z_s next to
+// Y_p, Y_s (4 x 36 doubles) is what pushed the d = 6 kernel's Schur assembly into scratch.
 template <int R>
 struct WbSolver {
   double L[R][R], dinv[R];
@@ -186,7 +189,7 @@ struct WbSolver {
     }
   }
   template <int N>
-  DGP_HD void yz(const double (&B)[R][N], double (&Y)[R][N], double (&Z)[R][N]) const {
+  DGP_HD void y(const double (&B)[R][N], double (&Y)[R][N]) const {
 #pragma unroll
     for (int c = 0; c < N; ++c)
 #pragma unroll
@@ -195,21 +198,25 @@ struct WbSolver {
 #pragma unroll
         for (int g = 0; g < f; ++g) v -= L[f][g] * Y[g][c];
         Y[f][c] = v;
-        Z[f][c] = dinv[f] * v;
       }
   }
+  template <int N>
+  DGP_HD void zcol(const double (&Y)[R][N], int c, double (&z)[R]) const {
+#pragma unroll
+    for (int f = 0; f < R; ++f) z[f] = dinv[f] * Y[f][c];
+  }
   DGP_HD void solve(const double (&c)[R], double (&m)[R]) const {
-    double y[R];
+    double yv[R];
 #pragma unroll
     for (int f = 0; f < R; ++f) {
       double v = c[f];
 #pragma unroll
-      for (int g = 0; g < f; ++g) v -= L[f][g] * y[g];
-      y[f] = v;
+      for (int g = 0; g < f; ++g) v -= L[f][g] * yv[g];
+      yv[f] = v;
     }
 #pragma unroll
     for (int f = R - 1; f >= 0; --f) {
-      double v = dinv[f] * y[f];
+      double v = dinv[f] * yv[f];
 #pragma unroll
       for (int g = f + 1; g < R; ++g) v -= L[g][f] * m[g];
       m[f] = v;
@@ -222,14 +229,16 @@ struct WbSolver<3> {
   template <typename OK>
   DGP_HD void factor(const Sym<3>& S, OK& ok) { sym_inverse<3>(S, M, ok); }
   template <int N>
-  DGP_HD void yz(const double (&B)[3][N], double (&Y)[3][N], double (&Z)[3][N]) const {
+  DGP_HD void y(const double (&B)[3][N], double (&Y)[3][N]) const {
 #pragma unroll
     for (int c = 0; c < N; ++c)
 #pragma unroll
-      for (int f = 0; f < 3; ++f) {
-        Y[f][c] = B[f][c];
-        Z[f][c] = M(f, 0) * B[0][c] + M(f, 1) * B[1][c] + M(f, 2) * B[2][c];
-      }
+      for (int f = 0; f < 3; ++f) Y[f][c] = B[f][c];
+  }
+  template <int N>
+  DGP_HD void zcol(const double (&Y)[3][N], int c, double (&z)[3]) const {
+#pragma unroll
+    for (int f = 0; f < 3; ++f) z[f] = M(f, 0) * Y[0][c] + M(f, 1) * Y[1][c] + M(f, 2) * Y[2][c];
   }
   DGP_HD void solve(const double (&c)[3], double (&m)[3]) const {
 #pragma unroll
@@ -237,10 +246,15 @@ struct WbSolver<3> {
   }
 };
 
-template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, typename Ctx, typename Hook>
+// `staged`: the table cells this lane still has to commit to LDS (first solve of a launch), or null.
+// COLWISE: order of the Schur assembly.  true: one column of S^-1 B at a time (no Z arrays); false: Z_p, Z_s formed up front, entries
+// row by row.  Same arithmetic; which one the compiler turns into the better d = 6 kernel depends on the surrounding program
+// (measured, B = 4096: d = 6 step 25.6 us row-wise / 26.8 us column-wise, d = 6 fused loop 34.9 / 22.2 us per iteration,
+// d = 4 step 10.08 / 9.92 us) -- the callers choose.
+template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[4][2 * DOF],
                                const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[4][2 * DOF],
-                               double (&dx)[4][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
+                               double (&dx)[4][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, const WbStaged* staged, Hook&& before_pcr) {
   constexpr int D = 2 * DOF, C = 4;
   typedef WbF<DOF> F;
   constexpr int NF = F::NF, R = F::R;
@@ -272,6 +286,8 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
     DGP_STAMP_NOWAIT(p, cx, 9);
     lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
     DGP_STAMP_NOWAIT(p, cx, 10);
+    // the table: its loads were issued before the tap loads and vector loads return in order, so the cells are here
+    if (staged) wb_stage_commit(cx, *staged);
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
@@ -382,7 +398,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   //      separator row the moment it exists: own block (Ess, es) subtracted here, the NEXT lane's (Epp', Eps', ep') fetched across
   //      lanes entry by entry -- no E block is ever live as a whole
   {
-    double Yp[R][D], Zp[R][D], Ys[R][D], Zs[R][D], yr[R][1], zr[R][1];
+    double Yp[R][D], Ys[R][D], yr[R][1];
     {
       double br[R][1], Bp[R][D], Bs[R][D];
 #pragma unroll
@@ -404,40 +420,83 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
           Bp[f][c] = sp; Bs[f][c] = ss;
         }
       }
-      sv.template yz<1>(br, yr, zr);
-      sv.template yz<D>(Bs, Ys, Zs);
-      sv.template yz<D>(Bp, Yp, Zp);
+      sv.template y<1>(br, yr);
+      sv.template y<D>(Bs, Ys);
+      sv.template y<D>(Bp, Yp);
     }
     const bool has_next = (j + 1 < LPT);
     constexpr bool kZeroFill = Nbr<LPT, 1, Ctx>::kDpp;       // a DPP row shift already yields 0 where there is no next lane
-    // Cp^T t = L_0^T t_0 = m_prev0 u_fix t_0 ;   Cs^T t = U_2^T t_2 = u_fix^T t_2
+    // right-hand sides:  Cp^T t = L_0^T t_0 = m_prev0 u_fix t_0 ;   Cs^T t = U_2^T t_2 = u_fix^T t_2
+    {
+      double zr[R];
+      sv.template zcol<1>(yr, 0, zr);
 #pragma unroll
-    for (int a = 0; a < D; ++a) {
-      double sp = 0.0, ss = 0.0;
+      for (int a = 0; a < D; ++a) {
+        double sp = 0.0, ss = 0.0;
 #pragma unroll
-      for (int q = 0; q < D; ++q) if (gp_nz<D>(a, q)) { sp += p.u_fix[a * D + q] * t[0][q]; ss += p.u_fix[q * D + a] * t[2][q]; }
-      sp *= m_prev0;
+        for (int q = 0; q < D; ++q) if (gp_nz<D>(a, q)) { sp += p.u_fix[a * D + q] * t[0][q]; ss += p.u_fix[q * D + a] * t[2][q]; }
+        sp *= m_prev0;
 #pragma unroll
-      for (int f = 0; f < R; ++f) { sp -= Yp[f][a] * zr[f][0]; ss -= Ys[f][a] * zr[f][0]; }
-      const double epn = nb.hi(sp);
-      rs[a] -= ss + ((kZeroFill || has_next) ? epn : 0.0);
+        for (int f = 0; f < R; ++f) { sp -= Yp[f][a] * zr[f]; ss -= Ys[f][a] * zr[f]; }
+        const double epn = nb.hi(sp);
+        rs[a] -= ss + ((kZeroFill || has_next) ? epn : 0.0);
+      }
+    }
+    if constexpr (COLWISE) {
+      // blocks, one COLUMN c at a time: z_p = (S^-1 B_p)_.c, z_s = (S^-1 B_s)_.c, then every entry of that column
 #pragma unroll
       for (int c = 0; c < D; ++c) {
-        const bool same = (a % DOF) == (c % DOF);
-        if (c >= a) {
-          double spp = same ? T(WB_GPP + (a / DOF) + (c / DOF)) : 0.0;      // packed 2 x 2 symmetric: (0,0) (0,1) (1,1)
-          double sss = same ? T(WB_GSS + (a / DOF) + (c / DOF)) : 0.0;
+        double zp[R], zs[R];
+        sv.template zcol<D>(Yp, c, zp);
+        sv.template zcol<D>(Ys, c, zs);
 #pragma unroll
-          for (int f = 0; f < R; ++f) { spp -= Yp[f][a] * Zp[f][c]; sss -= Ys[f][a] * Zs[f][c]; }
-          const double en = nb.hi(spp);
-          Ds(a, c) -= sss + ((kZeroFill || has_next) ? en : 0.0);
+        for (int a = 0; a < D; ++a) {
+          const bool same = (a % DOF) == (c % DOF);
+          if (a <= c) {
+            double spp = same ? T(WB_GPP + (a / DOF) + (c / DOF)) : 0.0;      // packed 2 x 2 symmetric: (0,0) (0,1) (1,1)
+            double sss = same ? T(WB_GSS + (a / DOF) + (c / DOF)) : 0.0;
+#pragma unroll
+            for (int f = 0; f < R; ++f) { spp -= Yp[f][a] * zp[f]; sss -= Ys[f][a] * zs[f]; }
+            const double en = nb.hi(spp);
+            Ds(a, c) -= sss + ((kZeroFill || has_next) ? en : 0.0);
+          }
+          double sps = same ? T(WB_GPS + (a / DOF) * 2 + (c / DOF)) : 0.0;
+#pragma unroll
+          for (int f = 0; f < R; ++f) sps -= Yp[f][a] * zs[f];
+          const double un = nb.hi(sps);
+          Us.v[a][c] = (kZeroFill || has_next) ? -un : 0.0;                    // block (s_j, s_{j+1}) = -Eps of lane j+1
         }
-        double sps = same ? T(WB_GPS + (a / DOF) * 2 + (c / DOF)) : 0.0;
-#pragma unroll
-        for (int f = 0; f < R; ++f) sps -= Yp[f][a] * Zs[f][c];
-        const double un = nb.hi(sps);
-        Us.v[a][c] = (kZeroFill || has_next) ? -un : 0.0;                    // block (s_j, s_{j+1}) = -Eps of lane j+1
+        if constexpr (kFence) { if (c % 2 == 1) sched_fence(); }
       }
+    } else {
+      double Zp[R][D], Zs[R][D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        double zp[R], zs[R];
+        sv.template zcol<D>(Yp, c, zp);
+        sv.template zcol<D>(Ys, c, zs);
+#pragma unroll
+        for (int f = 0; f < R; ++f) { Zp[f][c] = zp[f]; Zs[f][c] = zs[f]; }
+      }
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          const bool same = (a % DOF) == (c % DOF);
+          if (c >= a) {
+            double spp = same ? T(WB_GPP + (a / DOF) + (c / DOF)) : 0.0;
+            double sss = same ? T(WB_GSS + (a / DOF) + (c / DOF)) : 0.0;
+#pragma unroll
+            for (int f = 0; f < R; ++f) { spp -= Yp[f][a] * Zp[f][c]; sss -= Ys[f][a] * Zs[f][c]; }
+            const double en = nb.hi(spp);
+            Ds(a, c) -= sss + ((kZeroFill || has_next) ? en : 0.0);
+          }
+          double sps = same ? T(WB_GPS + (a / DOF) * 2 + (c / DOF)) : 0.0;
+#pragma unroll
+          for (int f = 0; f < R; ++f) sps -= Yp[f][a] * Zs[f][c];
+          const double un = nb.hi(sps);
+          Us.v[a][c] = (kZeroFill || has_next) ? -un : 0.0;
+        }
     }
   }
   DGP_STAMP_NOWAIT(p, cx, 3);

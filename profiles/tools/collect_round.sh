@@ -26,9 +26,15 @@ cp gpurun_out/pmc/report.txt "$O/pmc_counters.txt"; cp gpurun_out/pmc/traffic.js
 timeout 900 python profiles/tools/shape_sweep.py 2>/dev/null > "$O/shape_sweep.jsonl"
 timeout 600 python profiles/tools/microbench.py 2>/dev/null | grep -a '^{' > "$O/microbench.jsonl"
 U="python profiles/tools/ubench.py"
-( $U --what step,solve,eval,bwd,bwd_sdf8,bwd_sdf16; $U --what step,solve,bwd,bwd_sdf16 --covs perstate; $U --what step,solve,bwd --covs qfull; $U --what step,solve,bwd --dof 3;
+( $U --what step,solve,eval,bwd,bwd_sdf8,bwd_sdf16; DGP_NO_WOODBURY=1 $U --what step,solve,bwd --tag block_elimination; $U --what step,solve,bwd,bwd_sdf16 --covs perstate; $U --what step,solve,bwd --covs qfull; $U --what step,solve,bwd --dof 3;
+  DGP_NO_WOODBURY=1 $U --what step,solve,bwd --dof 3 --tag block_elimination; $U --what step,solve --dof 3 --covs perstate; $U --what step --B 32768; $U --what step --n 128 --B 2048; $U --what step --n 256 --B 1024;
   $U --what step --flags vel; $U --what step,bwd,bwd_sdf --sdf persample --grids 6; $U --what step --sdf persample --grids 1; $U --what bwd,bwd_sdf8,bwd_sdf16 --th 0 --tag straight_line_init;
   $U --what step,bwd --io f64 ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
+# probes: built HERE before the call (profiles/tools/build_probes.sh cross-compiles them into dgpmp2_amd/lib/, which travels with the snapshot)
 ./dgpmp2_amd/lib/atomic_probe > "$O/atomic_probe.txt" 2>&1
 ./dgpmp2_amd/lib/mfma_probe > "$O/mfma_probe.txt" 2>&1
+# in-kernel phase timeline (s_memrealtime stamps) of the headline kernel: block elimination (QK 1) and Woodbury (QK 3)
+for q in 1 3; do (echo "=== gn_kernel<2,16,4,float,STEP,QK=$q>"; ./dgpmp2_amd/lib/phase_probe_qk$q) >> "$O/phase_timeline.txt" 2>&1; done
+# randomised stress run against the C oracle (two seeds) and the emulator
+for seed in 0 1; do (timeout 900 python tests/stress_random_configs.py --seed $seed 2>&1 | grep -v amdgpu.ids | tail -4) >> "$O/stress.txt"; done
 ls -la "$O"; du -sh "$R/gpurun_out"
