@@ -185,7 +185,7 @@ class Solver(object):
     return l.value, c.value
 
   def step_kernel_variant(self, batch):
-    """Kernel variant a static-covariance step of this batch launches: 1 block elimination, 3 Woodbury interior elimination, 0 general."""
+    """Kernel variant a static-covariance step of this batch launches: 1 block elimination, 3 / 4 Woodbury interior elimination (num_states fills the shape / does not), 0 general."""
     v = self.api.step_kernel_variant(self.handle, int(batch))
     if v < 0: self.api.check(v)
     return v

@@ -84,7 +84,8 @@ inline int step_kernel_variant(const DgpHandle* h, int B) {
   p.qc_mode = dgp::QC_STATIC;
   const DgpShape sh = choose_shape(h, B);
   if (!dgp::use_static_kernels(p)) return dgp::QK_GENERAL;
-  return dgp::wb_applies(p, sh.lpt, sh.c) ? dgp::QK_WB : dgp::QK_STATIC;
+  if (!dgp::wb_applies(p, sh.lpt, sh.c)) return dgp::QK_STATIC;
+  return p.n == sh.lpt * sh.c ? dgp::QK_WB : dgp::QK_WBR;
 }
 
 // The constant blocks of a GP factor under the configured (static) Q_c_inv: Q^-1 exactly as dgp::fixed_Qinv builds it,

@@ -91,13 +91,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   // QK_WB: the adjoint solve eliminates the interior rows through the Woodbury identity (gn_woodbury.h; same matrix as the forward
   // step, the cotangent as right-hand side); everything else of this program is the static-covariance (QK_STATIC) form
   struct NoStage {};
-  typename std::conditional<QK == QK_WB, WbStaged, NoStage>::type wbv;
+  typename std::conditional<is_wb(QK), WbStaged, NoStage>::type wbv;
   const bool vec = p.vec_io != 0;
   double x[C][D], gbar[C][D], lam[C][D], mu_s[D], mu_g[D];
   load_lane_rows<DOF, C, IO>(p, p.th, b, g0, traj_ok, vec, x);
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
-  if constexpr (QK == QK_WB) wb_stage_issue(p, cx, wbv);
+  if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
 #pragma unroll
   for (int k = 0; k < C; ++k)
 #pragma unroll
@@ -109,9 +109,9 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   if (gp.g_dtheta) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     SpdCheck<Ctx> ok = {&cx, 0};
-    if constexpr (QK == QK_WB) {
+    if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, true, (D == 4)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
+      gn_linear_solve_wb<DOF, LPT, IO, true, (D == 4), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
     } else {
       gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
     }
@@ -181,7 +181,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
     if (g < n - 1) {
       Sym<D> Q;
-      if constexpr (QK == QK_STATIC || QK == QK_WB) fixed_Qinv<DOF>(p, Q);
+      if constexpr (QK == QK_STATIC || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
       else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, lq.c[k], Q);
       else Q = lq.q[k];
       double e[D], u[D], rho[D];
@@ -242,7 +242,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g-1 -> g): this row's share is +(Q_{g-1} u_{g-1} + ebar Qfix e_{g-1})
     if (g > 0) {
       Sym<D> Q;
-      if constexpr (QK == QK_STATIC || QK == QK_WB) fixed_Qinv<DOF>(p, Q);
+      if constexpr (QK == QK_STATIC || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
       else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], Q);
       else Q = (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0];
       double e[D], u[D];

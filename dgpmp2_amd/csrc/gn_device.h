@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
   constexpr int kRows = (MODE == dgp::MODE_SOLVE) ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;
   constexpr int kLds = (MODE == dgp::MODE_SOLVE) ? kRows + kStash : (kRows > kStash ? kRows : kStash);
-  constexpr int kWb = (QK == dgp::QK_WB) ? dgp::kWbLdsBytes : 0;
+  constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
   __shared__ __attribute__((aligned(16))) char lds[kLds + kWb];
   DevCtx cx;
   cx.lds_ = lds;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
-  constexpr int kWb = (QK == dgp::QK_WB) ? dgp::kWbLdsBytes : 0;
+  constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
   __shared__ __attribute__((aligned(16))) char lds[kAll + kWb];
   DevCtx cx;
   cx.lds_ = lds;
@@ -181,8 +181,13 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
     if constexpr (GROUP == GROUP_STATIC) {                                                                                 \
       if constexpr (CC == 4) {                                                                                             \
         if (dgp::wb_applies(p, L, CC)) {                                                                                   \
-          if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WB>));                 \
-          else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WB>));                                       \
+          if (p.n == L * CC) {                                                                                             \
+            if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WB>));               \
+            else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WB>));                                     \
+          } else {                                                                                                         \
+            if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WBR>));              \
+            else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WBR>));                                    \
+          }                                                                                                                \
           return hipGetLastError();                                                                                        \
         }                                                                                                                  \
       }                                                                                                                    \
@@ -199,7 +204,8 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
     } else {                                                                                                               \
       if constexpr (CC == 4) {                                                                                             \
         if (qstat && dgp::wb_applies(p, L, CC)) {                                                                          \
-          DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB>));                                                \
+          if (p.n == L * CC) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB>));                             \
+          else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WBR>));                                          \
           return hipGetLastError();                                                                                        \
         }                                                                                                                  \
       }                                                                                                                    \

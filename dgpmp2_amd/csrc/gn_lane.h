@@ -69,15 +69,22 @@ enum { FLAG_NONHOLONOMIC = 1u, FLAG_VEL_LIMITS = 2u };
 //   QK_KRON   : per-state Q_c^-1 tensors (qc_mode PERSTATE: the learned modes diag_identity / qc_full) -- Q^-1 = T (x) C_k is never
 //               formed, a row keeps the symmetric dof x dof C_k only
 //   QK_GENERAL: per-state full Q^-1 (q_full) or a non-diagonal static Q_c_inv -- a row keeps its symmetric d x d Q_k^-1
-//   QK_WB     : QK_STATIC with Q_c_inv = c I, no velocity-limit factors, C = 4 and n == LPT * C -- the three interior rows of a lane are
+//   QK_WB     : QK_STATIC with Q_c_inv = c I, no velocity-limit factors, C = 4 and n >= 4 -- the three interior rows of a lane are
 //               eliminated through the Woodbury identity on a constant interior block (gn_woodbury.h)
-enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2, QK_WB = 3 };
+//   QK_WBR    : the same for trajectory lengths that do not fill the shape (n < 4 LPT: the goal row inside a lane, lanes of padding rows);
+//               a separate instantiation because the lane-type arithmetic and the two extra table versions cost the n = 4 LPT kernel
+//               (the benchmark's) 0.25 us when they are compiled into it
+enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2, QK_WB = 3, QK_WBR = 4 };
+constexpr DGP_HD bool is_wb(int qk) { return qk == QK_WB || qk == QK_WBR; }
 
-// Layout of the QK_WB constant table (GnParams::wb_tab; doubles, per version -- 0: every lane but the first of a trajectory, 1: the first):
+// Layout of the QK_WB constant table (GnParams::wb_tab; doubles, per version -- by what the lane's three interior rows are:
+// 0 (WB_T_STD) three ordinary rows, 1 (WB_T_FIRST) rows 0..2 of a trajectory, 2 (WB_T_GOAL) the goal row n-1 among them and padding
+// rows behind it (position (n-1) mod 4: one per trajectory length), 3 (WB_T_PAD) padding rows only):
 //   K6 (6 x 6, row-major; index (k * 2 + pv) of interior row k, pv = 0 position / 1 velocity), K6 Cp (6 x 2), K6 Cs (6 x 2),
 //   Cp^T K6 Cp (packed symmetric 2 x 2 + pad), Cp^T K6 Cs (2 x 2), Cs^T K6 Cs (packed + pad)
-enum { WB_K6 = 0, WB_KCP = 36, WB_KCS = 48, WB_GPP = 60, WB_GPS = 64, WB_GSS = 68, WB_TYPE_DOUBLES = 72, WB_TYPES = 2 };
-constexpr int kWbTypeStrideBytes = WB_TYPE_DOUBLES * 8 + 16;      // LDS copy: the second version starts 16 bytes (4 banks) off a multiple of 64 banks
+enum { WB_K6 = 0, WB_KCP = 36, WB_KCS = 48, WB_GPP = 60, WB_GPS = 64, WB_GSS = 68, WB_TYPE_DOUBLES = 72, WB_TYPES = 4 };
+enum { WB_T_STD = 0, WB_T_FIRST = 1, WB_T_GOAL = 2, WB_T_PAD = 3 };
+constexpr int kWbTypeStrideBytes = WB_TYPE_DOUBLES * 8 + 16;      // LDS copy: every version starts 16 more bytes (4 banks) off a multiple of 64 banks
 constexpr int kWbLdsBytes = WB_TYPES * kWbTypeStrideBytes;
 
 // Kernel arguments (plain data, passed by value).
@@ -832,6 +839,7 @@ template <int D, int C, int QK> struct LaneQ;
 template <int D, int C> struct LaneQ<D, C, QK_GENERAL> { Sym<D> q[C]; Sym<D> qm0; };
 template <int D, int C> struct LaneQ<D, C, QK_STATIC> {};
 template <int D, int C> struct LaneQ<D, C, QK_WB> {};
+template <int D, int C> struct LaneQ<D, C, QK_WBR> {};
 template <int D, int C> struct LaneQ<D, C, QK_KRON> { Sym<D / 2> c[C]; Sym<D / 2> cm0; };      // C_k = Q_c^-1 of the factor, read as a symmetric matrix
 
 // N consecutive elements starting at src: 16-byte vector loads when `vec` (host-checked alignment) and N is a whole number of
@@ -893,6 +901,8 @@ template <int DOF, int C, typename IO>
 DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_STATIC>&) {}
 template <int DOF, int C, typename IO>
 DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_WB>&) {}
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_WBR>&) {}
 
 // per-state C = Q_c^-1 (dof x dof) of factor f, upper triangle (qc_mode PERSTATE only: p.qc is the (B, n-1, dof, dof) tensor)
 template <int DOF, typename IO>
@@ -2527,7 +2537,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 
   // constants of the Woodbury elimination (host-checked: C == 4, n == LPT * C): loads issued ahead of the th rows, committed to LDS behind them
   struct NoStage {};
-  typename std::conditional<QK == QK_WB, WbStaged, NoStage>::type wbv;
+  typename std::conditional<is_wb(QK), WbStaged, NoStage>::type wbv;
   const bool vec = p.vec_io != 0;
   double x[C][D], mu_s[D], mu_g[D];
   LaneQ<D, C, QK> lq;                           // generic covariances: Q^-1 of the lane's C + 1 GP factors, loaded once (loop-invariant in MODE_SOLVE)
@@ -2544,7 +2554,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   }
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
-  if constexpr (QK == QK_WB) wb_stage_issue(p, cx, wbv);
+  if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
   DGP_STAMP(p, cx, 1);
 
   if (MODE == MODE_EVAL) {
@@ -2587,9 +2597,9 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         if (p.err_ext) st<IO>(p.err_ext, b, div_M(p, ee));
       }
     };
-    if constexpr (QK == QK_WB) {
+    if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {

@@ -1,13 +1,14 @@
 // gn_woodbury.h -- interior elimination of a lane's three interior rows through the Woodbury identity (kernel variant QK_WB).
 //
 // Included by gn_lane.h (uses its helpers).  Applies to static covariances with Q_c_inv = c I, no velocity-limit factors, C = 4
-// states per lane and n == LPT * C (every row of every lane exists): BASELINE configs[1] and configs[3].
+// states per lane and n >= 4 (BASELINE configs[1] and configs[3]; the reference YAML's n = 101).
 //
 // A lane's interior block (rows g0 .. g0+2, unknowns y; p = separator of the previous lane, s = own separator) is
 //     Int y + Cp p + Cs s = r,      Int = K0 + sum_f w_f h_f h_f^T,
 // where K0 -- delta I + the prior / GP terms of plan_layer.py:152-200 restricted to the three rows -- is the SAME constant
-// matrix for every lane of every trajectory (two versions: the first lane of a trajectory, whose row 0 carries the start
-// prior and has no predecessor, and all others) and only the single-state factors f (obstacle, obstacle_factor.py:35-40;
+// matrix for every lane of every trajectory -- in up to four versions: ordinary rows; the first lane of a trajectory, whose row
+// 0 carries the start prior and has no predecessor; the lane that holds the goal row n-1 as an interior row (when n is not a
+// multiple of 4), padding rows behind it; lanes of padding rows only -- and only the single-state factors f (obstacle, obstacle_factor.py:35-40;
 // non-holonomic, nonholonomic_factor.py:16-30) depend on the data: ONE rank-1 term per factor and state.  With Q_c_inv = c I,
 // K0 does not couple different degrees of freedom and is identical for each: K = K0^-1 is a 6 x 6 matrix per dof
 // (3 rows x {position, velocity}), inverted once on the host (dgp_host::create).  With hh_f = sqrt(w_f) h_f:
@@ -46,16 +47,35 @@ inline void wb_fill_table(GnParams& p, int dof) {
   for (int k = 0; k < 2; ++k) { U2[0][k] = -Q2[0][k]; U2[1][k] = -(dt * Q2[0][k] + Q2[1][k]); }
   // A2 = -U2 Phi2 : col pos = -U2[:,pos], col vel = -(dt U2[:,pos] + U2[:,vel])
   for (int k = 0; k < 2; ++k) { A2[k][0] = -U2[k][0]; A2[k][1] = -(dt * U2[k][0] + U2[k][1]); }
+  const int n = p.n;
+  if (n < 4) return;                                                       // (the first lane would hold the goal row as an interior row)
   for (int type = 0; type < WB_TYPES; ++type) {
-    const bool first = (type == 1);
+    // global index g0 of the lane's first row for this version (a representative: only g == 0, g vs n-1 and g >= n matter)
+    int g0;
+    if (type == WB_T_STD) g0 = 4;                                          // (whatever n is, the CONSTANTS are those of three ordinary rows)
+    else if (type == WB_T_FIRST) g0 = 0;
+    else if (type == WB_T_GOAL) g0 = ((n - 1) / 4) * 4;                    // the lane that holds row n-1
+    else g0 = ((n + 3) / 4) * 4 + 4;                                       // beyond the trajectory
+    const bool std_rows = (type == WB_T_STD);
+    const bool first = (type == WB_T_FIRST);
+    if (type == WB_T_GOAL && ((n - 1) % 4 == 3 || g0 == 0)) continue;      // the goal row is a separator (n a multiple of 4): version unused, left zero
+    auto valid = [&](int k) { return std_rows || (g0 + k <= n - 1); };
+    auto goal = [&](int k) { return !std_rows && (g0 + k == n - 1); };
     L K0[6][6] = {};
     for (int k = 0; k < 3; ++k) {
+      const bool has_next = valid(k) && !goal(k);                          // GP factor (g -> g+1) exists: A2 on the diagonal, U2 to row k+1
+      const bool has_prev = valid(k) && !(first && k == 0);                // GP factor (g-1 -> g) exists: Q2 on the diagonal
       for (int a = 0; a < 2; ++a)
         for (int e = 0; e < 2; ++e) {
-          L v = A2[a][e] + ((first && k == 0) ? (L)0 : Q2[a][e]);           // (the factor g-1 -> g contributes Q^-1: none for row 0 of a trajectory)
-          if (a == e) v += (L)p.reg + ((first && k == 0) ? (L)p.w_s : (L)0);  // delta I (plan_layer.py:219), start prior (:64)
+          L v = 0;
+          if (!valid(k)) v = (a == e) ? (L)1 : (L)0;                        // padding row: identity (static_diag: dbase = 1)
+          else {
+            if (has_next) v += A2[a][e];
+            if (has_prev) v += Q2[a][e];
+            if (a == e) v += (L)p.reg + ((first && k == 0) ? (L)p.w_s : (L)0) + (goal(k) ? (L)p.w_g : (L)0);   // delta I (plan_layer.py:219), priors (:64-65)
+          }
           K0[2 * k + a][2 * k + e] = v;
-          if (k < 2) { K0[2 * k + a][2 * (k + 1) + e] = U2[a][e]; K0[2 * (k + 1) + e][2 * k + a] = U2[a][e]; }
+          if (k < 2 && has_next) { K0[2 * k + a][2 * (k + 1) + e] = U2[a][e]; K0[2 * (k + 1) + e][2 * k + a] = U2[a][e]; }
         }
     }
     // K = K0^-1 : Gauss-Jordan with partial pivoting in long double
@@ -80,12 +100,12 @@ inline void wb_fill_table(GnParams& p, int dof) {
     L K[6][6];
     for (int i = 0; i < 6; ++i)
       for (int k = 0; k < 6; ++k) K[i][k] = (L)0.5 * (Aug[i][6 + k] + Aug[k][6 + i]);
-    // Cp = [L_0; 0; 0] with L_0 = U2^T (none for the first lane), Cs = [0; 0; U2]
+    // Cp = [L_0; 0; 0] with L_0 = U2^T (row 0 valid and not the first row of a trajectory), Cs = [0; 0; U2] (row 2 valid and not the goal)
     L Cp[6][2] = {}, Cs[6][2] = {};
     for (int a = 0; a < 2; ++a)
       for (int e = 0; e < 2; ++e) {
-        if (!first) Cp[a][e] = U2[e][a];
-        Cs[4 + a][e] = U2[a][e];
+        if (valid(0) && !first) Cp[a][e] = U2[e][a];
+        if (valid(2) && !goal(2)) Cs[4 + a][e] = U2[a][e];
       }
     L KCp[6][2], KCs[6][2];
     for (int i = 0; i < 6; ++i)
@@ -113,36 +133,45 @@ inline void wb_fill_table(GnParams& p, int dof) {
   p.wb_ok = 1;
 }
 
-// The Woodbury kernels apply to a launch of shape (LPT, C) iff the handle's table is valid, C == 4 and every row exists.
-DGP_HD bool wb_applies(const GnParams& p, int lpt, int c) { return p.wb_ok != 0 && p.qc_mode == QC_STATIC && c == 4 && p.n == lpt * 4; }
+// The Woodbury kernels apply to a launch of shape (LPT, C) iff the handle's table is valid (which includes n >= 4) and C == 4.
+DGP_HD bool wb_applies(const GnParams& p, int lpt, int c) { return p.wb_ok != 0 && p.qc_mode == QC_STATIC && c == 4 && p.n <= lpt * 4; }
+// table version of the lane whose first row is g0 (WB_T_*): padding only / first lane / three ordinary rows / the goal row among them
+DGP_HD int wb_lane_type(int g0, int n) { return g0 >= n ? WB_T_PAD : (g0 == 0 ? WB_T_FIRST : (g0 + 3 <= n - 1 ? WB_T_STD : WB_T_GOAL)); }
 
 // ---- device / emulator ---------------------------------------------------------------------------------
-// Every wavefront copies the table from the kernel arguments into its LDS block (72 16-byte cells; the second version is
-// shifted by 16 bytes so that the two addresses a 16-lane group reads from hit different banks).  Two steps: the loads are
+// Every wavefront copies the table from the kernel arguments into its LDS block (144 16-byte cells; every version is shifted
+// by 16 more bytes so that the addresses a 16-lane group reads from -- up to four versions -- hit different banks).  Two steps: the loads are
 // ISSUED behind the start / goal rows and ahead of the SDF taps, and COMMITTED to LDS inside the first solve once the taps have
 // arrived -- vector loads return in order, so by then the table cells are there too and nothing waits for them.  (A first
 // version loaded and stored on the spot at kernel entry: two exposed kernel-argument round trips in front of everything else
-// ate the whole gain; issued at entry and committed behind the th rows they still cost 0.16 us of the load phase.)  Lane l carries cells l and 64 + (l & 7) (duplicates
-// write the same value to the same address: no branch).
-struct WbStaged { double c0 __attribute__((vector_size(16))); double c1 __attribute__((vector_size(16))); };
-template <typename Ctx>
+// ate the whole gain; issued at entry and committed behind the th rows they still cost 0.16 us of the load phase.)  Lane l carries
+// cells l, 64 + l and 128 + (l & 15) (duplicates write the same value to the same address: no branch).
+struct WbStaged { double c0 __attribute__((vector_size(16))); double c1 __attribute__((vector_size(16))); double c2 __attribute__((vector_size(16))); };
+// RAGGED = false (n = 4 LPT): only versions 0 and 1 are needed -- 72 cells, lane l carries cells l and 64 + (l & 7).
+// RAGGED = true: all four versions -- 144 cells, lane l carries cells l, 64 + l and 128 + (l & 15).
+template <bool RAGGED, typename Ctx>
 DGP_HD void wb_stage_issue(const GnParams& p, Ctx& cx, WbStaged& w) {
   typedef double V2 __attribute__((vector_size(16)));
+  static_assert(WB_TYPES * WB_TYPE_DOUBLES / 2 == 144 && WB_T_STD == 0 && WB_T_FIRST == 1, "cell-to-lane assignment");
   const V2* src = (const V2*)cx.wb_source(p);
   const int lane = cx.lane();
   w.c0 = src[lane];
-  w.c1 = src[64 + (lane & 7)];
+  if constexpr (RAGGED) { w.c1 = src[64 + lane]; w.c2 = src[128 + (lane & 15)]; }
+  else w.c1 = src[64 + (lane & 7)];
 }
-template <typename Ctx>
+template <bool RAGGED, typename Ctx>
 DGP_HD void wb_stage_commit(Ctx& cx, const WbStaged& w) {
   typedef double V2 __attribute__((vector_size(16)));
   constexpr int kCellsPerType = WB_TYPE_DOUBLES / 2;
-  static_assert(WB_TYPES * kCellsPerType == 72, "cell-to-lane assignment of wb_stage_issue");
   char* dst = cx.wb_lds();
   const int lane = cx.lane();
-  const int c1 = 64 + (lane & 7);
+  const int c1 = RAGGED ? 64 + lane : 64 + (lane & 7);
   *(V2*)(dst + (lane / kCellsPerType) * kWbTypeStrideBytes + (lane % kCellsPerType) * 16) = w.c0;
   *(V2*)(dst + (c1 / kCellsPerType) * kWbTypeStrideBytes + (c1 % kCellsPerType) * 16) = w.c1;
+  if constexpr (RAGGED) {
+    const int c2 = 128 + (lane & 15);
+    *(V2*)(dst + (c2 / kCellsPerType) * kWbTypeStrideBytes + (c2 % kCellsPerType) * 16) = w.c2;
+  }
   cx.lds_sync();
 }
 
@@ -251,7 +280,9 @@ struct WbSolver<3> {
 // row by row.  Same arithmetic; which one the compiler turns into the better d = 6 kernel depends on the surrounding program
 // (measured, B = 4096: d = 6 step 25.6 us row-wise / 26.8 us column-wise, d = 6 fused loop 34.9 / 22.2 us per iteration,
 // d = 4 step 10.08 / 9.92 us) -- the callers choose.
-template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, typename Ctx, typename Hook>
+// RAGGED: the trajectory does not fill the shape (n < 4 LPT): the lane picks one of four table versions from g0 and n; otherwise
+// (every row of every lane exists) the first lane of a trajectory reads version 1, all others version 0.
+template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, bool RAGGED, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[4][2 * DOF],
                                const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[4][2 * DOF],
                                double (&dx)[4][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, const WbStaged* staged, Hook&& before_pcr) {
@@ -287,16 +318,17 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
     lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
     DGP_STAMP_NOWAIT(p, cx, 10);
     // the table: its loads were issued before the tap loads and vector loads return in order, so the cells are here
-    if (staged) wb_stage_commit(cx, *staged);
+    if (staged) wb_stage_commit<RAGGED>(cx, *staged);
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
   constexpr bool kFence = (D == 6);      // d = 6: keep the scheduler from interleaving the phases (see sched_fence)
   if constexpr (kFence) sched_fence();
-  // this lane's version of the constants: the first lane of a trajectory / every other lane
-  const char* tb = cx.wb_lds() + ((j == 0) ? kWbTypeStrideBytes : 0);
+  // this lane's version of the constants (ordinary rows / first lane / goal row inside / padding only)
+  const char* tb = cx.wb_lds() + (RAGGED ? wb_lane_type(g0, n) : (j == 0 ? (int)WB_T_FIRST : (int)WB_T_STD)) * kWbTypeStrideBytes;
   auto T = [&](int i) -> double { return *(const double*)(tb + 8 * i); };
-  const double m_prev0 = (traj_ok && g0 > 0) ? 1.0 : 0.0;        // L_0 = m_prev0 * u_fix^T
+  const double m_prev0 = (traj_ok && g0 > 0 && (!RAGGED || g0 < n)) ? 1.0 : 0.0;        // L_0 = m_prev0 * u_fix^T
+  const double m_last2 = (!RAGGED || (traj_ok && g0 + 2 < n - 1)) ? 1.0 : 0.0;           // U_2 = m_last2 * u_fix  (row g0+2 couples to the separator)
 
   // ---- the single-state factors of the three interior states: hh_f = sqrt(w_f) h_f, ch_f = sqrt(w_f) cost_f
   double hh[R][D], ch[R];
@@ -436,6 +468,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
 #pragma unroll
         for (int q = 0; q < D; ++q) if (gp_nz<D>(a, q)) { sp += p.u_fix[a * D + q] * t[0][q]; ss += p.u_fix[q * D + a] * t[2][q]; }
         sp *= m_prev0;
+        if constexpr (RAGGED) ss *= m_last2;
 #pragma unroll
         for (int f = 0; f < R; ++f) { sp -= Yp[f][a] * zr[f]; ss -= Ys[f][a] * zr[f]; }
         const double epn = nb.hi(sp);

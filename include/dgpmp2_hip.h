@@ -110,8 +110,9 @@ int  dgp_num_factor_rows(const DgpHandle* h);
 int  dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lanes_per_trajectory, int32_t* states_per_lane);
 
 /* Kernel variant dgp_gn_step / dgp_gn_solve launch for a batch of `batch` trajectories WITH STATIC covariances (covs == NULL):
- * 1 = block elimination with the constant GP blocks as scalar operands, 3 = interior rows eliminated through the Woodbury identity
- * on the constant GP block (Q_c_inv = c I, no velocity-limit factors, num_states == 4 * lanes per trajectory; gn_woodbury.h),
+ * 1 = block elimination with the constant GP blocks as scalar operands, 3 / 4 = interior rows eliminated through the Woodbury identity
+ * on the constant GP block (Q_c_inv = c I, no velocity-limit factors, a launch shape with four states per lane; gn_woodbury.h --
+ * 3 when num_states fills the shape exactly, 4 otherwise),
  * 0 = the general kernels (non-diagonal Q_c_inv).  Per-state covariance tensors select their own kernels per call.  Reporting
  * only (bench.py names the kernel whose instruction counts it quotes); DGP_NO_WOODBURY=1 at dgp_create keeps variant 1. */
 int  dgp_step_kernel_variant(const DgpHandle* h, int32_t batch);

@@ -110,9 +110,15 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
       const int qk = dgp::kernel_variant(p);
       if constexpr (C == 4) {      // the Woodbury kernels, chosen exactly as dgp_dev::launch_typed does
         if (mode != dgp::MODE_EVAL && qk == dgp::QK_STATIC && dgp::wb_applies(p, LPT, C)) {
-          if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_WB>(p, cx);
-          else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_WB>(p, cx);
-          else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_WB>(p, *g, cx);
+          if (p.n == LPT * C) {
+            if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_WB>(p, cx);
+            else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_WB>(p, cx);
+            else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_WB>(p, *g, cx);
+          } else {
+            if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_WBR>(p, cx);
+            else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_WBR>(p, cx);
+            else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_WBR>(p, *g, cx);
+          }
           return;
         }
       }

@@ -460,7 +460,7 @@ def case_solve_with_covariances(be, golden, io):
 ALL_CASES.append(case_solve_with_covariances)
 
 
-def case_woodbury_kernels(be, golden, io, shapes=('16,4', '32,4', '64,4'), nb=3):
+def case_woodbury_kernels(be, golden, io, shapes=('16,4', '32,4', '64,4'), nb=3, ragged=True):
   """The QK_WB kernels (gn_woodbury.h: interior rows eliminated through the Woodbury identity on the constant GP block) against the
   oracle, for every shape they are built for (n == LPT * 4), both robots, static and per-state obstacle weights, the single step and the
   fused loop -- and against the block-elimination kernels on the same inputs (DGP_NO_WOODBURY=1): both within tolerance of the oracle,
@@ -469,9 +469,13 @@ def case_woodbury_kernels(be, golden, io, shapes=('16,4', '32,4', '64,4'), nb=3)
   rs = np.random.RandomState(5)
   saved = {k: os.environ.get(k) for k in ('DGP_FORCE_SHAPE', 'DGP_NO_WOODBURY')}
   try:
+    # per shape: every row present; then (ragged) the goal row as an interior row of the last lane at positions 2, 1, 0, lanes of padding rows only
+    cases = []
     for shape in shapes:
       lpt = int(shape.split(',')[0])
-      n = lpt * 4
+      ns = (lpt * 4,) if not ragged else ((lpt * 4, lpt * 4 - 1, lpt * 4 - 2, lpt * 4 - 3, lpt * 4 - 9, 5) if lpt == 16 else (lpt * 4, lpt * 4 - 6))
+      cases += [(shape, n) for n in ns]
+    for shape, n in cases:
       os.environ['DGP_FORCE_SHAPE'] = shape
       for dof, kw in ((2, {}), (2, dict(Q_c_inv=2.5 * np.eye(2), cost_sigma=0.05, K_s=0.1, reg=1e-2)),      # (reg = 1e-3 at n = 256: cond 4e7, every solver 2-3e-9 off the dense oracle)
                       (3, dict(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0 if n == 64 else 0.05)),      # reg = 0: BASELINE configs[3] (n = 64); at n = 256 cond(Lambda) > 1e7

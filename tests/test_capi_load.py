@@ -99,13 +99,15 @@ def test_launch_shape_choice(api):
 
 def test_step_kernel_variant_choice(api, monkeypatch):
   """dgp_step_kernel_variant (host logic): the Woodbury kernels (3) exactly where gn_woodbury.h applies -- Q_c_inv = c I, no velocity
-  limits, four states per lane and every row present -- the block elimination (1) elsewhere, the general kernels (0) for a
+  limits, four states per lane, at least four states (3 when the trajectory fills the shape, 4 otherwise) -- the block elimination (1) elsewhere, the general kernels (0) for a
   non-diagonal Q_c_inv; DGP_NO_WOODBURY=1 keeps the block elimination."""
   monkeypatch.delenv('DGP_NO_WOODBURY', raising=False)
   monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
   assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(4096) == 3            # BASELINE configs[1]
   assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(256) == 1             # (32,2) at small batches
-  assert _capi.Solver(_cfg(num_states=63)).step_kernel_variant(4096) == 1            # a missing row
+  assert _capi.Solver(_cfg(num_states=63)).step_kernel_variant(4096) == 4            # a missing row: the goal row is an interior row of the last lane -> the 'ragged' instantiation
+  assert _capi.Solver(_cfg(num_states=101)).step_kernel_variant(4096) == 4           # the reference YAML's length, shape (32,4)
+  assert _capi.Solver(_cfg(num_states=16)).step_kernel_variant(4096) == 1            # one state per lane
   assert _capi.Solver(_cfg(num_states=256)).step_kernel_variant(8) == 3
   assert _capi.Solver(_cfg(num_states=64, use_vel_limits=True, K_v=0.01)).step_kernel_variant(4096) == 1
   assert _capi.Solver(_cfg(num_states=64, Q_c_inv=[[1, 0], [0, 2]])).step_kernel_variant(4096) == 1
