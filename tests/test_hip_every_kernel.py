@@ -1,7 +1,8 @@
-"""GPU (-m gpu): EVERY forward kernel instantiation of the library -- 2 robots x 2 I/O types x 9 launch shapes x 4 covariance
+"""GPU (-m gpu): EVERY kernel instantiation of the library.  Forward: -- 2 robots x 2 I/O types x 9 launch shapes x 4 covariance
 representations (static diagonal Q_c_inv: block elimination or Woodbury; static non-diagonal: general; per-state tensors: Kronecker;
 q_full: general) x {single step, fused loop} -- on a small batch against oracle/gn_blocktri.c, with the trajectory length that fills
-the shape exactly (n = LPT * C: full-line row I/O, the Woodbury kernels) and a ragged one (padding rows, scalar row I/O).
+the shape exactly (n = LPT * C: full-line row I/O, the exact-fit Woodbury kernels) and a ragged one (padding rows, scalar row I/O, the
+ragged Woodbury kernels).  Backward: every instantiation against the CPU wavefront emulator (second test).
 
 Why this exists: hipcc 7.0 has miscompiled several of the largest d = 6 kernels (wrong results or wild stores, while the same source
 is exact on the CPU wavefront emulator and in every other instantiation).  Which instantiation breaks changes with
@@ -84,3 +85,36 @@ def test_hip_every_forward_kernel_vs_c_oracle(be, dof, io, monkeypatch):
         es = PC.rel_err(tho, cur) if np.all(np.isfinite(tho)) else np.inf
         if not (es < (1e-7 if io == 'f64' else 1e-5) and not sinfo.any() and np.all(its == 3)): bad.append((tag, 'fused loop', es))
   assert not bad, '%d kernel instantiations differ from the C oracle:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_backward_kernel_vs_emulator(be, dof, io, monkeypatch):
+  """Every BACKWARD kernel instantiation (2 robots x 2 I/O types x 9 shapes x static [block elimination / Woodbury, exact fit and ragged] /
+  general / per-state) against the CPU wavefront emulator -- the same lane program compiled for the host -- on one small batch each, every
+  gradient tensor.  (The emulator's backward is itself pinned to the reference's autograd fixture and to finite differences of the oracle.)"""
+  emul = harness.Backend('emul')
+  rs = np.random.RandomState(200 * dof + (io == 'f32'))
+  bad = []
+  for lpt, c in SHAPES:
+    monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+    for cov, n in (('static', lpt * c), ('static', max(4, lpt * c - 2)), ('static_full', lpt * c), ('perstate', lpt * c - 1), ('qfull', lpt * c)):
+      B = 2
+      p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, cov, io)
+      d = 2 * dof
+      kw = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
+      dth = be.step(p, th, start, goal, sdf, **kw)[0]
+      gbar = PC.rnd(rs.randn(B, n, d), io); gext = PC.rnd(rs.randn(B), io)
+      copies = 16 if (lpt + c) % 3 == 0 else 1
+      g_h = be.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, **kw)
+      g_e = emul.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, **kw)
+      tag = 'dof %d %s shape (%d,%d) n %d cov %s' % (dof, io, lpt, c, n, cov)
+      for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
+        if g_h[key] is None: continue
+        if key == 'sdf' and io == 'f32': continue      # accumulated in fp32 in memory by atomics: order-dependent cancellation noise, not a code-generation signal
+        a_, b_ = g_h[key], g_e[key]
+        if key == 'sdf' and copies > 1: a_, b_ = a_.sum(0), b_.sum(0)
+        if not np.all(np.isfinite(a_)): bad.append((tag, key, 'non-finite')); continue
+        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(g_e['th']).max() if key == 'sdf' else 0.0, 1e-300)
+        if not eb < (1e-6 if io == 'f64' else 3e-4): bad.append((tag, key, eb))
+  assert not bad, '%d backward results differ from the emulator:\n' % len(bad) + '\n'.join(map(str, bad))
