@@ -14,6 +14,9 @@
 #pragma once
 #include "gn_lane.h"
 
+#ifndef DGP_BWD_COLWISE
+#define DGP_BWD_COLWISE(D) true      // order of the Woodbury Schur assembly in the adjoint solve (see gn_linear_solve_wb): column-wise for both robots (d = 6 backward 47.8 -> 40.2 us); tuning aid
+#endif
 namespace dgp {
 
 enum { kMaxXcds = 8 };               // XCDs (each with its own, mutually non-coherent L2) on a gfx950 device
@@ -111,7 +114,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     SpdCheck<Ctx> ok = {&cx, 0};
     if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, true, (D == 4), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
+      gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
     } else {
       gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
     }
