@@ -16,7 +16,7 @@ DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64 = 0, 1
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
-DGP_ABI_VERSION = 2
+DGP_ABI_VERSION = 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
@@ -49,7 +49,7 @@ class CApi(object):
   """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
-             'eval_errors', 'gn_step_backward', 'time_next_launch')
+             'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -76,7 +76,13 @@ class CApi(object):
     self.gn_step_backward = f('gn_step_backward'); self.gn_step_backward.restype = C.c_int
     self.gn_step_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, i64,
                                       i32, vp, vp, vp, vp]
+    self.eval_errors_backward = f('eval_errors_backward'); self.eval_errors_backward.restype = C.c_int
+    self.eval_errors_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
     self.time_next_launch = f('time_next_launch'); self.time_next_launch.restype = C.c_int; self.time_next_launch.argtypes = [vp, vp]
+    self.event_create = f('event_create'); self.event_create.restype = C.c_int; self.event_create.argtypes = [C.POINTER(vp)]
+    self.event_destroy = f('event_destroy'); self.event_destroy.restype = None; self.event_destroy.argtypes = [vp]
+    self.event_elapsed_ms = f('event_elapsed_ms'); self.event_elapsed_ms.restype = C.c_int
+    self.event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
     v = self.abi_version()
     if v != DGP_ABI_VERSION:
       raise ImportError('%s: ABI version %d, binding expects %d' % (path, v, DGP_ABI_VERSION))
@@ -87,21 +93,18 @@ class CApi(object):
 
 
 class KernelTimer(object):
-  """Per-kernel execution times through dgp_time_next_launch: a pool of HIP event pairs (created through the HIP runtime torch
-  has already loaded); `arm()` before a launch makes that launch record its own begin / end, `durations_ms()` reads them back
-  after a synchronisation.  Measurement aid for bench.py and the profiling tools -- not used by the planner."""
+  """Per-kernel execution times through dgp_time_next_launch: a pool of HIP event pairs, created and read through the library's own
+  dgp_event_* helpers (i.e. the HIP runtime the kernels are launched with); `arm()` before a launch makes that launch record its own
+  begin / end, `durations_ms()` reads them back after a synchronisation.  Measurement aid for bench.py and the profiling tools --
+  not used by the planner."""
 
   def __init__(self, n, api=None):
     self.api = api if api is not None else get_api()
-    self.hip = C.CDLL('libamdhip64.so')
-    self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
-    self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
-    self.hip.hipEventDestroy.argtypes = [C.c_void_p]
     self.pairs = []
     for _ in range(n):
       a, b = C.c_void_p(), C.c_void_p()
-      if self.hip.hipEventCreate(C.byref(a)) != 0 or self.hip.hipEventCreate(C.byref(b)) != 0:
-        raise RuntimeError('hipEventCreate failed')
+      self.api.check(self.api.event_create(C.byref(a)))
+      self.api.check(self.api.event_create(C.byref(b)))
       self.pairs.append((a, b))
     self.used = 0
 
@@ -116,14 +119,13 @@ class KernelTimer(object):
     out = []
     for a, b in self.pairs[:self.used]:
       ms = C.c_float()
-      rc = self.hip.hipEventElapsedTime(C.byref(ms), a, b)
-      if rc != 0: raise RuntimeError('hipEventElapsedTime failed (%d): synchronise before reading' % rc)
+      self.api.check(self.api.event_elapsed_ms(a, b, C.byref(ms)))
       out.append(ms.value)
     return out
 
   def __del__(self):
     for a, b in getattr(self, 'pairs', []):
-      self.hip.hipEventDestroy(a); self.hip.hipEventDestroy(b)
+      self.api.event_destroy(a); self.api.event_destroy(b)
     self.pairs = []
 
 
@@ -218,3 +220,9 @@ class Solver(object):
     self.api.check(self.api.gn_step_backward(self.handle, batch, th, start, goal, C.byref(sdf),
                                              C.byref(covs) if covs is not None else None, dtheta, g_dtheta, g_err_ext, g_th, g_start,
                                              g_goal, g_sdf, int(g_sdf_batch_stride), int(g_sdf_copies), g_qc_inv, g_obs_w, g_eps, stream))
+
+  def eval_errors_backward(self, batch, th, start, goal, sdf, covs, g_err_ext=None, g_unw_sg=None, g_unw_gp=None, g_unw_obs=None,
+                           g_th=None, g_start=None, g_goal=None, g_sdf=None, g_sdf_batch_stride=0, g_eps=None, stream=None, g_sdf_copies=1):
+    self.api.check(self.api.eval_errors_backward(self.handle, batch, th, start, goal, C.byref(sdf),
+                                                 C.byref(covs) if covs is not None else None, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs,
+                                                 g_th, g_start, g_goal, g_sdf, int(g_sdf_batch_stride), int(g_sdf_copies), g_eps, stream))

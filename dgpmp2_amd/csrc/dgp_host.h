@@ -262,8 +262,36 @@ inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   if (g_dtheta && !dtheta) return fail(DGP_EINVAL, "dtheta (the forward output) is needed with a g_dtheta cotangent");
   if (g_qc_inv && p.qc_mode == DGP_QC_STATIC) return fail(DGP_EINVAL, "g_qc_inv given but qc_mode is DGP_QC_STATIC");
   g.dtheta = dtheta; g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
+  g.g_unw_sg = g.g_unw_gp = g.g_unw_obs = nullptr;
   g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
   p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(g_th)) ? 1 : 0;
+  return DGP_OK;
+}
+
+// dgp_eval_errors_backward: the backward kernels without the adjoint solve (no dtheta cotangent).  Only eps of the covariance
+// inputs enters err_ext / the unweighted errors (fixed GP / obstacle weights, plan_layer.py:318,330; unit weights, :374-388), so the
+// static-covariance kernel is launched whatever qc_mode the caller's covs carry.
+inline int fill_eval_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                              const DgpCovs* covs, const void* g_err_ext, const void* g_unw_sg, const void* g_unw_gp, const void* g_unw_obs,
+                              void* g_th, void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                              void* g_eps, dgp::GnParams& p, dgp::GnGradParams& g) {
+  const bool no_grid = !sdf || !sdf->data;
+  if (no_grid && (g_err_ext || g_unw_obs || g_sdf))
+    return fail(DGP_EINVAL, "sdf may be NULL only when g_err_ext, g_unw_obs and g_sdf (what reads / writes the grid) are NULL");
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
+  if (covs && (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_QFULL)) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+  int rc = fill_call(h, batch, th, start, goal, sdf, &c, p, /*sdf_optional=*/true);
+  if (rc != DGP_OK) return rc;
+  if (no_grid) p.sdf = nullptr;
+  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
+  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
+  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
+  if (g_eps && !c.eps) return fail(DGP_EINVAL, "g_eps given but covs->eps is NULL (static epsilon)");
+  g.dtheta = nullptr; g.g_dtheta = nullptr; g.g_err_ext = g_err_ext;
+  g.g_unw_sg = g_unw_sg; g.g_unw_gp = g_unw_gp; g.g_unw_obs = g_unw_obs;
+  g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
+  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = g_eps;
+  p.vec_io = (aligned16(th) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
 }
 

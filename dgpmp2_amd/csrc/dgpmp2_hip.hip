@@ -9,6 +9,13 @@ namespace {
 
 using dgp_host::fail;
 
+// a call that fails validation launches nothing: a pending dgp_time_next_launch request must not attach to an unrelated later launch
+int drop_events(int rc) {
+  dgp_host::LaunchEvents& le = dgp_host::launch_events();
+  le.start = le.stop = nullptr;
+  return rc;
+}
+
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const DgpShape sh = dgp_host::choose_shape(h, p.B);
   // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
@@ -55,7 +62,7 @@ int dgp_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* s
                 const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void* stream) {
   dgp::GnParams p;
   int rc = dgp_host::fill_step(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, p);
-  if (rc != DGP_OK) return rc;
+  if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_STEP, p, nullptr, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step launch failed: %s", hipGetErrorString(e));
   return DGP_OK;
@@ -67,7 +74,7 @@ int dgp_gn_solve(const DgpHandle* h, int32_t batch, const void* th_init, const v
   dgp::GnParams p;
   int rc = dgp_host::fill_solve(h, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist,
                                 errext_hist, err_final, info, p);
-  if (rc != DGP_OK) return rc;
+  if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_SOLVE, p, nullptr, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_solve launch failed: %s", hipGetErrorString(e));
   return DGP_OK;
@@ -77,7 +84,7 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const voi
                     const DgpCovs* covs, void* err, void* err_ext, void* unw_sg, void* unw_gp, void* unw_obs, void* stream) {
   dgp::GnParams p;
   int rc = dgp_host::fill_eval(h, batch, th, start, goal, sdf, covs, err, err_ext, unw_sg, unw_gp, unw_obs, p);
-  if (rc != DGP_OK) return rc;
+  if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_EVAL, p, nullptr, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_eval_errors launch failed: %s", hipGetErrorString(e));
   return DGP_OK;
@@ -91,9 +98,41 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   dgp::GnGradParams g;
   int rc = dgp_host::fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf,
                                    g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
-  if (rc != DGP_OK) return rc;
+  if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step_backward launch failed: %s", hipGetErrorString(e));
+  return DGP_OK;
+}
+
+int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                             const DgpCovs* covs, const void* g_err_ext, const void* g_unw_sg, const void* g_unw_gp, const void* g_unw_obs,
+                             void* g_th, void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                             void* g_eps, void* stream) {
+  dgp::GnParams p;
+  dgp::GnGradParams g;
+  int rc = dgp_host::fill_eval_backward(h, batch, th, start, goal, sdf, covs, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start, g_goal,
+                                        g_sdf, g_sdf_batch_stride, g_sdf_copies, g_eps, p, g);
+  if (rc != DGP_OK) return drop_events(rc);
+  hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_eval_errors_backward launch failed: %s", hipGetErrorString(e));
+  return DGP_OK;
+}
+
+// Event helpers for dgp_time_next_launch: created / read through the HIP runtime THIS library is linked against (an event made by
+// another copy of the runtime in the process is not portable to it).
+int dgp_event_create(void** out) {
+  if (!out) return fail(DGP_EINVAL, "null argument");
+  hipEvent_t ev;
+  hipError_t e = hipEventCreate(&ev);
+  if (e != hipSuccess) return fail(DGP_EHIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+  *out = (void*)ev;
+  return DGP_OK;
+}
+void dgp_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); }
+int dgp_event_elapsed_ms(void* start_event, void* stop_event, float* ms) {
+  if (!start_event || !stop_event || !ms) return fail(DGP_EINVAL, "null argument");
+  hipError_t e = hipEventElapsedTime(ms, (hipEvent_t)start_event, (hipEvent_t)stop_event);
+  if (e != hipSuccess) return fail(DGP_EHIP, "hipEventElapsedTime failed (synchronise first): %s", hipGetErrorString(e));
   return DGP_OK;
 }
 

@@ -24,6 +24,7 @@ enum { kMaxXcds = 8 };               // XCDs (each with its own, mutually non-co
 struct GnGradParams {
   const void *dtheta;                 // dtheta of the forward pass (B,n,d)
   const void *g_dtheta, *g_err_ext;   // cotangents; either may be null (= 0)
+  const void *g_unw_sg, *g_unw_gp, *g_unw_obs;   // (B) cotangents of the unweighted errors (plan_layer.py:374-388; dgp_eval_errors_backward), null = 0
   void *g_th, *g_start, *g_goal, *g_sdf, *g_qc, *g_obs_w, *g_eps;
   int64_t g_sdf_bstride;
   int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
@@ -55,7 +56,7 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
   if (gp.g_sdf_copies > 1) {
     const int xcc = cx.xcc_id();
     const int per_xcd = gp.g_sdf_copies / kMaxXcds;
-    const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? xcc + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;
+    const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? (xcc % kMaxXcds) + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;      // (XCC_ID is a 4-bit field: never index past the copies)
     base += (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
   }
   E* l = (E*)cx.lds();
@@ -120,6 +121,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
   }
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
+  // cotangents of the unweighted errors (dgp_eval_errors_backward): start_goal_error = 1/2 |mu_s - x_0|^2 + 1/2 |mu_g - x_{n-1}|^2
+  // (plan_layer.py:384-388), gp_error = mean over the n-1 factors of 1/2 |e|^2 (:374-377), obs_error = mean over the n states of
+  // 1/2 c^2 (:379-382) -- each the err_ext term of the same factor with the weight replaced by 1 (x the mean's 1/count)
+  const double gsg = (traj_ok && gp.g_unw_sg) ? ld<IO>(gp.g_unw_sg, b) : 0.0;
+  const double ggp = (traj_ok && gp.g_unw_gp) ? ld<IO>(gp.g_unw_gp, b) / (double)(n - 1) : 0.0;
+  const double gob = (traj_ok && gp.g_unw_obs) ? ld<IO>(gp.g_unw_obs, b) / (double)n : 0.0;
+  const bool has_grid = p.sdf != nullptr;      // wave-uniform; no grid (host-checked: nothing that reads it was requested): no obstacle factors
 
   // states / adjoints across the lane boundaries
   double x_prev[D], x_next[D], lam_prev[D], lam_next[D];
@@ -142,7 +150,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
   for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
   LaneTaps<C, IO> taps;
-  lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
+  if (has_grid) lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
   // SDF-gradient contributions of the lane's states: element offset inside the grid (-1: none -- hinge inactive or no such
   // row) and value for the four taps (x1,y1), (x2,y1), (x1,y2), (x2,y2)
   int32_t tap_i[C][4];
@@ -176,7 +184,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double ea = (is_start ? mu_s[a] : mu_g[a]) - xk[a];
-        const double t = w * (lk[a] + ebar * ea);
+        const double t = w * (lk[a] + ebar * ea) + gsg * ea;
         gx[a] -= t;
         if (gmu) st<IO>(gmu, b * D + a, t);
       }
@@ -204,7 +212,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
-        t[a] = s;
+        t[a] = s + ggp * e[a];
       }
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {
@@ -261,11 +269,14 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         double s = 0.0;
 #pragma unroll
         for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
-        gx[a] += s;
+        gx[a] += s + ggp * e[a];
       }
     }
     // ---- obstacle factor: e = c, H = [hx, hy, 0..], K = omega
-    {
+    if (!has_grid) {
+      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, 0.0);
+      if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, 0.0);
+    } else {
       const double w = taps.ow[k];
       double c, hx, hy;
       ObsTaps tp;
@@ -278,7 +289,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         const double rho = c - (hx * dth[0] + hy * dth[1]);
         const double al = w * (rho * lk[0] - u * dth[0]);        // coefficient of d hx
         const double be = w * (rho * lk[1] - u * dth[1]);        // coefficient of d hy
-        const double ga = u * w + ebar * p.obs_w_fix * c;        // coefficient of d c  (c = eps + r - dist)
+        const double ga = u * w + (ebar * p.obs_w_fix + gob) * c;      // coefficient of d c  (c = eps + r - dist)
         const double ir = 1.0 / p.res;
         // hx = (wja (d21-d11) + wjb (d22-d12)) / res ; hy = -(wjc (d12-d11) + wjd (d22-d21)) / res ; px = ox + x/res ; py = oy - y/res
         gx[0] += be * (-tp.cross * ir * ir) - ga * hx;

@@ -157,6 +157,57 @@ class _GNStep(torch.autograd.Function):
     return (None, None, g_th, g_st, g_go, r(g_sdf, sdf) if g_sdf is not None else None, r(g_qc, qc), r(g_ow, ow), r(g_eps, eps))
 
 
+class _EvalErrors(torch.autograd.Function):
+  """err_ext, start_goal_error, gp_error, obs_error at a trajectory = one launch of dgp_eval_errors; backward = one launch of
+  dgp_eval_errors_backward.  These are the quantities the reference's training loss differentiates besides dtheta
+  (learning/train_planner.py:327,342 -> one_step_loss :75-120): plain torch ops there (plan_layer.py:310-345, :374-388), hence
+  differentiable w.r.t. thb, sdfb, the start / goal means and the current eps (all remembered WITH their graphs by the last
+  forward(), plan_layer.py:88-94).  None of them depends on qc_inv / obscov_inv (fixed or unit weights)."""
+
+  @staticmethod
+  def forward(ctx, layer, th, start, goal, sdf, eps):
+    eps_arg = None if (eps is None or getattr(eps, '_dgp_static', False)) else eps
+    o = layer._eval(th, sdf, start, goal, None, None, eps_arg)
+    ctx.layer = layer
+    ctx.has_eps = eps_arg is not None
+    ctx.save_for_backward(th, start, goal, sdf, eps_arg)
+    ctx.set_materialize_grads(False)
+    return o[1], o[2], o[3], o[4]            # (the three that read the grid are None without one)
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, g_eex, g_usg, g_ugp, g_uobs):
+    layer = ctx.layer
+    th, start, goal, sdf, eps = ctx.saved_tensors
+    B, n, d = th.shape
+    solver = layer._solver(th.dtype)
+    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
+    covs, cov_keep = layer._covs_arg(solver, None, None, eps, th.dtype, B, (True, True, eps is None))
+    need = ctx.needs_input_grad                       # (layer, th, start, goal, sdf, eps)
+    cot = [None if g is None else g.contiguous().to(th.dtype) for g in (g_eex, g_usg, g_ugp, g_uobs)]
+    thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
+    mk = lambda ref, on: torch.empty_like(ref, memory_format=torch.contiguous_format) if on else None
+    g_th, g_st, g_go = mk(thc, need[1]), mk(stc, need[2]), mk(goc, need[3])
+    g_sdf, shared, copies = None, True, 1
+    if sdf is not None:
+      shared = sdf.stride(0) == 0 or sdf.shape[0] == 1
+      copies = _SDF_GRAD_COPIES if shared else 1
+      if need[4]:
+        g_sdf = torch.zeros((copies if shared else B, 1) + tuple(sdf.shape[-2:]), dtype=th.dtype, device=th.device)
+    g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[5] and eps is not None) else None
+    p = lambda t: None if t is None else t.data_ptr()
+    with _on_device(th.device):
+      solver.eval_errors_backward(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, p(cot[0]), p(cot[1]), p(cot[2]), p(cot[3]),
+                                  p(g_th), p(g_st), p(g_go), p(g_sdf), 0 if (sdf is None or shared) else sdf.shape[-1] * sdf.shape[-2], p(g_eps),
+                                  _stream(), g_sdf_copies=copies)
+    if g_sdf is not None and shared:
+      g_sdf = g_sdf.sum(0, keepdim=True)
+      if sdf.shape[0] != 1:                           # expand()ed view: autograd sums the B slices of what is returned (see _GNStep.backward)
+        g_sdf = (g_sdf / sdf.shape[0]).expand(sdf.shape)
+    r = lambda g, ref: None if g is None else g.reshape(ref.shape).to(ref.dtype)
+    return (None, g_th, r(g_st, start), r(g_go, goal), r(g_sdf, sdf) if g_sdf is not None else None, r(g_eps, eps) if g_eps is not None else None)
+
+
 class PlanLayer(nn.Module):
   """See module docstring.  Constructor mirrors plan_layer.py:14."""
 
@@ -277,9 +328,11 @@ class PlanLayer(nn.Module):
     self._check_inputs(thb, startb, goalb)
     # like the reference (plan_layer.py:88-94) remember means / covariances for the error_* helpers below
     static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+    # (start / goal / eps are kept WITH their graphs, as set_mean / set_eps do: error_ext_batch and the unweighted errors are
+    #  differentiable w.r.t. them; qc_inv / obscov_inv only feed error_batch, which runs under no_grad, :275)
     det = lambda t, st: None if (t is None or st) else t.detach()
-    object.__setattr__(self, '_last', (startb.detach(), goalb.detach(), det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
-                                       det(eps_trajb, static[2])))
+    object.__setattr__(self, '_last', (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
+                                       None if (eps_trajb is None or static[2]) else eps_trajb))
     needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad
                                                   for t in (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb))
     if not needs_graph:        # planning / validation loops: no autograd node, one launch
@@ -295,7 +348,7 @@ class PlanLayer(nn.Module):
     covs, k2 = self._covs_arg(solver, qc, ow, eps, thb.dtype, B, self.static_flags(qc, ow, eps))
     want = [sdfb is not None, sdfb is not None, True, True, sdfb is not None]
     outs = [torch.empty(B, 1, 1, dtype=thb.dtype, device=thb.device) if w else None for w in want]
-    thc, stc, goc = thb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
+    thc, stc, goc = thb.contiguous(), startb.contiguous(), goalb.contiguous()
     with _on_device(thb.device):
       solver.eval_errors(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, *[None if o is None else o.data_ptr() for o in outs],
                          stream=_stream())
@@ -319,31 +372,37 @@ class PlanLayer(nn.Module):
     with torch.no_grad():
       return self._eval(thb, sdfb, st, go, qc, ow, eps)[0]
 
+  def _eval_diff(self, thb, sdfb, st, go, eps):
+    """(err_ext, start_goal_error, gp_error, obs_error) at thb, each (B,1,1) (None where a grid is needed and sdfb is None), carrying
+    the autograd graph the reference's plain torch ops would carry: w.r.t. thb, sdfb, the start / goal means and the current eps."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (thb, sdfb, st, go, eps)):
+      return _EvalErrors.apply(self, thb, st, go, sdfb, eps)
+    o = self._eval(thb, sdfb, st, go, None, None, eps)
+    return o[1], o[2], o[3], o[4]
+
   def error_ext_batch(self, thb, sdfb):
-    """plan_layer.py:310-345: same with the FIXED GP / obstacle weights and the current eps.  Differentiable w.r.t.
-    thb and sdfb (through dgp_gn_step_backward with a zero dtheta cotangent)."""
+    """plan_layer.py:310-345: same with the FIXED GP / obstacle weights and the current eps.  Differentiable w.r.t. thb, sdfb, the
+    start / goal means and the eps tensor of the last forward()."""
     st, go, qc, ow, eps = self._last_or_raise()
-    if torch.is_grad_enabled() and (thb.requires_grad or sdfb.requires_grad):
-      return _GNStep.apply(self, self.static_flags(qc, ow, eps), thb, st, go, sdfb, qc, ow, eps)[2]
-    return self._eval(thb, sdfb, st, go, qc, ow, eps)[1]
+    return self._eval_diff(thb, sdfb, st, go, eps)[0]
 
   def start_goal_error(self, thb):
-    """plan_layer.py:384-388 (unweighted)."""
+    """plan_layer.py:384-388 (unweighted; (B,1): the reference's mean(dim=1) drops one of the two singleton dimensions)."""
     st, go, qc, ow, eps = self._last_or_raise()
-    return self._eval(thb, None, st, go, None, None, None)[2]
+    return self._eval_diff(thb, None, st, go, None)[1].reshape(thb.shape[0], 1)
 
   def gp_error(self, thb):
     """plan_layer.py:374-377 (unweighted, mean over the GP factors)."""
     st, go, qc, ow, eps = self._last_or_raise()
-    return self._eval(thb, None, st, go, None, None, None)[3]
+    return self._eval_diff(thb, None, st, go, None)[2]
 
   def obs_error(self, thb, sdfb):
     """plan_layer.py:379-382 (unweighted, mean over states; uses the eps of the last forward())."""
     st, go, qc, ow, eps = self._last_or_raise()
-    return self._eval(thb, sdfb, st, go, None, None, eps)[4]
+    return self._eval_diff(thb, sdfb, st, go, eps)[3]
 
   def unweighted_errors(self, thb, sdfb):
-    """(start_goal_error, gp_error, obs_error) in one launch."""
+    """(start_goal_error (B,1), gp_error (B,1,1), obs_error (B,1,1)) in one launch (and one backward launch)."""
     st, go, qc, ow, eps = self._last_or_raise()
-    o = self._eval(thb, sdfb, st, go, None, None, eps)
-    return o[2], o[3], o[4]
+    o = self._eval_diff(thb, sdfb, st, go, eps)
+    return o[1].reshape(thb.shape[0], 1), o[2], o[3]

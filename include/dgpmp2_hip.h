@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGP_ABI_VERSION 2
+#define DGP_ABI_VERSION 3
 
 /* status codes */
 #define DGP_OK              0
@@ -173,12 +173,33 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                          void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);
 
+/* Backward of dgp_eval_errors == torch autograd through PlanLayer.error_ext_batch (plan_layer.py:310-345) and the unweighted errors
+ * gp_error / obs_error / start_goal_error (:374-388), which the reference's training loss differentiates
+ * (learning/train_planner.py:327,342 -> one_step_loss :75-120 -> final_loss.backward() :366-374).
+ * Cotangents g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs: (B), any may be NULL (= 0).  Writes dL/d{th,start,goal} (same shapes as the
+ * inputs), dL/d(eps) (B,n; only with covs->eps, the current epsilons of plan_layer.py:94,329) and ACCUMULATES dL/d(sdf) into g_sdf
+ * (layout and partial copies exactly as in dgp_gn_step_backward; the caller zeroes it).  NULL outputs are skipped.  err (error_batch)
+ * runs under no_grad in the reference (:275) and has no cotangent; none of these errors depends on qc_inv / obs_w (fixed or unit
+ * weights), so covs->qc_inv and covs->obs_w are ignored.  `sdf` (or sdf->data) may be NULL when g_err_ext, g_unw_obs and g_sdf are. */
+int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch,
+                             const void* th, const void* start, const void* goal,
+                             const DgpSdf* sdf, const DgpCovs* covs,
+                             const void* g_err_ext, const void* g_unw_sg, const void* g_unw_gp, const void* g_unw_obs,
+                             void* g_th, void* g_start, void* g_goal,
+                             void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                             void* g_eps, void* stream);
+
 /* Measurement aid (no counterpart in the reference): the NEXT kernel launched by the calling thread through any entry point
  * above records its own begin and end on the two HIP events (hipEvent_t, created with timing enabled, cast to void*), the way
  * hipExtLaunchKernelGGL does -- hipEventElapsedTime(start, stop) is then that kernel's execution time, the quantity
  * rocprofv3 --kernel-trace reports, with no marker packets between back-to-back launches.  One-shot: consumed by that launch.
  * Passing NULL for either event cancels a pending request. */
 int dgp_time_next_launch(void* start_event, void* stop_event);
+/* Events for dgp_time_next_launch, created and read through the HIP runtime this library is linked against (hipEvent_t as void*);
+ * dgp_event_elapsed_ms needs both events completed (synchronise the stream first). */
+int  dgp_event_create(void** out_event);
+void dgp_event_destroy(void* event);
+int  dgp_event_elapsed_ms(void* start_event, void* stop_event, float* ms);
 
 #ifdef __cplusplus
 }

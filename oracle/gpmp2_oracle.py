@@ -351,8 +351,8 @@ def unweighted_errors_batch(thb, startb, goalb, sdfb, epsb, p):
   B, n, d = thb.shape
   e_p, _ = prior_error(startb.reshape(B, d), thb[:, 0])
   e_g, _ = prior_error(goalb.reshape(B, d), thb[:, n - 1])
-  # torch.mean(..., dim=1) over a (B,1,1) tensor: identity
-  err_sg = (0.5 * np.sum(e_p * e_p, axis=1) + 0.5 * np.sum(e_g * e_g, axis=1)).reshape(B, 1, 1)
+  # torch.mean(..., dim=1) over a (B,1,1) tensor: the values unchanged, shape (B,1) (plan_layer.py:387)
+  err_sg = (0.5 * np.sum(e_p * e_p, axis=1) + 0.5 * np.sum(e_g * e_g, axis=1)).reshape(B, 1)
   e_gp, _, _ = gp_factor_error(thb, p.dof, p.dt)
   err_gp = np.mean(0.5 * np.sum(e_gp[..., 0] ** 2, axis=-1), axis=1).reshape(B, 1, 1)
   e_o, _ = obstacle_error(thb, sdfb, epsb, p)

@@ -231,4 +231,21 @@ int emul_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, con
   return DGP_OK;
 }
 
+int emul_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                              const DgpCovs* covs, const void* g_err_ext, const void* g_unw_sg, const void* g_unw_gp, const void* g_unw_obs,
+                              void* g_th, void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                              void* g_eps, void*) {
+  dgp::GnParams p;
+  dgp::GnGradParams g;
+  int rc = dgp_host::fill_eval_backward(h, batch, th, start, goal, sdf, covs, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start, g_goal,
+                                        g_sdf, g_sdf_batch_stride, g_sdf_copies, g_eps, p, g);
+  if (rc != DGP_OK) return rc;
+  run(h, p, &g, 3);
+  return DGP_OK;
+}
+
+int emul_event_create(void** out) { if (out) *out = nullptr; return DGP_OK; }      // nothing to time on the host
+void emul_event_destroy(void*) {}
+int emul_event_elapsed_ms(void*, void*, float* ms) { if (ms) *ms = 0.0f; return DGP_OK; }
+
 }  // extern "C"

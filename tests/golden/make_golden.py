@@ -492,5 +492,103 @@ def g6_dataset():
   save('g6_dataset', **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# G7: autograd through the errors the reference's TRAINING LOSS differentiates besides dtheta:
+#   unweighted_errors_batch (diff_gpmp2_planner.py:229-237 -> plan_layer.py:374-388) and error_ext_batch (:310-345), evaluated at
+#   th + dtheta (learning/train_planner.py:313,327), with start / goal / eps remembered WITH their graphs by forward() (:88-94).
+#   g7_errors: plan_layer-level, every leaf learnable (incl. eps);  g7_tbptt: one batch of train() (train_planner.py:258-410, restated
+#   in tests/tbptt_loop.py) through planner.step() with learn modules -- stubs injected in place of LearnModuleConv / LearnModuleFCN
+#   (the latter cannot be constructed under Python 3, learn_module_fcn.py:41), in memory only.
+# ------------------------------------------------------------------------------------------------
+def g7_errors():
+  B, n, Gsz = 4, 16, 48
+  start, goal = rand_start_goal(B, seed=13)
+  g = torch.Generator().manual_seed(71)
+  th = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.2
+  th_eval = th + torch.randn(B, n, 4, generator=g) * 0.1
+  circ = ((-1.0, -1.0, 1.5), (2.0, 1.5, 1.2), (0.5, -2.5, 1.0))
+  sdf = T(circles_sdf(Gsz, circ))[None, None].repeat(B, 1, 1, 1)
+  qc, ow, eps = rand_covs(B, n, 2, 72)
+  c_sg = torch.randn(B, 1, generator=g); c_gp = torch.randn(B, 1, 1, generator=g); c_obs = torch.randn(B, 1, 1, generator=g)
+  c_ee = torch.randn(B, 1, 1, generator=g)
+  planner = make_planner(B, n)
+  names = ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps')
+  z = lambda gr, x: torch.zeros_like(x) if gr is None else gr
+  out = dict(th=th, th_eval=th_eval, G=Gsz, circles=np.asarray(circ), start=start, goal=goal, qc=qc, ow=ow, eps=eps,
+             c_sg=c_sg, c_gp=c_gp, c_obs=c_obs, c_ee=c_ee)
+  # (a) the errors at a trajectory that is a LEAF (isolates the backward of the error evaluation itself)
+  leaves = [x.clone().requires_grad_(True) for x in (th, sdf, start, goal, qc, ow, eps)]
+  the = th_eval.clone().requires_grad_(True)
+  planner.plan_layer(leaves[0], leaves[2], leaves[3], (sdf > 0).double(), leaves[1], leaves[4], leaves[5], leaves[6])
+  e_sg, e_gp, e_obs = planner.unweighted_errors_batch(the, leaves[1])
+  e_ee = planner.error_ext_batch(the, leaves[1])
+  out.update(a_sg=e_sg, a_gp=e_gp, a_obs=e_obs, a_ee=e_ee)
+  for tag, loss in (('unw', (c_sg * e_sg).sum() + (c_gp * e_gp).sum() + (c_obs * e_obs).sum()), ('ee', (c_ee * e_ee).sum())):
+    gr = torch.autograd.grad(loss, [the] + leaves, retain_graph=True, allow_unused=True)
+    out['a_%s_g_th_eval' % tag] = z(gr[0], the)
+    for nm, gk, x in zip(names, gr[1:], leaves):
+      out['a_%s_g_%s' % (tag, nm)] = z(gk, x); out['a_%s_none_%s' % (tag, nm)] = gk is None
+  # (b) the training-loop composition: errors at th + dtheta (train_planner.py:313,327)
+  leaves = [x.clone().requires_grad_(True) for x in (th, sdf, start, goal, qc, ow, eps)]
+  dth, err, err_ext = planner.plan_layer(leaves[0], leaves[2], leaves[3], (sdf > 0).double(), leaves[1], leaves[4], leaves[5], leaves[6])
+  th_new = leaves[0] + dth
+  e_sg, e_gp, e_obs = planner.unweighted_errors_batch(th_new, leaves[1])
+  e_ee = planner.error_ext_batch(th_new, leaves[1])
+  out.update(b_dth=dth, b_sg=e_sg, b_gp=e_gp, b_obs=e_obs, b_ee=e_ee)
+  loss = (c_sg * e_sg).sum() + (c_gp * e_gp).sum() + (c_obs * e_obs).sum() + (c_ee * e_ee).sum()
+  gr = torch.autograd.grad(loss, leaves, allow_unused=True)
+  for nm, gk, x in zip(names, gr, leaves):
+    out['b_g_' + nm] = z(gk, x)
+  save('g7_errors', **out)
+
+
+TBPTT_LEARN_PARAMS = {
+    'model': {'type': 'feed_forward'},
+    'dgpmp2': {'learn_eps': False, 'sdf_predict': True, 'dtheta_predict': False, 'fixed_conv': False, 'T': 4, 'tk': 2, 'tk2': 2,
+               'use_inter_loss': True, 'optimize_tk': False},
+    'data': {'im_size': 48},
+    'optim': {'vel_loss_lambda': 0.5, 'ext_obs_lambda': 2.0, 'ext_loss_weight': 0.3, 'batch_size': 3, 'do_validation': False},
+}
+
+
+def g7_tbptt():
+  import copy
+  import diff_gpmp2.gpmp2.diff_gpmp2_planner as pmod
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import tbptt_loop as TL
+  B, n, Gsz = 3, 16, 48
+  out = {}
+  saved = (pmod.LearnModuleConv, pmod.LearnModuleFCN)
+  pmod.LearnModuleConv = lambda lp, *a, **k: TL.ConvStub()
+  pmod.LearnModuleFCN = lambda lp, *a, **k: TL.FcnStub(lp['out_dim'])
+  try:
+    for mode in ('fix_dynamics', 'qc_full'):
+      lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
+      lp['dgpmp2']['dynamics_mode'] = mode
+      gp, obs, plp, opt = params_2d(n)
+      planner = DiffGPMP2Planner(gp, obs, plp, opt, ENV, PointRobot2D(torch.tensor(0.4), B, n), learn_params=lp, batch_size=B)
+      start, goal = rand_start_goal(B, seed=17)
+      circ = ((-1.0, -1.0, 1.5), (2.0, 1.5, 1.2), (0.5, -2.5, 1.0))
+      sdf = T(circles_sdf(Gsz, circ))[None, None].repeat(B, 1, 1, 1)
+      g = torch.Generator().manual_seed(73)
+      th_opt = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.3
+      sample = {'im': (sdf > 0).double(), 'sdf': sdf.clone(), 'start': start, 'goal': goal, 'th_opt': th_opt}
+      import contextlib, io
+      with contextlib.redirect_stdout(io.StringIO()):
+        r = TL.tbptt_batch(planner, sample, lp, plp, lambda s, e, tt, ts, dof, dev: straight_line_trajb(s, e, tt, ts, dof), torch.device('cpu'))
+      if mode == 'fix_dynamics':
+        out.update(G=Gsz, circles=np.asarray(circ), start=start, goal=goal, th_opt=th_opt)
+      pre = mode + '_'
+      out[pre + 'w_grad'] = r['param_grads']['learn_module_fcn.w']
+      out[pre + 'sdf_grad'] = r['sdf_grad']; out[pre + 'th_final'] = r['th_final']; out[pre + 'err'] = r['err']; out[pre + 'err_ext'] = r['err_ext']
+      out[pre + 'th_curr_grad_last'] = r['th_curr_grad_last']
+      out[pre + 'th_init_grad_is_none'] = r['th_init_grad'] is None
+      out[pre + 'param_names'] = np.asarray(sorted(r['param_grads'].keys()))
+      for k, v in r['log'].items(): out[pre + 'log_' + k] = np.asarray(v)
+  finally:
+    pmod.LearnModuleConv, pmod.LearnModuleFCN = saved
+  save('g7_tbptt', **out)
+
+
 if __name__ == '__main__':
-  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset()
+  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset(); g7_errors(); g7_tbptt()

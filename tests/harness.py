@@ -170,3 +170,22 @@ class Backend(object):
                             gep_p, self.stream(), g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc),
                 ow=self.to_np(gow), eps=self.to_np(gep))
+
+  def eval_backward(self, p, th, start, goal, sdf, g_err_ext=None, g_unw_sg=None, g_unw_gp=None, g_unw_obs=None, eps=None, io='f64', sdf_copies=1,
+                    want_sdf=True):
+    """dgp_eval_errors_backward -> dict of gradients: th, start, goal, sdf, eps (numpy fp64).  sdf None: no grid (sg / gp cotangents only)."""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, None, None, eps, False)
+    n = th.shape[1]
+    cot = [self.to_dev(None if c is None else np.reshape(c, (B,)), io)[1] for c in (g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs)]
+    gth, gth_p = self.empty(th.shape, io)
+    gst, gst_p = self.empty(np.asarray(start).shape, io)
+    ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
+    gsdf, gsdf_p, stride = None, None, 0
+    if sdf is not None and want_sdf:
+      sdf = np.asarray(sdf)
+      gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+      stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
+    solver.eval_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride, gep_p,
+                                self.stream(), g_sdf_copies=sdf_copies)
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), eps=self.to_np(gep))

@@ -533,3 +533,78 @@ def case_woodbury_kernels(be, golden, io, shapes=('16,4', '32,4', '64,4'), nb=3,
 
 
 ALL_CASES.append(case_woodbury_kernels)
+
+
+def case_eval_errors_backward(be, golden, io):
+  """dgp_eval_errors_backward vs the reference's torch autograd through unweighted_errors_batch / error_ext_batch (fixture g7_errors,
+  part (a): the errors at a leaf trajectory; gradients w.r.t. the trajectory, the grid, the start / goal means and the CURRENT eps the
+  last forward() left behind, plan_layer.py:88-94,329,374-388), per-sample grids; then central finite differences of the ORACLE for the
+  configurations the reference cannot run in batch (velocity limits, xyh robot: err_ext carries those factors) and the grid-less call."""
+  g = golden('g7_errors')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  th, st, go, sdf, eps = rnd(g['th_eval'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io), rnd(g['eps'].reshape(B, n), io)
+  tol = 1e-10 if io == 'f64' else 2e-5
+  err, eex, usg, ugp, uobs = be.eval_errors(p, th, st, go, sdf, eps=eps, io=io)
+  for got, key in ((usg, 'a_sg'), (ugp, 'a_gp'), (uobs, 'a_obs'), (eex, 'a_ee')):
+    assert rel_err(got, g[key].reshape(-1)) < (1e-11 if io == 'f64' else 2e-6), key
+  r = be.eval_backward(p, th, st, go, sdf, None, rnd(g['c_sg'], io), rnd(g['c_gp'], io), rnd(g['c_obs'], io), eps=eps, io=io)
+  for k, key in (('th', 'th_eval'), ('sdf', 'sdf'), ('start', 'start'), ('goal', 'goal'), ('eps', 'eps')):
+    ref = g['a_unw_g_' + key]
+    assert rel_err(r[k].reshape(ref.shape), ref) < tol, ('unweighted', k, rel_err(r[k].reshape(ref.shape), ref))
+  r = be.eval_backward(p, th, st, go, sdf, rnd(g['c_ee'], io), None, None, None, eps=eps, io=io)
+  for k, key in (('th', 'th_eval'), ('sdf', 'sdf'), ('start', 'start'), ('goal', 'goal'), ('eps', 'eps')):
+    ref = g['a_ee_g_' + key]
+    assert rel_err(r[k].reshape(ref.shape), ref) < tol, ('err_ext', k, rel_err(r[k].reshape(ref.shape), ref))
+  assert bool(g['a_unw_none_qc']) and bool(g['a_unw_none_ow']) and bool(g['a_ee_none_qc']) and bool(g['a_ee_none_ow'])
+  # no grid: start_goal_error / gp_error alone (PlanLayer.gp_error(thb) takes none) -- same th / start / goal gradients as with the
+  # obstacle cotangent left out
+  r0 = be.eval_backward(p, th, st, go, sdf, None, rnd(g['c_sg'], io), rnd(g['c_gp'], io), None, io=io)
+  r1 = be.eval_backward(p, th, st, go, None, None, rnd(g['c_sg'], io), rnd(g['c_gp'], io), None, io=io)
+  assert np.array_equal(r0['th'], r1['th']) and np.array_equal(r0['start'], r1['start']) and np.array_equal(r0['goal'], r1['goal'])
+  assert np.all(r0['sdf'] == 0)
+  if io != 'f64': return
+  # shared grid with partial copies == per-sample grids summed
+  sdf1 = sdf[:1]
+  ra = be.eval_backward(p, th, st, go, sdf1, rnd(g['c_ee'], io), rnd(g['c_sg'], io), rnd(g['c_gp'], io), rnd(g['c_obs'], io), eps=eps, io=io)
+  rb = be.eval_backward(p, th, st, go, sdf, rnd(g['c_ee'], io), rnd(g['c_sg'], io), rnd(g['c_gp'], io), rnd(g['c_obs'], io), eps=eps, io=io)
+  rc = be.eval_backward(p, th, st, go, sdf1, rnd(g['c_ee'], io), rnd(g['c_sg'], io), rnd(g['c_gp'], io), rnd(g['c_obs'], io), eps=eps, io=io, sdf_copies=8)
+  assert rel_err(ra['sdf'], rb['sdf'].sum(0, keepdims=True)) < 1e-12 and rel_err(rc['sdf'].sum(0, keepdims=True), ra['sdf']) < 1e-12
+  assert np.array_equal(ra['th'], rb['th']) and np.array_equal(ra['eps'], rb['eps'])
+  # finite differences of the oracle: C3 (velocity limits) and C4 (xyh) -- err_ext includes those factors (plan_layer.py:333-343)
+  rs = np.random.RandomState(12)
+  for name, P in (('g3_c3_vel', lambda n: O.OracleParams(dof=2, total_time_step=n - 1, use_vel_limits=True)),
+                  ('g3_c4_xyh', lambda n: O.OracleParams(dof=3, total_time_step=n - 1, non_holonomic=True, epsilon_dist=0.2, reg=0.0))):
+    gg = golden(name)
+    n2 = gg['th'].shape[1]
+    pp = P(n2)
+    sdf2 = O.circles_sdf(int(gg['G']), gg['circles'])[None, None]
+    th2, st2, go2 = gg['th'][:2], gg['start'][:2], gg['goal'][:2]
+    B2, _, d2 = th2.shape
+    ce, cs, cg, co = rs.randn(B2), rs.randn(B2), rs.randn(B2), rs.randn(B2)
+    eps2 = rs.uniform(0.2, 0.5, (B2, n2))
+
+    def loss(th_, st_, go_, eps_):
+      qc_, ow_, _ = pp.static_covs(B2)
+      sdfB = np.broadcast_to(sdf2, (B2,) + sdf2.shape[1:])
+      ee = O.error_batch(th_, st_, go_, sdfB, O.calc_Q_inv_batch(qc_, pp.dt), ow_, eps_.reshape(B2, n2, 1, 1), pp)      # fixed weights = the static ones
+      sg, gp_, ob = O.unweighted_errors_batch(th_, st_, go_, sdfB, eps_.reshape(B2, n2, 1, 1), pp)
+      return float(np.sum(ce * ee.reshape(-1)) + np.sum(cs * sg.reshape(-1)) + np.sum(cg * gp_.reshape(-1)) + np.sum(co * ob.reshape(-1)))
+    r = be.eval_backward(pp, th2, st2, go2, sdf2, ce, cs, cg, co, eps=eps2, io='f64')
+    h = 1e-6
+    for nm, arr, grad in (('th', th2, r['th']), ('start', st2, r['start']), ('goal', go2, r['goal']), ('eps', eps2, r['eps'])):
+      flat = arr.reshape(-1)
+      for i in rs.choice(flat.size, min(12, flat.size), replace=False):
+        ap, am = arr.copy().reshape(-1), arr.copy().reshape(-1)
+        ap[i] += h; am[i] -= h
+        args = dict(th=th2, start=st2, goal=go2, eps=eps2)
+        kp = dict(args); km = dict(args)
+        kp[nm] = ap.reshape(arr.shape); km[nm] = am.reshape(arr.shape)
+        fd = (loss(kp['th'], kp['start'], kp['goal'], kp['eps']) - loss(km['th'], km['start'], km['goal'], km['eps'])) / (2 * h)
+        scale = max(1.0, float(np.abs(grad).max()))
+        assert abs(fd - grad.reshape(-1)[i]) < 2e-5 * scale, (name, nm, int(i), fd, float(grad.reshape(-1)[i]))
+
+
+ALL_CASES.append(case_eval_errors_backward)

@@ -34,6 +34,8 @@ def test_emul_static_qc_variants(be, golden): PC.case_static_qc_variants(be, gol
 def test_emul_unaligned(be, golden): PC.case_unaligned_buffers(be, golden, 'f64')
 def test_emul_unaligned_f32(be, golden): PC.case_unaligned_buffers(be, golden, 'f32')
 def test_emul_solve_with_covariances(be, golden): PC.case_solve_with_covariances(be, golden, 'f64')
+def test_emul_eval_errors_backward(be, golden): PC.case_eval_errors_backward(be, golden, 'f64')
+def test_emul_eval_errors_backward_f32(be, golden): PC.case_eval_errors_backward(be, golden, 'f32')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)

@@ -90,6 +90,7 @@ def test_g3_c1_known_answers_and_steps(golden):
     assert rel_err(dth, g['dth_hist'][k]) < TOL, k
     assert rel_err(err, g['err_hist'][k]) < 1e-12 and rel_err(err_ext, g['errext_hist'][k]) < 1e-12
   usg, ugp, uobs = O.unweighted_errors_batch(g['th_hist'][3], g['start'], g['goal'], sdf, eps, p)
+  assert usg.shape == g['unw_sg'].shape and ugp.shape == g['unw_gp'].shape and uobs.shape == g['unw_obs'].shape
   assert rel_err(usg, g['unw_sg']) < 1e-12 and rel_err(ugp, g['unw_gp']) < 1e-12 and rel_err(uobs, g['unw_obs']) < 1e-12
 
 

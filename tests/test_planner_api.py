@@ -120,7 +120,7 @@ def test_error_helpers_and_unweighted_errors(golden):
   assert rel_err(planner.error_batch(th, sdf).cpu().numpy(), g['err_hist'][3]) < 1e-11
   assert rel_err(planner.error_ext_batch(th, sdf).cpu().numpy(), g['errext_hist'][3]) < 1e-11
   usg, ugp, uobs = planner.unweighted_errors_batch(th, sdf)
-  assert usg.shape == (1, 1, 1)
+  assert usg.shape == (1, 1) and ugp.shape == (1, 1, 1) and uobs.shape == (1, 1, 1)      # the reference's shapes (plan_layer.py:374-388)
   assert rel_err(ugp.cpu().numpy(), g['unw_gp']) < 1e-11 and rel_err(uobs.cpu().numpy(), g['unw_obs']) < 1e-11
   assert abs(float(usg) - float(g['unw_sg'].item())) < 1e-12
 
@@ -135,7 +135,7 @@ def test_unweighted_error_methods_one_by_one(golden):
   th = T(g['th_hist'][3])
   pl = planner.plan_layer
   usg, ugp, uobs = pl.start_goal_error(th), pl.gp_error(th), pl.obs_error(th, sdf)
-  assert usg.shape == (1, 1, 1) and ugp.shape == (1, 1, 1) and uobs.shape == (1, 1, 1)
+  assert usg.shape == (1, 1) and ugp.shape == (1, 1, 1) and uobs.shape == (1, 1, 1)
   assert abs(float(usg) - float(g['unw_sg'].item())) < 1e-12
   assert rel_err(ugp.cpu().numpy(), g['unw_gp']) < 1e-11 and rel_err(uobs.cpu().numpy(), g['unw_obs']) < 1e-11
   a, b, c = pl.unweighted_errors(th, sdf)
@@ -152,6 +152,7 @@ def test_unweighted_error_methods_one_by_one(golden):
                                                 sdf.double().cpu().numpy(), p.static_covs(B)[2], p)
   pl = planner.plan_layer
   assert rel_err(pl.gp_error(th).cpu().numpy(), r_gp) < 2e-6 and rel_err(pl.obs_error(th, sdf).cpu().numpy(), r_obs) < 2e-6
+  assert pl.start_goal_error(th).shape == r_sg.shape == (B, 1)
   assert float(np.max(np.abs(pl.start_goal_error(th).double().cpu().numpy() - r_sg))) < 1e-6
 
 
@@ -242,30 +243,114 @@ def test_autograd_shared_sdf_expand_and_static_covs(golden):
   assert rel_err(sdf1.grad.cpu().numpy(), sdfB.grad.sum(0, keepdim=True).cpu().numpy()) < 1e-10
 
 
-def test_tbptt_outer_loop_runs(golden):
-  """The shape of the reference's learning loop (learning/train_planner.py:297-374): detach -> step -> th + dtheta ->
-  loss on the new trajectory -> backward, with learnable per-state obstacle weights and epsilons feeding the solver."""
-  g = golden('g3_c2mini')
-  B, n, G = 8, 64, int(g['G'])
+def _learn_planner(n, B, lp, out_dim=None):
+  """dgpmp2_amd planner in learned mode with the stub learn modules of tests/tbptt_loop.py (the ones make_golden.py injected into the
+  reference planner); out_dim as the reference's constructor computes it (diff_gpmp2_planner.py:62-76)."""
+  import tbptt_loop as TL
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  gp, ob, pp, op, ev = ref_params(n)
+  mode = lp['dgpmp2']['dynamics_mode']
+  n_gp = {'fix_dynamics': 0, 'diag_identity': n - 1, 'qc_full': (n - 1) * 2, 'q_full': (n - 1) * 4}[mode]
+  out_dim = n_gp + n + (n if lp['dgpmp2'].get('learn_eps') else 0)
+  planner = DiffGPMP2Planner(gp, ob, pp, op, ev, PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n), learn_params=lp,
+                             batch_size=B, use_cuda=True, learn_module_conv=TL.ConvStub(), learn_module_fcn=TL.FcnStub(out_dim).to(DEV))
+  return planner, pp
+
+
+TBPTT_LEARN_PARAMS = {      # == tests/golden/make_golden.py::TBPTT_LEARN_PARAMS
+    'model': {'type': 'feed_forward'},
+    'dgpmp2': {'learn_eps': False, 'sdf_predict': True, 'dtheta_predict': False, 'fixed_conv': False, 'T': 4, 'tk': 2, 'tk2': 2,
+               'use_inter_loss': True, 'optimize_tk': False},
+    'data': {'im_size': 48},
+    'optim': {'vel_loss_lambda': 0.5, 'ext_obs_lambda': 2.0, 'ext_loss_weight': 0.3, 'batch_size': 3, 'do_validation': False},
+}
+
+
+@pytest.mark.parametrize('mode', ['fix_dynamics', 'qc_full'])
+def test_tbptt_outer_loop_runs(golden, mode):
+  """One batch of the reference's train() -- learning/train_planner.py:258-410 + one_step_loss :75-120, restated statement by
+  statement in tests/tbptt_loop.py -- driven through dgpmp2_amd's planner: detach -> step() -> th + dtheta ->
+  unweighted_errors_batch(th_new, sdf) -> one_step_loss (expert loss on dtheta + ext_loss_weight * (gp + sg + obs_lambda * obs)) ->
+  final_loss.backward() + the chained buffer backward.  The SAME function ran on the reference's planner to make the fixture
+  (tests/golden/make_golden.py::g7_tbptt): losses, the final trajectory and the gradients deposited in the learn module's parameters,
+  in sdf_b and in the last th_curr_b must agree."""
+  import copy
+  import tbptt_loop as TL
+  from dgpmp2_amd.utils.planner_utils import straight_line_trajb
+  g = golden('g7_tbptt')
+  B, n, G = 3, 16, int(g['G'])
+  lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
+  lp['dgpmp2']['dynamics_mode'] = mode
+  planner, pp = _learn_planner(n, B, lp)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1)
+  sample = {'im': (sdf > 0).double(), 'sdf': sdf.clone(), 'start': T(g['start']), 'goal': T(g['goal']), 'th_opt': T(g['th_opt'])}
+  r = TL.tbptt_batch(planner, sample, lp, pp, straight_line_trajb, torch.device(DEV))
+  pre = mode + '_'
+  assert sorted(r['param_grads'].keys()) == list(g[pre + 'param_names'])
+  for k in ('final_loss', 'ext_loss', 'obs_loss', 'gp_loss', 'sg_loss', 'pos_loss'):
+    assert rel_err(np.asarray(r['log'][k]), g[pre + 'log_' + k]) < 1e-9, k
+  assert rel_err(r['th_final'].cpu().numpy(), g[pre + 'th_final']) < 1e-9
+  assert rel_err(r['err'].cpu().numpy(), g[pre + 'err']) < 1e-9 and rel_err(r['err_ext'].cpu().numpy(), g[pre + 'err_ext']) < 1e-9
+  assert rel_err(r['param_grads']['learn_module_fcn.w'].cpu().numpy(), g[pre + 'w_grad']) < 1e-8
+  assert rel_err(r['sdf_grad'].cpu().numpy(), g[pre + 'sdf_grad']) < 1e-8
+  assert rel_err(r['th_curr_grad_last'].cpu().numpy(), g[pre + 'th_curr_grad_last']) < 1e-8
+  assert (r['th_init_grad'] is None) == bool(g[pre + 'th_init_grad_is_none'])
+
+
+def test_unweighted_errors_and_error_ext_are_differentiable_like_the_reference(golden):
+  """unweighted_errors_batch / error_ext_batch carry the graph the reference's plain torch ops carry (plan_layer.py:310-345,
+  374-388): w.r.t. the trajectory, the grid and -- remembered WITH their graphs by the last forward(), :88-94 -- the start / goal
+  means and the current eps.  Fixture g7_errors = the reference's autograd, (a) at a leaf trajectory, (b) at th + dtheta."""
+  g = golden('g7_errors')
+  B, n, G = 4, 16, int(g['G'])
   planner = make_planner(n, B)
-  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
-  start, goal = T(g['start']), T(g['goal'])
-  log_w = torch.full((B, n, 1, 1), float(np.log(1e4)), dtype=torch.float64, device=DEV, requires_grad=True)
-  eps = torch.full((B, n, 1, 1), 0.4, dtype=torch.float64, device=DEV, requires_grad=True)
-  qc = torch.eye(2, dtype=torch.float64, device=DEV).expand(B, n - 1, 2, 2).contiguous()
-  opt = torch.optim.SGD([log_w, eps], lr=1e-3)
-  th = T(g['th_hist'][0])
-  losses = []
-  for t in range(3):
-    th_curr = th.detach().requires_grad_(True)
-    dth, err, err_ext = planner.plan_layer(th_curr, start, goal, None, sdf, qc, log_w.exp(), eps)
-    th_new = th_curr + dth
-    loss = ((th_new - T(g['th_hist'][10])) ** 2).mean() + 1e-3 * planner.error_ext_batch(th_new, sdf).mean()
-    opt.zero_grad(); loss.backward(); opt.step()
-    assert torch.isfinite(log_w.grad).all() and float(log_w.grad.abs().max()) > 0 and float(eps.grad.abs().max()) > 0
-    assert th_curr.grad is not None
-    losses.append(float(loss)); th = th_new
-  assert all(np.isfinite(losses))
+  names = ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps')
+  c_sg, c_gp, c_obs, c_ee = T(g['c_sg']), T(g['c_gp']), T(g['c_obs']), T(g['c_ee'])
+
+  def leaves():
+    L = {k: T(g[k]).requires_grad_(True) for k in ('th', 'start', 'goal', 'qc', 'ow', 'eps')}
+    L['sdf'] = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1).requires_grad_(True)
+    return L
+  # (a)
+  L = leaves()
+  the = T(g['th_eval']).requires_grad_(True)
+  planner.plan_layer(L['th'], L['start'], L['goal'], None, L['sdf'], L['qc'], L['ow'], L['eps'])
+  e_sg, e_gp, e_obs = planner.unweighted_errors_batch(the, L['sdf'])
+  e_ee = planner.error_ext_batch(the, L['sdf'])
+  assert e_sg.shape == (B, 1) and e_gp.shape == (B, 1, 1) and e_obs.shape == (B, 1, 1) and e_ee.shape == (B, 1, 1)
+  for got, key in ((e_sg, 'a_sg'), (e_gp, 'a_gp'), (e_obs, 'a_obs'), (e_ee, 'a_ee')):
+    assert got.requires_grad and rel_err(got.detach().cpu().numpy(), g[key]) < 1e-11, key
+  for tag, loss in (('unw', (c_sg * e_sg).sum() + (c_gp * e_gp).sum() + (c_obs * e_obs).sum()), ('ee', (c_ee * e_ee).sum())):
+    gr = torch.autograd.grad(loss, [the] + [L[k] for k in names], retain_graph=True, allow_unused=True)
+    assert rel_err(gr[0].cpu().numpy(), g['a_%s_g_th_eval' % tag]) < 1e-10, tag
+    for k, gk in zip(names, gr[1:]):
+      if bool(g['a_%s_none_%s' % (tag, k)]):
+        assert gk is None or float(gk.abs().max()) == 0.0, (tag, k)
+      else:
+        assert gk is not None and rel_err(gk.cpu().numpy(), g['a_%s_g_%s' % (tag, k)]) < 1e-10, (tag, k)
+  # the one-by-one methods of PlanLayer carry the same graphs
+  pl = planner.plan_layer
+  gr = torch.autograd.grad((c_sg * pl.start_goal_error(the)).sum() + (c_gp * pl.gp_error(the)).sum() + (c_obs * pl.obs_error(the, L['sdf'])).sum(),
+                           [the, L['start'], L['eps']])
+  assert rel_err(gr[0].cpu().numpy(), g['a_unw_g_th_eval']) < 1e-10 and rel_err(gr[1].cpu().numpy(), g['a_unw_g_start']) < 1e-10
+  assert rel_err(gr[2].cpu().numpy(), g['a_unw_g_eps']) < 1e-10
+  # (b) learning/train_planner.py:313,327: the errors at th + dtheta, every leaf learnable
+  L = leaves()
+  dth, err, err_ext = planner.plan_layer(L['th'], L['start'], L['goal'], None, L['sdf'], L['qc'], L['ow'], L['eps'])
+  th_new = L['th'] + dth
+  e_sg, e_gp, e_obs = planner.unweighted_errors_batch(th_new, L['sdf'])
+  e_ee = planner.error_ext_batch(th_new, L['sdf'])
+  assert rel_err(dth.detach().cpu().numpy(), g['b_dth']) < 1e-9
+  for got, key in ((e_sg, 'b_sg'), (e_gp, 'b_gp'), (e_obs, 'b_obs'), (e_ee, 'b_ee')):
+    assert rel_err(got.detach().cpu().numpy(), g[key]) < 1e-9, key
+  loss = (c_sg * e_sg).sum() + (c_gp * e_gp).sum() + (c_obs * e_obs).sum() + (c_ee * e_ee).sum()
+  gr = torch.autograd.grad(loss, [L[k] for k in names])
+  for k, gk in zip(names, gr):
+    assert rel_err(gk.cpu().numpy(), g['b_g_' + k]) < 1e-8, k
+  # under no_grad nothing is recorded
+  with torch.no_grad():
+    assert not planner.unweighted_errors_batch(the, L['sdf'])[0].requires_grad and not planner.error_ext_batch(the, L['sdf']).requires_grad
 
 
 def test_forward_with_grad_keeps_graph_across_iterations(golden):
