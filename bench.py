@@ -341,9 +341,15 @@ def main():
   torch.cuda.set_device(local_rank)
   device = torch.device('cuda', local_rank)
   dist = None
-  if world > 1:
+  # one process per GPU under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment).  A world of ONE rank launched
+  # that way (torchrun --nproc-per-node 1, or DGP_BENCH_FORCE_DIST=1) takes the same RCCL branch -- process group, barriers, the
+  # all-gather of the final trajectories, the max-over-ranks reduction -- so that the code an N-GPU scaling run executes can be
+  # exercised on a one-GPU box (profiles/r03_bench_dist_world1.json)
+  under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ and 'MASTER_PORT' in os.environ
+  if world > 1 or under_launcher or os.environ.get('DGP_BENCH_FORCE_DIST') == '1':
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
     dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
   import __graft_entry__

@@ -17,25 +17,29 @@ class OrcParams(C.Structure):
               ('w_v', C.c_double), ('vmax', C.c_double * 2), ('M', C.c_double)]
 
 
-_lib = None
+_LIB_LD = os.path.join(_HERE, 'libgn_blocktri_ld.so')
+_libs = {}
 
 
-def lib():
-  global _lib
-  if _lib is None:
+def lib(extended=False):
+  """fp64 build, or (extended=True) the build whose assembly and block solve run in 80-bit extended precision."""
+  if extended not in _libs:
+    path = _LIB_LD if extended else _LIB
     src = os.path.join(_HERE, 'gn_blocktri.c')
-    if not os.path.exists(_LIB) or os.path.getmtime(src) > os.path.getmtime(_LIB):
-      subprocess.check_call(['make', '-s', '-C', _HERE])
-    _lib = C.CDLL(_LIB)
-    assert _lib.orc_sizeof_params() == C.sizeof(OrcParams)
-    _lib.orc_work_doubles.restype = C.c_int64
-  return _lib
+    if not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path):
+      subprocess.check_call(['make', '-s', '-C', _HERE, 'all'])
+    L = C.CDLL(path)
+    assert L.orc_sizeof_params() == C.sizeof(OrcParams)
+    L.orc_work_doubles.restype = C.c_int64
+    assert L.orc_real_bytes() == (16 if extended else 8)
+    _libs[extended] = L
+  return _libs[extended]
 
 
-def gn_step(p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, nthreads=1):
+def gn_step(p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, nthreads=1, extended=False):
   """p: oracle.gpmp2_oracle.OracleParams; arrays as in gpmp2_oracle.plan_layer_forward (sdf (B|1,1,H,W)).
-  -> dtheta (B,n,d), err (B,), err_ext (B,), info (B,)"""
-  L = lib()
+  -> dtheta (B,n,d), err (B,), err_ext (B,), info (B,).  extended: solve in extended precision (results rounded to fp64)."""
+  L = lib(extended)
   B, n, d = th.shape
   f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float64)
   th, start, goal, sdf, qc, ow, eps = f(th), f(start), f(goal), f(sdf), f(qc), f(ow), f(eps)
@@ -54,7 +58,8 @@ def gn_step(p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, n
   P.vmax[0], P.vmax[1] = p.v_x, p.v_y
   P.M = float(p.M)
   dth = np.empty((B, n, d)); err = np.empty(B); eex = np.empty(B); info = np.empty(B, dtype=np.int32)
-  work = np.empty(int(L.orc_work_doubles(n)) * max(1, nthreads))
+  work = np.empty(int(L.orc_work_doubles(n)) * max(1, nthreads) + 2)
+  work = work[(-work.ctypes.data // 8) % 2:]      # 16-byte aligned (long double)
   ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
   L.orc_gn_step(C.byref(P), C.c_int64(B), ptr(th), ptr(start), ptr(goal), ptr(sdf), ptr(qc), ptr(ow), ptr(eps), ptr(dth), ptr(err),
                 ptr(eex), ptr(info), ptr(work), C.c_int(nthreads))

@@ -15,7 +15,7 @@ args = ap.parse_args()
 be = harness.Backend(args.backend)
 rs = np.random.RandomState(args.seed)
 worst = 0.0
-emul = None
+conditioned = []      # cases beyond the fp64 tolerance that the extended-precision arbiter attributed to conditioning
 for case in range(args.cases):
   dof = int(rs.choice([2, 2, 3]))
   n = int(rs.choice([2, 3, 5, 8, 16, 17, 31, 32, 33, 48, 63, 64, 65, 101, 128, 129, 200, 256]))
@@ -69,21 +69,28 @@ for case in range(args.cases):
     tol = PC.TOL[io] * (30 if p.reg < 0.01 else 1)          # weakly regularised systems: cond(Lambda) up to 1e7
     worst = max(worst, e / tol)
     status = 'ok' if (e < tol and ee < 10 * PC.TOL_ERR[io]) else 'FAIL'
-    if status == 'FAIL' and e < 100 * tol and ee < 10 * PC.TOL_ERR[io] and be.kind == 'hip':
-      # conditioning or code generation?  The worst trajectory again on the CPU wavefront emulator (the same lane program compiled
-      # for the host, without FMA contraction): three fp64 computations of one system -- GPU, emulator, block-Thomas oracle -- that differ
-      # pairwise by the same few 1e-9 show the conditioning of that system (cond(Lambda) up to 1e7); a code-generation fault shows as an
-      # O(1) error (every one this script has found did) and is excluded by the 100 x tolerance cap.
-      if emul is None: emul = harness.Backend('emul')
-      bw = int(np.argmax(np.where(ok, np.abs(dth - c_dth).reshape(B, -1).max(1) / scale, 0.0)))
-      sl = slice(bw, bw + 1)
-      sub = lambda a: None if a is None else a[sl]
-      e_dth, _, _, _ = emul.step(p, th[sl], start[sl], goal[sl], sdf[sl] if per_sample else sdf, qc=sub(qc), ow=sub(ow), eps=sub(eps), q_full=q_full, io=io)
-      agree = np.abs(dth[sl] - e_dth).max() / scale[bw]
-      status = ('ok(conditioning: gpu == emulator to %.1e)' if agree < 10 * e + 1e-13 else 'FAIL(gpu vs emulator %.1e)') % agree
+    if status == 'FAIL' and ee < 10 * PC.TOL_ERR[io]:
+      # conditioning or a wrong result?  An INDEPENDENT arbiter decides: oracle/gn_blocktri.c built with the assembly and the block
+      # solve in 80-bit extended precision (libgn_blocktri_ld.so; it shares nothing with the kernels or their host emulator).  On a
+      # weakly regularised system (cond(Lambda) up to 1e7) the fp64 C oracle itself is cond * 2^-53 away from that solution; the GPU
+      # result is accepted -- and REPORTED as 'cond', never as 'ok' -- only when it is no further from the extended-precision solution
+      # than 3 x the fp64 C oracle is.  Anything else fails.
+      x_dth, _, _, x_info = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh),
+                                       q_full=q_full, nthreads=4, extended=True)
+      xs = np.abs(x_dth).reshape(B, -1).max(1) + 1e-300
+      okx = ok & (x_info == 0)
+      e_gpu = (np.abs(dth - x_dth).reshape(B, -1).max(1) / xs)
+      e_c = (np.abs(c_dth - x_dth).reshape(B, -1).max(1) / xs)
+      accept = (e_gpu <= tol) | (e_gpu <= 3.0 * e_c)
+      if np.all(accept[okx]):
+        status = 'cond(gpu %.1e, fp64 C oracle %.1e off the extended-precision solve)' % (e_gpu[okx].max(), e_c[okx].max())
+        conditioned.append(case)
+      else:
+        bw = int(np.argmax(np.where(okx & ~accept, e_gpu, 0.0)))
+        status = 'FAIL(trajectory %d: gpu %.1e, fp64 C oracle %.1e off the extended-precision solve)' % (bw, e_gpu[bw], e_c[bw])
     print('%3d %s dof=%d n=%3d B=%4d %s shape=%s sdf=%dx%d%s cov=%s Qc=%s flags=%s  dth %.1e err %.1e' % (case, status, dof, n, B, io, forced or 'auto', H, W, '(per-sample)' if per_sample else '', cov, qmode,
           ','.join(k for k in ('non_holonomic', 'use_vel_limits') if k in kw), e, ee), flush=True)
-    assert status.startswith('ok')
+    assert not status.startswith('FAIL'), status
   if case % 3 == 0 and ok.all():      # the fused loop (dgp_gn_solve) on the same configuration
     tho, its, eh, eeh, ef, sinfo = be.solve(p, th, start, goal, sdf, 3, 0.0, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
     if io == 'f64':                   # three iterations == three chained steps
@@ -100,22 +107,24 @@ for case in range(args.cases):
     if good and not sinfo.any():
       es = np.abs(tho - cur).max() / (np.abs(cur).max() + 1e-300)
       assert es < (1e-7 if io == 'f64' else 1e-5) * (30 if p.reg < 0.01 else 1), ('fused loop differs from ' + ref_name, case, es, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, qmode=qmode, reg=p.reg, flags=kw))
-  # the backward kernel of the same configuration against the CPU wavefront emulator (the same lane program compiled for the host):
-  # a code-generation check of every backward variant, on batches small enough for the emulator
+  # the backward kernel of the same configuration against an INDEPENDENT gradient oracle: torch autograd over the dense restatement of
+  # the reference's step (oracle/autograd_torch.py; pinned to the reference's own autograd fixtures) -- every backward variant, on
+  # batches small enough for the dense solve
   if B <= 8 and n <= 65 and ok.all() and be.kind == 'hip':
-    if emul is None: emul = harness.Backend('emul')
+    from oracle import autograd_torch as AT
     gbar = rs.randn(B, n, d); gext = rs.randn(B)
     shared = sdf.shape[0] == 1
     kwb = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io, sdf_copies=(16 if shared and case % 2 else 1))
     rh = be.backward(p, th, start, goal, sdf, dth, r(gbar), r(gext), **kwb)
-    re_ = emul.backward(p, th, start, goal, sdf, dth, r(gbar), r(gext), **kwb)
+    ro = AT.step_gradients(p, th, start, goal, sdf, r(gbar), r(gext), qc=qc, ow=ow, eps=eps, q_full=q_full)
     for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
       if rh[key] is None: continue
       if key == 'sdf' and io == 'f32': continue      # accumulated in fp32 IN MEMORY by atomics: the order-dependent cancellation noise of ~1e7-sized summands is not a code-generation signal
-      a_, b_ = rh[key], re_[key]
-      if key == 'sdf' and a_.shape[0] != sdf.shape[0]: a_, b_ = a_.sum(0), b_.sum(0)
-      # (the SDF gradient is a sum of signed tap contributions whose accumulation order differs: judged against the size of the summands,
-      #  for which the trajectory gradient stands in, when the sum itself cancels)
-      eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(re_['th']).max() if key == 'sdf' else 0.0, 1e-300)
-      assert eb < (1e-6 if io == 'f64' else 3e-4) * (30 if p.reg < 0.01 else 1),  ('backward differs from the emulator', case, key, eb, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, copies=kwb['sdf_copies'], amax=float(np.abs(a_).max()), bmax=float(np.abs(b_).max()), thmax=float(np.abs(re_['th']).max())))
-print('all %d cases ok; worst dtheta error / tolerance = %.2f' % (args.cases, worst))
+      a_, b_ = rh[key], ro[key].reshape(rh[key].shape if not (key == 'sdf' and rh[key].shape[0] != sdf.shape[0]) else sdf.shape)
+      if key == 'sdf' and a_.shape[0] != sdf.shape[0]: a_ = a_.sum(0, keepdims=True)
+      # (the SDF gradient is a sum of signed tap contributions: judged against the size of the summands, for which the trajectory
+      #  gradient stands in, when the sum itself cancels)
+      eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(ro['th']).max() if key == 'sdf' else 0.0, 1e-300)
+      assert eb < (1e-6 if io == 'f64' else 3e-4) * (30 if p.reg < 0.01 else 1),  ('backward differs from the autograd oracle', case, key, eb, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, copies=kwb['sdf_copies'], amax=float(np.abs(a_).max()), bmax=float(np.abs(b_).max()), thmax=float(np.abs(ro['th']).max())))
+print('%d cases: %d within tolerance of the fp64 C oracle, %d beyond it but no further from the extended-precision solve than 3 x the fp64 C oracle is (%s), 0 failed; worst dtheta error / tolerance = %.2f'
+      % (args.cases, args.cases - len(conditioned), len(conditioned), ','.join(map(str, conditioned)) or '-', worst))

@@ -2,7 +2,8 @@
 representations (static diagonal Q_c_inv: block elimination or Woodbury; static non-diagonal: general; per-state tensors: Kronecker;
 q_full: general) x {single step, fused loop} -- on a small batch against oracle/gn_blocktri.c, with the trajectory length that fills
 the shape exactly (n = LPT * C: full-line row I/O, the exact-fit Woodbury kernels) and a ragged one (padding rows, scalar row I/O, the
-ragged Woodbury kernels).  Backward: every instantiation against the CPU wavefront emulator (second test).
+ragged Woodbury kernels).  Backward: every instantiation against an INDEPENDENT gradient oracle -- torch autograd over the dense
+restatement of the reference's step (oracle/autograd_torch.py, itself pinned to the reference's autograd fixtures) -- second test.
 
 Why this exists: hipcc 7.0 has miscompiled several of the largest d = 6 kernels (wrong results or wild stores, while the same source
 is exact on the CPU wavefront emulator and in every other instantiation).  Which instantiation breaks changes with
@@ -89,11 +90,14 @@ def test_hip_every_forward_kernel_vs_c_oracle(be, dof, io, monkeypatch):
 
 @pytest.mark.parametrize('io', ['f64', 'f32'])
 @pytest.mark.parametrize('dof', [2, 3])
-def test_hip_every_backward_kernel_vs_emulator(be, dof, io, monkeypatch):
+def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
   """Every BACKWARD kernel instantiation (2 robots x 2 I/O types x 9 shapes x static [block elimination / Woodbury, exact fit and ragged] /
-  general / per-state) against the CPU wavefront emulator -- the same lane program compiled for the host -- on one small batch each, every
-  gradient tensor.  (The emulator's backward is itself pinned to the reference's autograd fixture and to finite differences of the oracle.)"""
-  emul = harness.Backend('emul')
+  general / per-state) on one small batch each, every gradient tensor, against torch autograd over the dense restatement of the
+  reference's step (oracle/autograd_torch.py: dense A, K, Cholesky + two explicit inverses; it shares nothing with the kernels or with
+  tests/emul, and reproduces the reference's own autograd fixtures to 1e-12, tests/test_oracle_golden.py) -- so a mathematical error
+  common to the kernel source and its host emulator cannot pass.  The non-holonomic robot is included (the reference cannot run it
+  in batch; the oracle differentiates through H as torch would)."""
+  from oracle import autograd_torch as AT
   rs = np.random.RandomState(200 * dof + (io == 'f32'))
   bad = []
   for lpt, c in SHAPES:
@@ -107,14 +111,16 @@ def test_hip_every_backward_kernel_vs_emulator(be, dof, io, monkeypatch):
       gbar = PC.rnd(rs.randn(B, n, d), io); gext = PC.rnd(rs.randn(B), io)
       copies = 16 if (lpt + c) % 3 == 0 else 1
       g_h = be.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, **kw)
-      g_e = emul.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, **kw)
+      g_o = AT.step_gradients(p, th, start, goal, sdf, gbar, gext, qc=qc, ow=ow, eps=eps, q_full=q_full)
       tag = 'dof %d %s shape (%d,%d) n %d cov %s' % (dof, io, lpt, c, n, cov)
+      if not PC.rel_err(dth, g_o['dtheta']) < PC.TOL[io]: bad.append((tag, 'dtheta', PC.rel_err(dth, g_o['dtheta'])))
       for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
         if g_h[key] is None: continue
         if key == 'sdf' and io == 'f32': continue      # accumulated in fp32 in memory by atomics: order-dependent cancellation noise, not a code-generation signal
-        a_, b_ = g_h[key], g_e[key]
-        if key == 'sdf' and copies > 1: a_, b_ = a_.sum(0), b_.sum(0)
+        a_ = g_h[key]
+        if key == 'sdf' and copies > 1: a_ = a_.sum(0, keepdims=True)
+        b_ = g_o[key].reshape(a_.shape)
         if not np.all(np.isfinite(a_)): bad.append((tag, key, 'non-finite')); continue
-        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(g_e['th']).max() if key == 'sdf' else 0.0, 1e-300)
+        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(g_o['th']).max() if key == 'sdf' else 0.0, 1e-300)
         if not eb < (1e-6 if io == 'f64' else 3e-4): bad.append((tag, key, eb))
-  assert not bad, '%d backward results differ from the emulator:\n' % len(bad) + '\n'.join(map(str, bad))
+  assert not bad, '%d backward results differ from the autograd oracle:\n' % len(bad) + '\n'.join(map(str, bad))

@@ -207,3 +207,16 @@ def test_hip_c2_full_size_per_sample_sdf(be):
   for b in idx[:6]:                                          # shared-grid addressing of the same trajectory: identical bits
     d1, e1, _, _ = be.step(p, th[b:b + 1], start[b:b + 1], goal[b:b + 1], sdf32[b:b + 1], io='f32')
     assert np.array_equal(d1[0], dth[b]) and e1[0] == err[b]
+
+
+def test_hip_stress_seed_short():
+  """One short seed of tests/stress_random_configs.py (random lengths, batches, robots, factor flags, SDF shapes, covariance modes,
+  launch shapes, I/O types; forward vs oracle/gn_blocktri.c with the extended-precision arbiter, fused loop vs chained steps, backward vs
+  the autograd oracle), so that the round-end GPU run exercises it; the long seeds are run by hand (profiles/)."""
+  import os, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ); env.pop('DGP_FORCE_SHAPE', None)
+  r = subprocess.run([sys.executable, os.path.join(root, 'tests', 'stress_random_configs.py'), '--cases', '40', '--seed', '12345', '--maxB', '300'],
+                     capture_output=True, text=True, env=env, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+  assert ' 0 failed' in r.stdout.splitlines()[-1], r.stdout[-500:]

@@ -210,3 +210,54 @@ def test_blocktri_c_oracle_matches_reference_and_numpy_oracle(golden):
   _, _, _, info = BT.gn_step(P2d(16, reg=-1e7), golden('g2_system_n16')['th'], golden('g2_system_n16')['start'],
                              golden('g2_system_n16')['goal'], O.circles_sdf(64, O.C2_CIRCLES)[None, None])
   assert info.all()
+
+
+def test_autograd_oracle_matches_reference_grads(golden):
+  """oracle/autograd_torch.py (the independent gradient oracle of the GPU backward tests and of tests/stress_random_configs.py) against
+  the reference's OWN torch autograd: fixture g5_grads (cotangent on dtheta, then on err_ext) and g7_errors part (a) (unweighted
+  errors / error_ext_batch at a leaf trajectory)."""
+  import torch
+  from oracle import autograd_torch as AT
+  g = golden('g5_grads')
+  B, n = g['th'].shape[:2]
+  p = O.OracleParams(dof=2, total_time_step=n - 1)
+  G = int(g['G'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  r = AT.step_gradients(p, g['th'], g['start'], g['goal'], sdf, g['gbar'], np.zeros(B), qc=g['qc'], ow=g['ow'], eps=g['eps'])
+  assert rel_err(r['dtheta'], g['dth']) < 1e-11
+  for k in ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps'):
+    assert rel_err(r[k].reshape(g['g_' + k].shape), g['g_' + k]) < 1e-10, k
+  r = AT.step_gradients(p, g['th'], g['start'], g['goal'], sdf, np.zeros_like(g['gbar']), g['gext'].reshape(B), qc=g['qc'], ow=g['ow'], eps=g['eps'])
+  for k in ('th', 'sdf', 'start', 'goal', 'eps'):
+    assert rel_err(r[k].reshape(g['ge_' + k].shape), g['ge_' + k]) < 1e-12, k
+  assert np.all(r['qc'] == 0) and np.all(r['ow'] == 0) and bool(g['ge_none_qc']) and bool(g['ge_none_ow'])
+  # unweighted errors
+  g = golden('g7_errors')
+  T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).requires_grad_(True)
+  the, st, go, sd, ep = T(g['th_eval']), T(g['start']), T(g['goal']), T(sdf), T(g['eps'])
+  sg, gp, ob = AT.unweighted_errors(the, st, go, sd, ep, p)
+  assert sg.shape == g['a_sg'].shape and gp.shape == g['a_gp'].shape and ob.shape == g['a_obs'].shape
+  loss = (torch.from_numpy(g['c_sg']) * sg).sum() + (torch.from_numpy(g['c_gp']) * gp).sum() + (torch.from_numpy(g['c_obs']) * ob).sum()
+  gr = torch.autograd.grad(loss, [the, sd, st, go, ep])
+  for got, key in zip(gr, ('th_eval', 'sdf', 'start', 'goal', 'eps')):
+    assert rel_err(got.numpy(), g['a_unw_g_' + key]) < 1e-12, key
+
+
+def test_extended_precision_oracle_build(golden):
+  """oracle/gn_blocktri.c built with long-double assembly + solve (the arbiter of tests/stress_random_configs.py): same answers as the
+  fp64 build and the reference fixture on a well-conditioned system, closer to the truth on an ill-conditioned one."""
+  from oracle import blocktri as BT
+  g = golden('g3_c2mini')
+  p = O.OracleParams(dof=2, total_time_step=63)
+  sdf = O.circles_sdf(int(g['G']), g['circles'])[None, None]
+  th = g['th_hist'][0]
+  a = BT.gn_step(p, th, g['start'], g['goal'], sdf, nthreads=2)
+  b = BT.gn_step(p, th, g['start'], g['goal'], sdf, nthreads=2, extended=True)
+  assert rel_err(b[0], g['dth_hist'][0]) < 1e-11 and rel_err(a[0], b[0]) < 1e-11 and rel_err(a[1], b[1]) < 1e-14 and not b[3].any()
+  # weakly regularised (cond ~ 1e7): the fp64 and extended builds differ by cond * 2^-53, and the dense numpy oracle sides with neither exactly
+  p2 = O.OracleParams(dof=2, total_time_step=63, reg=1e-5)
+  a = BT.gn_step(p2, th, g['start'], g['goal'], sdf)
+  b = BT.gn_step(p2, th, g['start'], g['goal'], sdf, extended=True)
+  qc, ow, eps = p2.static_covs(8)
+  d_dense = O.plan_layer_forward(th, g['start'], g['goal'], np.broadcast_to(sdf, (8, 1) + sdf.shape[2:]), qc, ow, eps, p2)[0]
+  assert rel_err(a[0], b[0]) < 1e-7 and rel_err(d_dense, b[0]) < 1e-7
