@@ -291,6 +291,26 @@ def extra_workloads(device, stream, reps=1500):
   run('per_sample_sdf', 2, GRID, {}, sdf=ps, sdf_stride=GRID * GRID, traffic_key='per_sample_sdf',
       note='configs[1] with one 256x256 SDF PER trajectory (the reference API shape sdfb (B,1,H,W)): 1 GiB of grids per batch, six '
            'different batches of grids cycled so that the tap lines come from HBM, not from the 256 MiB Infinity Cache')
+  # the regime a GN loop is in: step k+1 reads (nearly) the lines step k read -- ONE batch of grids, the trajectory inputs cycling
+  run('per_sample_sdf_same_grids', 2, GRID, {}, sdf=ps[:1], sdf_stride=GRID * GRID,
+      note='configs[1] with one 256x256 SDF per trajectory, the SAME 4096 grids every step (GN iteration k+1 on the grids of iteration k): '
+           'the tap lines of the previous step are still in the Infinity Cache / L2')
+  # ... and the 10 GN iterations as ONE launch of the fused loop on 4096 distinct grids (DiffGPMP2Planner.forward on per-sample grids)
+  th0, start, goal, _ = make_inputs(B, n, GRID, device, seed=0, dof=2)
+  s = _capi.Solver(solver_config(num_states=n, dof=2, io_dtype=torch.float32))
+  tho = torch.empty_like(th0); its = torch.zeros(B, dtype=torch.int32, device=device); info = torch.zeros(B, dtype=torch.int32, device=device)
+  eh = torch.empty(B, GN_ITERS, device=device); eeh = torch.empty(B, GN_ITERS, device=device)
+  sas = [s.sdf_arg(g_.data_ptr(), GRID, GRID, GRID * GRID) for g_ in ps]
+  tp, sp, gp = th0.data_ptr(), start.data_ptr(), goal.data_ptr()
+  fus = time_launches(lambda k: s.gn_solve(B, tp, sp, gp, sas[k % len(sas)], None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(), eh.data_ptr(),
+                                           eeh.data_ptr(), None, info.data_ptr(), stream), 120, warm_s=0.2)
+  assert int(its.min()) == GN_ITERS and int(info.abs().max()) == 0
+  by = algorithmic_bytes_per_trajectory(n, 4) * B       # per GN iteration, as if every iteration were a step() (the fused loop moves LESS: th stays on chip)
+  out['per_sample_sdf_fused_forward'] = {
+      'workload': 'configs[1] with one 256x256 SDF per trajectory, the 10 GN iterations as ONE dgp_gn_solve launch, six batches of grids cycled (cold '
+                  'first iteration, iterations 2..10 re-touch the lines of the first)',
+      'ms_per_launch': fus * 1e-3, 'us_per_gn_iteration': fus / GN_ITERS, 'gn_steps_per_s': GN_ITERS / (fus * 1e-6),
+      'roofline': roofline_block(by, fus / GN_ITERS, 'gn_kernel<2,16,4,float,1,3>', note='algorithmic bytes of ONE step() per GN iteration')}
   del ps
   return out
 
@@ -321,6 +341,54 @@ def planner_api_rate(device, reps=300):
   us = best
   return {'us_per_call': us, 'gn_steps_per_s': 1e6 / us, 'note': 'DiffGPMP2Planner.step() under torch.no_grad(), B=4096, wall time per call '
           '(host-side Python + ctypes + one kernel launch); the headline `value` is the C-ABI launch rate'}
+
+
+def planner_api_backward_rate(device, reps=200):
+  """DiffGPMP2Planner.step() + the backward pass through it, wall microseconds per (forward + backward) at B = 4096, through the
+  Python mirror and torch autograd -- (a) static covariances, gradient w.r.t. the trajectory (a TBPTT link); (b) the learning loop's
+  shape: per-state qc_inv / obscov_inv / eps tensors that require grad (what learn modules emit, handed to PlanLayer.forward as
+  diff_gpmp2_planner.py:200 does), gradients w.r.t. all of them and the trajectory."""
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  B, n = B_PER_GPU, N_STATES
+  t = lambda v: torch.tensor(v, dtype=torch.float64)
+  gp = {'Q_c_inv': torch.eye(2, dtype=torch.float64), 'K_s': t(0.01), 'K_g': t(0.01)}
+  ob = {'cost_sigma': t(0.01), 'epsilon_dist': t(0.4)}
+  pp = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
+  op = {'method': 'gauss_newton', 'reg': 0.1, 'max_iters': GN_ITERS, 'tol_err': 1e-3, 'tol_delta': 1e-4}
+  planner = DiffGPMP2Planner(gp, ob, pp, op, {'x_lims': [-5.0, 5.0], 'y_lims': [-5.0, 5.0]}, PointRobot2D(t(0.4), B, n, use_cuda=True),
+                             batch_size=B, use_cuda=True)
+  th0, start, goal, sdf = make_inputs(B, n, GRID, device)
+  sdfb = sdf.expand(B, 1, GRID, GRID)
+  thr = th0.clone().requires_grad_(True)
+  g = torch.randn_like(th0)
+  qc = torch.eye(2, device=device).expand(B, n - 1, 2, 2).contiguous().requires_grad_(True)
+  ow = torch.full((B, n, 1, 1), 1e4, device=device, requires_grad=True)
+  ep = torch.full((B, n, 1, 1), 0.4, device=device, requires_grad=True)
+
+  def static_fb():
+    dth = planner.step(thr, start, goal, None, sdfb)[0]
+    torch.autograd.grad(dth, thr, g)
+
+  def learned_fb():
+    dth = planner.plan_layer(thr, start, goal, None, sdfb, qc, ow, ep)[0]
+    torch.autograd.grad(dth, (thr, qc, ow, ep), g)
+
+  def wall(f):
+    best = float('inf')
+    for _ in range(50): f()
+    for _ in range(3):
+      torch.cuda.synchronize(); t0 = time.perf_counter()
+      for _ in range(reps): f()
+      torch.cuda.synchronize()
+      best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+    return best
+
+  a, b = wall(static_fb), wall(learned_fb)
+  return {'us_per_call': a, 'learned_covariances_us_per_call': b,
+          'note': 'wall time of DiffGPMP2Planner.step() + torch.autograd.grad through it, B=4096: static covariances with the gradient w.r.t. the '
+                  'trajectory (us_per_call), and per-state qc_inv / obscov_inv / eps tensors with gradients w.r.t. all four (learned_covariances_us_per_call); '
+                  'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine'}
 
 
 def main():
@@ -460,6 +528,7 @@ def main():
     if world == 1 and not args.no_extras:
       out.update(extra_workloads(device, stream))
       out['planner_step_api'] = planner_api_rate(device)
+      out['planner_step_backward_api'] = planner_api_backward_rate(device)
     if world == 1 and not args.no_cpu_baseline:
       hist_cpu = [t.cpu() for t in th_hist]
       out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())

@@ -6,6 +6,7 @@ fails loudly when it is missing -- there is no CPU fallback.  The binding class 
 which exports the same entry points with the prefix `emul_`, through the very same marshalling code.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import torch  # noqa: F401  -- must be imported BEFORE the HIP library is dlopen'ed: torch ships its own libamdhip64.so.7 /
@@ -130,6 +131,8 @@ class KernelTimer(object):
 
 
 _api = None
+_pycall = None
+PYCALL_PATH = os.path.join(_HERE, 'lib', '_dgp_pycall.so')
 
 
 def get_api():
@@ -138,6 +141,24 @@ def get_api():
   if _api is None:
     _api = CApi(LIB_PATH, 'dgp_')
   return _api
+
+
+def get_pycall():
+  """The METH_FASTCALL trampoline onto the product library's entry points (csrc/dgp_pycall.c): the same C-ABI calls as the ctypes
+  binding above at a tenth of the per-call marshalling cost.  What the torch-facing layer (dgpmp2_amd.gpmp2) launches through;
+  the ctypes methods of `Solver` stay the reference binding (tests, tools).  Raises ImportError if it was not built."""
+  global _pycall
+  if _pycall is None:
+    api = get_api()
+    if not os.path.exists(PYCALL_PATH):
+      raise ImportError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"`' % PYCALL_PATH)
+    spec = importlib.util.spec_from_file_location('_dgp_pycall', PYCALL_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    addr = lambda f: C.cast(f, C.c_void_p).value
+    mod.bind(addr(api.gn_step), addr(api.gn_solve), addr(api.eval_errors), addr(api.gn_step_backward), addr(api.eval_errors_backward))
+    _pycall = mod
+  return _pycall
 
 
 def make_config(num_states, dof, io_dtype, total_time_sec, x_lims, y_lims, K_s, K_g, reg, sphere_radius, Q_c_inv,
@@ -171,6 +192,7 @@ class Solver(object):
     h = C.c_void_p()
     self.api.check(self.api.create(C.byref(cfg), C.byref(h)))
     self.handle = h
+    self.h = h.value                       # the handle as a plain int (what the trampoline of get_pycall() takes)
     self.M = self.api.num_factor_rows(h)
     self.n, self.dof, self.d = cfg.num_states, cfg.dof, 2 * cfg.dof
 

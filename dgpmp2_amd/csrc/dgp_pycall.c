@@ -1,0 +1,156 @@
+/* dgp_pycall.c -- CPython trampoline onto the C-ABI of include/dgpmp2_hip.h (module dgpmp2_amd.lib._dgp_pycall).
+ *
+ * ctypes spends 3-5 us converting the dozen-odd arguments of one dgp_gn_step call -- a third of the 10.9 us the kernel runs
+ * (planner_step_api).  This module does the same job with METH_FASTCALL: integers in, the two by-reference
+ * structs (DgpSdf, DgpCovs) built on the C stack, one indirect call.  It links against NOTHING of the product: bind() receives
+ * the addresses of the C-ABI entry points that dgpmp2_amd/_capi.py resolved in libdgpmp2_hip.so, so the boundary stays the
+ * C-ABI and this file contains no solver logic.  Pointers are passed as Python ints (tensor.data_ptr()), None or 0 = NULL.
+ * Every function returns the C-ABI status code; the caller turns a non-zero code into DgpError (dgp_last_error()).
+ *
+ * Built by __graft_entry__.build() with the host compiler (no HIP).
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include "../../include/dgpmp2_hip.h"
+
+typedef int (*gn_step_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, void*, void*, void*,
+                          int32_t*, void*);
+typedef int (*gn_solve_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, int32_t, double, void*,
+                           int32_t*, void*, void*, void*, int32_t*, void*);
+typedef int (*eval_errors_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, void*, void*, void*,
+                              void*, void*, void*);
+typedef int (*gn_step_backward_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, const void*,
+                                   const void*, const void*, void*, void*, void*, void*, int64_t, int32_t, void*, void*, void*, void*);
+typedef int (*eval_errors_backward_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*,
+                                       const void*, const void*, const void*, const void*, void*, void*, void*, void*, int64_t, int32_t, void*,
+                                       void*);
+
+static gn_step_fn f_gn_step;
+static gn_solve_fn f_gn_solve;
+static eval_errors_fn f_eval_errors;
+static gn_step_backward_fn f_gn_step_backward;
+static eval_errors_backward_fn f_eval_errors_backward;
+
+/* int / None -> address; sets *bad on a conversion error */
+static inline void* as_ptr(PyObject* o, int* bad) {
+  if (o == Py_None) return NULL;
+  void* p = PyLong_AsVoidPtr(o);
+  if (p == NULL && PyErr_Occurred()) *bad = 1;
+  return p;
+}
+static inline int64_t as_i64(PyObject* o, int* bad) {
+  const long long v = PyLong_AsLongLong(o);
+  if (v == -1 && PyErr_Occurred()) *bad = 1;
+  return (int64_t)v;
+}
+
+#define NEED(n, name)                                                                                       \
+  if (nargs != (n)) {                                                                                       \
+    PyErr_Format(PyExc_TypeError, name " takes exactly %d positional arguments (%zd given)", (n), nargs);   \
+    return NULL;                                                                                            \
+  }                                                                                                         \
+  int bad = 0
+#define P(i) as_ptr(a[i], &bad)
+#define I(i) as_i64(a[i], &bad)
+
+/* common prefix of every entry point: handle, batch, th, start, goal, sdf_data, sdf_rows, sdf_cols, sdf_batch_stride, qc_mode, qc_inv, obs_w, eps
+ * (13 arguments).  sdf_data None/0 -> a NULL DgpSdf* (only dgp_eval_errors[_backward] accept that). */
+#define PREFIX 13
+#define BUILD_PREFIX                                                                                        \
+  const DgpHandle* h = (const DgpHandle*)P(0);                                                              \
+  const int32_t batch = (int32_t)I(1);                                                                      \
+  const void *th = P(2), *start = P(3), *goal = P(4);                                                       \
+  DgpSdf sdf = {P(5), (int32_t)I(6), (int32_t)I(7), I(8)};                                                  \
+  DgpCovs covs = {(int32_t)I(9), P(10), P(11), P(12)};                                                      \
+  const DgpSdf* sdfp = sdf.data ? &sdf : NULL
+
+static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(5, "bind");
+  f_gn_step = (gn_step_fn)P(0);
+  f_gn_solve = (gn_solve_fn)P(1);
+  f_eval_errors = (eval_errors_fn)P(2);
+  f_gn_step_backward = (gn_step_backward_fn)P(3);
+  f_eval_errors_backward = (eval_errors_backward_fn)P(4);
+  if (bad) return NULL;
+  Py_RETURN_NONE;
+}
+
+#define BOUND(f)                                                                                            \
+  if (!(f)) { PyErr_SetString(PyExc_RuntimeError, "_dgp_pycall.bind() has not been called"); return NULL; }
+
+/* gn_step(PREFIX..., dtheta, err, err_ext, info, stream) */
+static PyObject* py_gn_step(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 5, "gn_step");
+  BOUND(f_gn_step);
+  BUILD_PREFIX;
+  void *dth = P(13), *err = P(14), *eex = P(15), *info = P(16), *stream = P(17);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_step(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, stream));
+}
+
+/* gn_solve(PREFIX..., max_iters, tol_delta, th_out, iters, err_hist, errext_hist, err_final, info, stream) */
+static PyObject* py_gn_solve(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 9, "gn_solve");
+  BOUND(f_gn_solve);
+  BUILD_PREFIX;
+  const int32_t max_iters = (int32_t)I(13);
+  const double tol = PyFloat_AsDouble(a[14]);
+  if (tol == -1.0 && PyErr_Occurred()) return NULL;
+  void *th_out = P(15), *iters = P(16), *eh = P(17), *eeh = P(18), *ef = P(19), *info = P(20), *stream = P(21);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_solve(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info, stream));
+}
+
+/* eval_errors(PREFIX..., err, err_ext, unw_sg, unw_gp, unw_obs, stream) */
+static PyObject* py_eval_errors(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 6, "eval_errors");
+  BOUND(f_eval_errors);
+  BUILD_PREFIX;
+  void *err = P(13), *eex = P(14), *usg = P(15), *ugp = P(16), *uobs = P(17), *stream = P(18);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_eval_errors(h, batch, th, start, goal, sdfp, &covs, err, eex, usg, ugp, uobs, stream));
+}
+
+/* gn_step_backward(PREFIX..., dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, stream) */
+static PyObject* py_gn_step_backward(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 13, "gn_step_backward");
+  BOUND(f_gn_step_backward);
+  BUILD_PREFIX;
+  const void *dth = P(13), *g_dth = P(14), *g_eex = P(15);
+  void *g_th = P(16), *g_st = P(17), *g_go = P(18), *g_sdf = P(19);
+  const int64_t g_stride = I(20);
+  const int32_t copies = (int32_t)I(21);
+  void *g_qc = P(22), *g_ow = P(23), *g_eps = P(24), *stream = P(25);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_step_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_th, g_st, g_go, g_sdf, g_stride, copies,
+                                            g_qc, g_ow, g_eps, stream));
+}
+
+/* eval_errors_backward(PREFIX..., g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, g_eps, stream) */
+static PyObject* py_eval_errors_backward(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 12, "eval_errors_backward");
+  BOUND(f_eval_errors_backward);
+  BUILD_PREFIX;
+  const void *g_eex = P(13), *g_usg = P(14), *g_ugp = P(15), *g_uobs = P(16);
+  void *g_th = P(17), *g_st = P(18), *g_go = P(19), *g_sdf = P(20);
+  const int64_t g_stride = I(21);
+  const int32_t copies = (int32_t)I(22);
+  void *g_eps = P(23), *stream = P(24);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_eval_errors_backward(h, batch, th, start, goal, sdfp, &covs, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf, g_stride,
+                                                copies, g_eps, stream));
+}
+
+static PyMethodDef methods[] = {
+    {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL, "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward): addresses of the C-ABI entry points"},
+    {"gn_step", (PyCFunction)(void (*)(void))py_gn_step, METH_FASTCALL, "dgp_gn_step"},
+    {"gn_solve", (PyCFunction)(void (*)(void))py_gn_solve, METH_FASTCALL, "dgp_gn_solve"},
+    {"eval_errors", (PyCFunction)(void (*)(void))py_eval_errors, METH_FASTCALL, "dgp_eval_errors"},
+    {"gn_step_backward", (PyCFunction)(void (*)(void))py_gn_step_backward, METH_FASTCALL, "dgp_gn_step_backward"},
+    {"eval_errors_backward", (PyCFunction)(void (*)(void))py_eval_errors_backward, METH_FASTCALL, "dgp_eval_errors_backward"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_dgp_pycall", "METH_FASTCALL trampoline onto the dgpmp2_hip C-ABI", -1, methods};
+
+PyMODINIT_FUNC PyInit__dgp_pycall(void) { return PyModule_Create(&moddef); }

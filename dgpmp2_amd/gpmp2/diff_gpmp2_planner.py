@@ -19,8 +19,15 @@ import time
 import torch
 import torch.nn as nn
 
-from .plan_layer import PlanLayer, _f, _stream
+from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC
 from ..utils.planner_utils import check_convergence
+
+
+def _global_module_hooks():
+  """True when torch.nn.modules.module has global forward / backward hooks registered (then PlanLayer goes through __call__)."""
+  m = torch.nn.modules.module
+  return bool(m._global_forward_hooks or m._global_forward_pre_hooks or m._global_backward_hooks or getattr(m, '_global_backward_pre_hooks', None)
+              or getattr(m, '_global_forward_hooks_always_called', None))
 
 
 class _PerSampleHistory(object):
@@ -71,6 +78,7 @@ class DiffGPMP2Planner(nn.Module):
     dd = torch.float64      # the static covariances are exact copies of the config values (the reference runs under a float64 default)
     mk = lambda shape, v: (torch.zeros(*shape, dtype=dd, device=self.device) + torch.as_tensor(v, dtype=dd, device=self.device))
     self._static_views = {}
+    self._static_triples = {}
     self.fixed_conv = False
     self.learn_eps = False
     self.dynamics_mode = None
@@ -102,6 +110,9 @@ class DiffGPMP2Planner(nn.Module):
       self.learn_module_fcn = learn_module_fcn
     self.plan_layer = PlanLayer(gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params,
                                 self.batch_size, self.use_cuda)
+    # plain-attribute aliases for step(): a submodule / None-module attribute is resolved by nn.Module.__getattr__ (~1 us per access)
+    self.__dict__['_pl'] = self.plan_layer
+    self.__dict__['_learned'] = self.learn_module_fcn is not None
 
   # -- helpers ------------------------------------------------------------------------------------------
   def _static_view(self, t, B, like):
@@ -114,6 +125,15 @@ class DiffGPMP2Planner(nn.Module):
       v = t.to(like.dtype).unsqueeze(0).expand(B, *t.shape)
       v._dgp_static = True
       self._static_views[key] = v
+    return v
+
+  def _static_covs(self, B, like):
+    """The three static covariance views of step() for a batch of B in the dtype of `like` (one dictionary look-up per call)."""
+    key = (B, like.dtype)
+    v = self._static_triples.get(key)
+    if v is None:
+      v = self._static_triples[key] = (self._static_view(self.qc_inv_traj, B, like), self._static_view(self.obscov_inv_traj, B, like),
+                                       self._static_view(self.eps_traj, B, like))
     return v
 
   def _predict(self, th_in, conv_out, hiddenb, im_in=None):
@@ -144,17 +164,20 @@ class DiffGPMP2Planner(nn.Module):
     -> (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr)"""
     B = th_currb.shape[0]
     hidden = None
-    if self.learn_module_fcn is not None:
+    pl = self.__dict__['_pl']
+    if self.__dict__['_learned']:
       im_in = None
       if not self.fixed_conv:
         im_in = torch.cat((imb, sdfb), dim=1) if self.sdf_predict else imb
       th_in = torch.cat((th_currb, dtheta_currb), dim=-1) if self.use_dtheta else th_currb
       qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._predict(th_in, conv_out, hiddenb, im_in)
     else:
-      qc_inv_curr = self._static_view(self.qc_inv_traj, B, th_currb)
-      obscov_inv_curr = self._static_view(self.obscov_inv_traj, B, th_currb)
-      eps_curr = self._static_view(self.eps_traj, B, th_currb)
-    dthetab, err_oldb, err_ext_oldb = self.plan_layer(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
+      qc_inv_curr, obscov_inv_curr, eps_curr = self._static_covs(B, th_currb)
+    # (nn.Module.__call__ costs ~2 us of hook bookkeeping per call; without hooks it does nothing but call forward())
+    if pl._forward_hooks or pl._forward_pre_hooks or pl._backward_hooks or pl._backward_pre_hooks or _global_module_hooks():
+      dthetab, err_oldb, err_ext_oldb = pl(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
+    else:
+      dthetab, err_oldb, err_ext_oldb = pl.forward(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
     hidden_newb = hidden if hiddenb is not None else None
     return dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr
 
@@ -178,7 +201,8 @@ class DiffGPMP2Planner(nn.Module):
     B = th_initb.shape[0]
     dt, dev = th_initb.dtype, th_initb.device
     solver = pl._solver(dt)
-    sdf_arg, keep = pl._sdf_arg(solver, sdfb, dt, B)
+    idx = th_initb.get_device()
+    sd = pl._sdf_args(sdfb, dt, B, idx)
     th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
     th_out = torch.empty_like(th0)
     iters = torch.empty(B, dtype=torch.int32, device=dev)
@@ -186,9 +210,8 @@ class DiffGPMP2Planner(nn.Module):
     eeh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
     ef = torch.empty(B, dtype=dt, device=dev)
     info = torch.empty(B, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
-      solver.gn_solve(B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sdf_arg, None, max_iters, tol_delta, th_out.data_ptr(),
-                      iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _stream())
+    _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
+            max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
     pl.last_info = info
     pl._last = (st, go, None, None, None)
     jb = iters.cpu().tolist()                       # synchronises

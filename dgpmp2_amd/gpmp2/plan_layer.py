@@ -16,6 +16,7 @@ Differences a caller can observe (all deliberate):
     because the check forces a device synchronisation; the per-trajectory flags are always available in `last_info`.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
@@ -49,8 +50,14 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
                            cost_sigma=cost_sigma, epsilon_dist=epsilon_dist, **kw)
 
 
-_ALL_STATIC_COVS = _capi.DgpCovs(_capi.DGP_QC_STATIC, None, None, None)
 _SDF_GRAD_COPIES = 16     # MI355X has 8 XCDs, each with its own L2: two partial grids per XCD (XCD-local atomics, summed afterwards)
+_ALL_STATIC = (True, True, True)
+_NO_COVS = (_capi.DGP_QC_STATIC, None, None, None)       # (qc_mode, qc_inv, obs_w, eps) as the trampoline takes them
+
+# current device / current raw stream as plain ints: torch.cuda.current_stream() builds a Stream object (1.2 us), the private getters
+# are what it calls underneath (0.1 us each); fall back to the public API where a torch build lacks them
+_cur_dev = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
 
 
 def _stream():
@@ -70,17 +77,32 @@ class _NoGuard(object):
 _NO_GUARD = _NoGuard()
 
 
-def _on_device(dev):
-  """Context in which the CURRENT device is `dev` (a launch goes to the current device's stream).  The usual case -- the tensors
+def _on_device(index):
+  """Context in which the CURRENT device is cuda:`index` (a launch goes to the current device's stream).  The usual case -- the tensors
   already live on the current device -- costs one integer compare instead of torch.cuda.device()'s get / set / restore."""
-  return _NO_GUARD if dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+  return _NO_GUARD if index == _cur_dev() else torch.cuda.device(index)
 
 
-def _same_device(ref, **named):
-  """Every tensor argument must live on the device of `thb`: the kernel receives raw addresses."""
+def _same_device(dev, **named):
+  """Every tensor argument must live on the device of `thb` (index `dev`): the kernel receives raw addresses."""
   for name, t in named.items():
-    if t is not None and torch.is_tensor(t) and t.device != ref.device:
-      raise RuntimeError('dgpmp2_amd: `%s` is on %s but `thb` is on %s; all inputs of one call must share a device' % (name, t.device, ref.device))
+    if t is not None and t.get_device() != dev:
+      raise RuntimeError('dgpmp2_amd: `%s` is on %s but `thb` is on cuda:%d; all inputs of one call must share a device' % (name, t.device, dev))
+
+
+def _ptr(t):
+  return None if t is None else t.data_ptr()
+
+
+def _launch(dev, fn, *args):
+  """One C-ABI call through the trampoline with cuda:`dev` as the current device; a non-zero status raises DgpError."""
+  if dev == _cur_dev():
+    rc = fn(*args)
+  else:
+    with torch.cuda.device(dev):
+      rc = fn(*args)
+  if rc:
+    _capi.get_api().check(rc)
 
 
 class _GNStep(torch.autograd.Function):
@@ -88,73 +110,107 @@ class _GNStep(torch.autograd.Function):
 
   @staticmethod
   def launch(layer, static, th, start, goal, sdf, qc, ow, eps):
-    """The forward launch itself (no autograd bookkeeping): -> dth, err, eex, and what the backward needs to keep alive."""
+    """The forward launch itself (no autograd bookkeeping): -> dth, err, eex, and what the backward needs (contiguous inputs,
+    the marshalled SDF / covariance arguments with the tensors they keep alive)."""
     B = th.shape[0]
-    solver = layer._solver(th.dtype)
-    _same_device(th, startb=start, goalb=goal, sdfb=sdf, qc_inv_trajb=qc, obscov_inv_trajb=ow, eps_trajb=eps)
-    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
-    covs, cov_keep = layer._covs_arg(solver, qc, ow, eps, th.dtype, B, static)
+    dtype = th.dtype
+    solver = layer._solvers.get(dtype) or layer._solver(dtype)
+    dev = th.get_device()
+    if start.get_device() != dev or goal.get_device() != dev:
+      _same_device(dev, startb=start, goalb=goal)
+    sd = layer._sdf_args(sdf, dtype, B, dev)
+    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
-    err = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
-    eex = torch.empty(B, 1, 1, dtype=th.dtype, device=th.device)
-    info = torch.empty(B, dtype=torch.int32, device=th.device)
-    with _on_device(th.device):             # the launch goes to the CURRENT device's stream: make that the tensors' device
-      solver.gn_step(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, dth.data_ptr(), err.data_ptr(), eex.data_ptr(),
-                     info.data_ptr(), _stream())
-    object.__setattr__(layer, 'last_info', info)      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
+    proto = layer._err_protos.get((B, dtype, dev))
+    if proto is None: proto = layer._err_proto(B, dtype, dev, thc)
+    err = torch.empty_like(proto)           # (empty_like of a cached (B,1,1) tensor: 1.3 us; new_empty / torch.empty with a shape: 2.1 us)
+    eex = torch.empty_like(proto)
+    stream = _raw_stream(dev)
+    info = layer._info_buffer(B, dev, stream, thc)
+    _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
+    layer.__dict__['last_info'] = info      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
-    return dth, err, eex, (thc, stc, goc), (sdf_keep, cov_keep)
+    return dth, err, eex, (thc, stc, goc), (sd, cv)
 
   @staticmethod
   def forward(ctx, layer, static, th, start, goal, sdf, qc, ow, eps):
-    dth, err, eex, (thc, stc, goc), keep = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
+    dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
     ctx.layer = layer
-    ctx.static = static
-    ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)
-    ctx.keep = keep
+    ctx.args = args                               # marshalled SDF / covariance arguments (and the converted copies they point into)
+    ctx.shapes = (start.shape, goal.shape, None if sdf is None else sdf.shape, None if qc is None else qc.shape,
+                  None if ow is None else ow.shape, None if eps is None else eps.shape)
+    ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)     # (inputs saved so that an in-place change before backward() raises)
     ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
     ctx.set_materialize_grads(False)              # an unused output arrives as None: no adjoint solve for an err_ext-only loss
     return dth, err, eex
 
   @staticmethod
-  @once_differentiable                            # the backward is a raw kernel: double backward raises instead of returning zeros
   def backward(ctx, g_dth, g_err, g_eex):
+    # The backward is a raw kernel: a double backward must raise instead of silently returning zeros.  torch's once_differentiable
+    # does that, at ~8 us of wrapper per call; grad mode is only enabled inside backward() under create_graph=True, so the wrapper
+    # is only paid there.
+    if torch.is_grad_enabled():
+      return _GNStep._backward_once(ctx, g_dth, g_err, g_eex)
+    return _GNStep._backward_impl(ctx, g_dth, g_err, g_eex)
+
+  @staticmethod
+  def _backward_impl(ctx, g_dth, g_err, g_eex):
     layer = ctx.layer
     th, start, goal, sdf, qc, ow, eps, dth = ctx.saved_tensors
+    sd, cv = ctx.args
     B, n, d = th.shape
-    solver = layer._solver(th.dtype)
-    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
-    covs, cov_keep = layer._covs_arg(solver, qc, ow, eps, th.dtype, B, ctx.static)
-    need = (None,) + tuple(ctx.needs_input_grad[2:])      # -> need[1..7] = th, start, goal, sdf, qc, ow, eps
-    g_dth = None if g_dth is None else g_dth.contiguous().to(th.dtype)
-    g_eex = None if g_eex is None else g_eex.contiguous().to(th.dtype)
-    mk = lambda ref, on: torch.empty_like(ref, memory_format=torch.contiguous_format) if on else None
-    g_th, g_st, g_go = mk(th, need[1]), mk(start, need[2]), mk(goal, need[3])
-    shared = sdf.stride(0) == 0 or sdf.shape[0] == 1
-    g_sdf = None
-    copies = _SDF_GRAD_COPIES if shared else 1     # shared grid: one partial grid per XCD (XCD-local atomics), summed below
-    if need[4]:
-      g_sdf = torch.zeros((copies if shared else B, 1) + tuple(sdf.shape[-2:]), dtype=th.dtype, device=th.device)
-    static_qc = covs.qc_mode == _capi.DGP_QC_STATIC
-    g_qc = torch.empty(qc.shape, dtype=th.dtype, device=th.device) if (need[5] and not static_qc) else None
-    g_ow = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[6] and covs.obs_w) else None
-    g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[7] and covs.eps) else None
-    p = lambda t: None if t is None else t.data_ptr()
-    with _on_device(th.device):
-      solver.gn_step_backward(B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf_arg, covs, dth.data_ptr(), p(g_dth), p(g_eex), p(g_th), p(g_st),
-                              p(g_go), p(g_sdf), 0 if shared else sdf.shape[-1] * sdf.shape[-2], p(g_qc), p(g_ow), p(g_eps), _stream(),
-                              g_sdf_copies=copies)
-    if g_sdf is not None and shared:
-      g_sdf = g_sdf.sum(0, keepdim=True)
-    if g_sdf is not None and shared and sdf.shape[0] != 1:
-      # the kernel already accumulated all B trajectories into the one shared grid; autograd's expand-backward will sum
-      # the B slices of whatever is returned here, so hand it B equal shares
-      g_sdf = (g_sdf / sdf.shape[0]).expand(sdf.shape)
-    r = lambda g, ref: None if g is None else g.reshape(ref.shape).to(ref.dtype)
-    return (None, None, g_th, g_st, g_go, r(g_sdf, sdf) if g_sdf is not None else None, r(g_qc, qc), r(g_ow, ow), r(g_eps, eps))
+    dtype = th.dtype
+    solver = layer._solvers[dtype]
+    dev = th.get_device()
+    need = ctx.needs_input_grad                   # (layer, static, th, start, goal, sdf, qc, ow, eps)
+    if g_dth is not None and (g_dth.dtype is not dtype or not g_dth.is_contiguous()): g_dth = g_dth.contiguous().to(dtype)
+    if g_eex is not None and (g_eex.dtype is not dtype or not g_eex.is_contiguous()): g_eex = g_eex.contiguous().to(dtype)
+    g_th = torch.empty_like(th) if need[2] else None
+    g_st = torch.empty_like(start) if need[3] else None
+    g_go = torch.empty_like(goal) if need[4] else None
+    shared = sd[3] == 0
+    g_sdf, copies, g_stride = None, 1, 0
+    if need[5]:
+      H, W = sd[1], sd[2]
+      copies = _SDF_GRAD_COPIES if shared else 1  # shared grid: two partial grids per XCD (XCD-local atomics), summed below
+      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
+      g_stride = 0 if shared else H * W
+    g_qc = th.new_empty(ctx.shapes[3]) if (need[6] and cv[1] is not None) else None
+    g_ow = th.new_empty((B, n)) if (need[7] and cv[2] is not None) else None
+    g_eps = th.new_empty((B, n)) if (need[8] and cv[3] is not None) else None
+    _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf), g_stride, copies,
+            _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _raw_stream(dev))
+    if g_sdf is not None:
+      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    shp = ctx.shapes
+    r = lambda g, i, ref: None if g is None else (g.reshape(shp[i]) if ref.dtype is dtype else g.reshape(shp[i]).to(ref.dtype))
+    return (None, None, g_th, r(g_st, 0, start), r(g_go, 1, goal), g_sdf, r(g_qc, 3, qc), r(g_ow, 4, ow), r(g_eps, 5, eps))
+
+
+_GNStep._backward_once = staticmethod(once_differentiable(_GNStep._backward_impl))
+
+
+def _finish_sdf_grad(g, sdf, shared):
+  """Partial SDF-gradient grids of a backward launch -> the gradient in the layout autograd expects for `sdf`."""
+  if shared:
+    g = g.sum(0, keepdim=True)
+  if sdf.shape[1] != 1:       # only channel 0 is read (obstacle_cost.py:35): the other channels get a zero gradient
+    full = g.new_zeros((g.shape[0],) + tuple(sdf.shape[1:]))
+    full[:, 0:1] = g
+    g = full
+  if shared and sdf.shape[0] != 1:
+    # the kernel already accumulated all B trajectories into the one shared grid; autograd's expand-backward will sum
+    # the B slices of whatever is returned here, so hand it B equal shares
+    g = (g / sdf.shape[0]).expand(sdf.shape)
+  return g if g.dtype is sdf.dtype else g.to(sdf.dtype)
+
+
+_NO_COVS_KEEP = _NO_COVS + ((),)
 
 
 class _EvalErrors(torch.autograd.Function):
@@ -166,46 +222,54 @@ class _EvalErrors(torch.autograd.Function):
 
   @staticmethod
   def forward(ctx, layer, th, start, goal, sdf, eps):
-    eps_arg = None if (eps is None or getattr(eps, '_dgp_static', False)) else eps
-    o = layer._eval(th, sdf, start, goal, None, None, eps_arg)
+    eps_arg = None if (eps is None or '_dgp_static' in eps.__dict__) else eps
+    o, thc, stc, goc, sd, cv = layer._eval_launch(th, sdf, start, goal, None, None, eps_arg)
     ctx.layer = layer
-    ctx.has_eps = eps_arg is not None
-    ctx.save_for_backward(th, start, goal, sdf, eps_arg)
+    ctx.args = (sd, cv)
+    ctx.shapes = (start.shape, goal.shape, None if eps_arg is None else eps_arg.shape)
+    ctx.save_for_backward(thc, stc, goc, sdf, eps_arg)
     ctx.set_materialize_grads(False)
     return o[1], o[2], o[3], o[4]            # (the three that read the grid are None without one)
 
   @staticmethod
-  @once_differentiable
   def backward(ctx, g_eex, g_usg, g_ugp, g_uobs):
+    if torch.is_grad_enabled():                       # create_graph=True: see _GNStep.backward
+      return _EvalErrors._backward_once(ctx, g_eex, g_usg, g_ugp, g_uobs)
+    return _EvalErrors._backward_impl(ctx, g_eex, g_usg, g_ugp, g_uobs)
+
+  @staticmethod
+  def _backward_impl(ctx, g_eex, g_usg, g_ugp, g_uobs):
     layer = ctx.layer
     th, start, goal, sdf, eps = ctx.saved_tensors
+    sd, cv = ctx.args
     B, n, d = th.shape
-    solver = layer._solver(th.dtype)
-    sdf_arg, sdf_keep = layer._sdf_arg(solver, sdf, th.dtype, B)
-    covs, cov_keep = layer._covs_arg(solver, None, None, eps, th.dtype, B, (True, True, eps is None))
+    dtype = th.dtype
+    solver = layer._solvers[dtype]
+    dev = th.get_device()
     need = ctx.needs_input_grad                       # (layer, th, start, goal, sdf, eps)
-    cot = [None if g is None else g.contiguous().to(th.dtype) for g in (g_eex, g_usg, g_ugp, g_uobs)]
-    thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
-    mk = lambda ref, on: torch.empty_like(ref, memory_format=torch.contiguous_format) if on else None
-    g_th, g_st, g_go = mk(thc, need[1]), mk(stc, need[2]), mk(goc, need[3])
-    g_sdf, shared, copies = None, True, 1
-    if sdf is not None:
-      shared = sdf.stride(0) == 0 or sdf.shape[0] == 1
+    cot = [None if g is None else (g if (g.dtype is dtype and g.is_contiguous()) else g.contiguous().to(dtype)) for g in (g_eex, g_usg, g_ugp, g_uobs)]
+    g_th = torch.empty_like(th) if need[1] else None
+    g_st = torch.empty_like(start) if need[2] else None
+    g_go = torch.empty_like(goal) if need[3] else None
+    shared = sd[3] == 0
+    g_sdf, copies, g_stride = None, 1, 0
+    if sdf is not None and need[4]:
+      H, W = sd[1], sd[2]
       copies = _SDF_GRAD_COPIES if shared else 1
-      if need[4]:
-        g_sdf = torch.zeros((copies if shared else B, 1) + tuple(sdf.shape[-2:]), dtype=th.dtype, device=th.device)
-    g_eps = torch.empty(B, n, dtype=th.dtype, device=th.device) if (need[5] and eps is not None) else None
-    p = lambda t: None if t is None else t.data_ptr()
-    with _on_device(th.device):
-      solver.eval_errors_backward(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, p(cot[0]), p(cot[1]), p(cot[2]), p(cot[3]),
-                                  p(g_th), p(g_st), p(g_go), p(g_sdf), 0 if (sdf is None or shared) else sdf.shape[-1] * sdf.shape[-2], p(g_eps),
-                                  _stream(), g_sdf_copies=copies)
-    if g_sdf is not None and shared:
-      g_sdf = g_sdf.sum(0, keepdim=True)
-      if sdf.shape[0] != 1:                           # expand()ed view: autograd sums the B slices of what is returned (see _GNStep.backward)
-        g_sdf = (g_sdf / sdf.shape[0]).expand(sdf.shape)
-    r = lambda g, ref: None if g is None else g.reshape(ref.shape).to(ref.dtype)
-    return (None, g_th, r(g_st, start), r(g_go, goal), r(g_sdf, sdf) if g_sdf is not None else None, r(g_eps, eps) if g_eps is not None else None)
+      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
+      g_stride = 0 if shared else H * W
+    g_eps = th.new_empty((B, n)) if (need[5] and eps is not None) else None
+    _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf),
+            g_stride, copies, _ptr(g_eps), _raw_stream(dev))
+    if g_sdf is not None:
+      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    shp = ctx.shapes
+    r = lambda g, i, ref: None if g is None else (g.reshape(shp[i]) if ref.dtype is dtype else g.reshape(shp[i]).to(ref.dtype))
+    return (None, g_th, r(g_st, 0, start), r(g_go, 1, goal), g_sdf, r(g_eps, 2, eps))
+
+
+_EvalErrors._backward_once = staticmethod(once_differentiable(_EvalErrors._backward_impl))
 
 
 class PlanLayer(nn.Module):
@@ -238,17 +302,24 @@ class PlanLayer(nn.Module):
     if self.use_vel_limits: self.M = self.M + self.dof * self.num_traj_states
     self.N = self.state_dim * self.num_traj_states
     self.dynamics_mode = learn_params['dgpmp2']['dynamics_mode'] if learn_params is not None else None
+    self._q_full = learn_params is not None and self.dynamics_mode == 'q_full'        # plan_layer.py:90
     self.check_spd = check_spd
     self.last_info = None
-    self._solvers = {}
+    self._last = None
+    self._solvers = {}                 # torch dtype -> _capi.Solver
+    self._sdf_cache = None             # marshalled arguments of the last SDF tensor seen (see _sdf_args)
+    self._err_protos = {}              # (B, dtype, device index) -> (B,1,1) prototype for torch.empty_like
+    self._info_bufs = {}               # (B, device index, raw stream) -> the int32 flag buffer launches on that stream write
     q = gp_params['Q_c_inv']
     self._qc_rows = [[float(v) for v in row] for row in (q.tolist() if torch.is_tensor(q) else q)]
-    self._solver(torch.float64)        # validates the configuration now (and fails loudly if the library is missing)
+    self._pc = _capi.get_pycall()      # fails loudly if the library / trampoline have not been built
+    self._solver(torch.float64)        # validates the configuration now
 
   # -- C-ABI plumbing -------------------------------------------------------------------------------
   def _solver(self, dtype):
-    code = _io_code(dtype)
-    if code not in self._solvers:
+    s = self._solvers.get(dtype)
+    if s is None:
+      code = _io_code(dtype)
       gp, ob = self.gp_params, self.obs_params
       cfg = _capi.make_config(
           num_states=self.num_traj_states, dof=self.dof, io_dtype=code, total_time_sec=_f(self.total_time_sec),
@@ -260,15 +331,37 @@ class PlanLayer(nn.Module):
           v_x=_f(gp['v_x']) if self.use_vel_limits else 0.0, v_y=_f(gp['v_y']) if self.use_vel_limits else 0.0, nlinks=self.nlinks)
       s = _capi.Solver(cfg)
       assert s.M == self.M
-      self._solvers[code] = s
-    return self._solvers[code]
+      self._solvers[dtype] = s
+    return s
 
-  def _sdf_arg(self, solver, sdfb, dtype, B):
-    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35).  An expand()ed / single grid is passed as shared.
-    None: no grid (dgp_eval_errors without obstacle outputs only)."""
+  def _err_proto(self, B, dtype, dev, like):
+    """A (B,1,1) tensor whose only purpose is to be the argument of torch.empty_like (the cheapest way to allocate err / err_ext)."""
+    if len(self._err_protos) > 64: self._err_protos.clear()
+    t = self._err_protos[(B, dtype, dev)] = torch.empty((B, 1, 1), dtype=dtype, device=like.device)
+    return t
+
+  def _info_buffer(self, B, dev, stream, like):
+    """The (B) int32 SPD flags a launch writes (`last_info`).  One buffer per (batch, device, stream), reused by the next forward() on
+    that stream (stream order makes that safe; clone() `last_info` to keep it across calls)."""
+    k = (B, dev, stream)
+    t = self._info_bufs.get(k)
+    if t is None:
+      if len(self._info_bufs) > 64: self._info_bufs.clear()
+      t = self._info_bufs[k] = torch.empty(B, dtype=torch.int32, device=like.device)
+    return t
+
+  def _sdf_args(self, sdfb, dtype, B, dev):
+    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35) -> (address, H, W, batch stride in elements, keep-alive tensor); an
+    expand()ed / single grid is passed as shared (stride 0).  None: no grid (dgp_eval_errors without obstacle outputs only).
+    The result for the LAST tensor seen is cached (same object, same version counter, same storage address, same dtype / batch):
+    a GN loop passes the same grid tensor every iteration, and slicing + checking it costs 5 us -- half a kernel."""
     if sdfb is None:
-      return solver.sdf_arg(None, 2, 2, 0), None
+      return _NO_SDF
+    c = self._sdf_cache
+    if c is not None and c[0]() is sdfb and c[1] == sdfb._version and c[2] == sdfb.data_ptr() and c[3] is dtype and c[4] == B and c[5] == dev:
+      return c[6]
     _require_cuda(sdfb, 'sdfb')
+    if sdfb.get_device() != dev: _same_device(dev, sdfb=sdfb)
     if sdfb.dim() != 4: raise ValueError('sdfb must be (B,1,H,W)')
     H, W = sdfb.shape[-2], sdfb.shape[-1]
     shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
@@ -276,50 +369,66 @@ class PlanLayer(nn.Module):
       raise ValueError('sdfb has %d grids for a batch of %d trajectories (expected %d, or 1 / an expand()ed view for a shared grid)'
                        % (sdfb.shape[0], B, B))
     t = sdfb[0:1, 0:1] if shared else sdfb[:, 0:1]
+    t = t.detach()
     if t.dtype != dtype or not t.is_contiguous():
       t = t.to(dtype).contiguous()
-    return solver.sdf_arg(t.data_ptr(), H, W, 0 if shared else t.stride(0)), t
+    own = t.data_ptr() != sdfb.data_ptr()       # a converted copy: the cache entry owns it; a view lives as long as sdfb does
+    res = (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), t if own else None)
+    me = weakref.ref(self)
+
+    def _drop(_, me=me):                        # the tensor died: let go of the converted copy
+      s = me()
+      if s is not None: s.__dict__['_sdf_cache'] = None
+    try:
+      self.__dict__['_sdf_cache'] = (weakref.ref(sdfb, _drop), sdfb._version, sdfb.data_ptr(), dtype, B, dev, res)
+    except TypeError:
+      self.__dict__['_sdf_cache'] = None
+    return res if own else res[:4] + (t,)       # (the caller's copy of the result keeps a view alive for the duration of the call)
 
   @staticmethod
   def static_flags(qc, ow, eps):
     """(qc, ow, eps) -> which of them stand for the handle's static constants: None, or a tensor that
     DiffGPMP2Planner tagged as the expand()ed view of its own static covariance."""
-    return tuple(t is None or getattr(t, '_dgp_static', False) for t in (qc, ow, eps))
+    return (qc is None or '_dgp_static' in qc.__dict__, ow is None or '_dgp_static' in ow.__dict__, eps is None or '_dgp_static' in eps.__dict__)
 
-  def _covs_arg(self, solver, qc, ow, eps, dtype, B, static=(False, False, False)):
-    """Covariance tensors -> DgpCovs.  A static entry selects the constants of the handle (no per-state tensor is streamed)."""
-    if static == (True, True, True):
-      return _ALL_STATIC_COVS, ()
+  def _cov_args(self, qc, ow, eps, dtype, B, dev, static=(False, False, False)):
+    """Covariance tensors -> (qc_mode, qc_inv, obs_w, eps addresses, keep-alive list).  A static entry selects the constants of the
+    handle (no per-state tensor is streamed)."""
+    if static == _ALL_STATIC:
+      return _NO_COVS_KEEP
     n, dof, d = self.num_traj_states, self.dof, self.state_dim
     keep = []
 
-    def prep(t, shape_tail, name, is_static=False):
-      if t is None or is_static:
-        return None
+    def prep(t, count, name):
       _require_cuda(t, name)
+      if t.get_device() != dev: _same_device(dev, **{name: t})
       if t.shape[0] != B: raise ValueError('%s has batch %d, expected %d' % (name, t.shape[0], B))
-      t = t.to(dtype).contiguous()
-      if t.numel() != B * shape_tail: raise ValueError('%s has %d elements, expected %d' % (name, t.numel(), B * shape_tail))
+      if t.numel() != B * count: raise ValueError('%s has %d elements, expected %d' % (name, t.numel(), B * count))
+      t = t.detach()
+      if t.dtype is not dtype: t = t.to(dtype)
+      t = t.contiguous()
       keep.append(t)
       return t.data_ptr()
 
-    mode = _capi.DGP_QC_STATIC
-    qc_p = None
+    mode, qc_p, ow_p, ep_p = _capi.DGP_QC_STATIC, None, None, None
     if qc is not None and not static[0]:
-      q_full = self.learn_params is not None and self.dynamics_mode == 'q_full'        # plan_layer.py:90
-      mode = _capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE
-      qc_p = prep(qc, (n - 1) * (d * d if q_full else dof * dof), 'qc_inv_trajb')
-    return solver.covs_arg(mode, qc_p, prep(ow, n * self.nlinks, 'obscov_inv_trajb', static[1]),
-                           prep(eps, n * self.nlinks, 'eps_trajb', static[2])), keep
+      mode = _capi.DGP_QC_QFULL if self._q_full else _capi.DGP_QC_PERSTATE
+      qc_p = prep(qc, (n - 1) * (d * d if self._q_full else dof * dof), 'qc_inv_trajb')
+    if ow is not None and not static[1]: ow_p = prep(ow, n * self.nlinks, 'obscov_inv_trajb')
+    if eps is not None and not static[2]: ep_p = prep(eps, n * self.nlinks, 'eps_trajb')
+    return (mode, qc_p, ow_p, ep_p, keep)
 
   def _check_inputs(self, thb, startb, goalb):
-    _require_cuda(thb, 'thb'); _require_cuda(startb, 'startb'); _require_cuda(goalb, 'goalb')
-    B = thb.shape[0]
-    if tuple(thb.shape[1:]) != (self.num_traj_states, self.state_dim):
+    if not (thb.is_cuda and startb.is_cuda and goalb.is_cuda):
+      _require_cuda(thb, 'thb'); _require_cuda(startb, 'startb'); _require_cuda(goalb, 'goalb')
+    shp = thb.shape
+    if len(shp) != 3 or shp[1] != self.num_traj_states or shp[2] != self.state_dim:
       raise ValueError('thb must be (B,%d,%d), got %s' % (self.num_traj_states, self.state_dim, tuple(thb.shape)))
-    if startb.numel() != B * self.state_dim or goalb.numel() != B * self.state_dim:
+    nd = shp[0] * self.state_dim
+    if startb.numel() != nd or goalb.numel() != nd:
       raise ValueError('startb/goalb must be (B,1,%d)' % self.state_dim)
-    if startb.dtype != thb.dtype or goalb.dtype != thb.dtype:
+    dt = thb.dtype
+    if startb.dtype is not dt or goalb.dtype is not dt:
       raise TypeError('thb, startb, goalb must share one dtype')
 
   # -- the reference's public surface -----------------------------------------------------------------
@@ -330,29 +439,41 @@ class PlanLayer(nn.Module):
     static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
     # (start / goal / eps are kept WITH their graphs, as set_mean / set_eps do: error_ext_batch and the unweighted errors are
     #  differentiable w.r.t. them; qc_inv / obscov_inv only feed error_batch, which runs under no_grad, :275)
-    det = lambda t, st: None if (t is None or st) else t.detach()
-    object.__setattr__(self, '_last', (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
-                                       None if (eps_trajb is None or static[2]) else eps_trajb))
-    needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad
-                                                  for t in (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb))
-    if not needs_graph:        # planning / validation loops: no autograd node, one launch
-      return _GNStep.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:3]
-    return _GNStep.apply(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+    if static == _ALL_STATIC:
+      self.__dict__['_last'] = (startb, goalb, None, None, None)
+    else:
+      det = lambda t, st: None if (t is None or st) else t.detach()
+      self.__dict__['_last'] = (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
+                                None if (eps_trajb is None or static[2]) else eps_trajb)
+    if torch.is_grad_enabled() and (thb.requires_grad or startb.requires_grad or goalb.requires_grad or (sdfb is not None and sdfb.requires_grad) or
+                                    any(t is not None and t.requires_grad for t in (qc_inv_trajb, obscov_inv_trajb, eps_trajb))):
+      return _GNStep.apply(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+    # planning / validation loops: no autograd node, one launch
+    return _GNStep.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:3]
+
+  def _eval_launch(self, thb, sdfb, startb, goalb, qc, ow, eps):
+    """One dgp_eval_errors launch -> ([err, err_ext, start_goal_error, gp_error, obs_error] (None where a grid is needed and sdfb is
+    None), the contiguous inputs, the marshalled SDF / covariance arguments)."""
+    B = thb.shape[0]
+    dtype = thb.dtype
+    solver = self._solvers.get(dtype) or self._solver(dtype)
+    dev = thb.get_device()
+    if dev < 0: _require_cuda(thb, 'thb')
+    if startb.get_device() != dev or goalb.get_device() != dev: _same_device(dev, startb=startb, goalb=goalb)
+    sd = self._sdf_args(sdfb, dtype, B, dev)
+    cv = self._cov_args(qc, ow, eps, dtype, B, dev, self.static_flags(qc, ow, eps))
+    grid = sdfb is not None
+    thc, stc, goc = thb.contiguous(), startb.contiguous(), goalb.contiguous()
+    proto = self._err_protos.get((B, dtype, dev))
+    if proto is None: proto = self._err_proto(B, dtype, dev, thc)
+    outs = [torch.empty_like(proto) if w else None for w in (grid, grid, True, True, grid)]
+    _launch(dev, self._pc.eval_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(outs[4]), _raw_stream(dev))
+    return outs, thc, stc, goc, sd, cv
 
   def _eval(self, thb, sdfb, startb, goalb, qc, ow, eps):
     """-> [err, err_ext, start_goal_error, gp_error, obs_error]; without a grid (sdfb None) the three that read it are None."""
-    B = thb.shape[0]
-    solver = self._solver(thb.dtype)
-    _same_device(thb, startb=startb, goalb=goalb, sdfb=sdfb, qc_inv_trajb=qc, obscov_inv_trajb=ow, eps_trajb=eps)
-    sdf_arg, k1 = self._sdf_arg(solver, sdfb, thb.dtype, B)
-    covs, k2 = self._covs_arg(solver, qc, ow, eps, thb.dtype, B, self.static_flags(qc, ow, eps))
-    want = [sdfb is not None, sdfb is not None, True, True, sdfb is not None]
-    outs = [torch.empty(B, 1, 1, dtype=thb.dtype, device=thb.device) if w else None for w in want]
-    thc, stc, goc = thb.contiguous(), startb.contiguous(), goalb.contiguous()
-    with _on_device(thb.device):
-      solver.eval_errors(B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sdf_arg, covs, *[None if o is None else o.data_ptr() for o in outs],
-                         stream=_stream())
-    return outs
+    return self._eval_launch(thb, sdfb, startb, goalb, qc, ow, eps)[0]
 
   def errors(self, thb, startb, goalb, sdfb, qc_inv_trajb=None, obscov_inv_trajb=None, eps_trajb=None):
     """(err, err_ext, start_goal_error, gp_error, obs_error), each (B,1,1), in one launch (dgp_eval_errors).  Unlike the
@@ -406,3 +527,6 @@ class PlanLayer(nn.Module):
     st, go, qc, ow, eps = self._last_or_raise()
     o = self._eval_diff(thb, sdfb, st, go, eps)
     return o[1].reshape(thb.shape[0], 1), o[2], o[3]
+
+
+_NO_SDF = (None, 2, 2, 0, None)

@@ -125,6 +125,7 @@ for case in range(args.cases):
       # (the SDF gradient is a sum of signed tap contributions: judged against the size of the summands, for which the trajectory
       #  gradient stands in, when the sum itself cancels)
       eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(ro['th']).max() if key == 'sdf' else 0.0, 1e-300)
-      assert eb < (1e-6 if io == 'f64' else 3e-4) * (30 if p.reg < 0.01 else 1),  ('backward differs from the autograd oracle', case, key, eb, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, copies=kwb['sdf_copies'], amax=float(np.abs(a_).max()), bmax=float(np.abs(b_).max()), thmax=float(np.abs(ro['th']).max())))
+      # (fp32 I/O: the kernels rebuild rho = e - H dtheta from the fp32-ROUNDED forward output, the oracle from its own fp64 one: cond(Lambda) * 6e-8)
+      assert eb < (1e-6 if io == 'f64' else 2e-3) * (30 if p.reg < 0.01 else 1),  ('backward differs from the autograd oracle', case, key, eb, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, copies=kwb['sdf_copies'], amax=float(np.abs(a_).max()), bmax=float(np.abs(b_).max()), thmax=float(np.abs(ro['th']).max())))
 print('%d cases: %d within tolerance of the fp64 C oracle, %d beyond it but no further from the extended-precision solve than 3 x the fp64 C oracle is (%s), 0 failed; worst dtheta error / tolerance = %.2f'
       % (args.cases, args.cases - len(conditioned), len(conditioned), ','.join(map(str, conditioned)) or '-', worst))

@@ -122,5 +122,8 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
         b_ = g_o[key].reshape(a_.shape)
         if not np.all(np.isfinite(a_)): bad.append((tag, key, 'non-finite')); continue
         eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(g_o['th']).max() if key == 'sdf' else 0.0, 1e-300)
-        if not eb < (1e-6 if io == 'f64' else 3e-4): bad.append((tag, key, eb))
+        # f32 I/O: the kernels are handed the forward output dtheta ROUNDED to fp32 and rebuild rho = e - H dtheta from it, so the gradients
+        # carry cond(Lambda) * 6e-8 relative to the oracle's (which differentiates its own fp64 dtheta): up to 4e-4 on the random q_full
+        # systems here.  The fp64 run pins the mathematics at 1e-6; this one only has to catch code-generation faults (O(1) errors).
+        if not eb < (1e-6 if io == 'f64' else 2e-3): bad.append((tag, key, eb))
   assert not bad, '%d backward results differ from the autograd oracle:\n' % len(bad) + '\n'.join(map(str, bad))

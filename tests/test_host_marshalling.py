@@ -1,0 +1,176 @@
+"""Host logic of the torch-facing layer (dgpmp2_amd/gpmp2/plan_layer.py) WITHOUT a GPU: the argument marshalling of PlanLayer.forward /
+backward / the error helpers is driven with CPU tensors against a recording stand-in for the METH_FASTCALL trampoline (no kernel runs,
+no numbers are checked here -- that is what the -m gpu parity tests do through the real C-ABI).  What is pinned: argument order and
+count of every entry point as csrc/dgp_pycall.c unpacks them, the shared / per-sample SDF decision, the static-covariance short cut,
+the SDF-argument cache (hit on the same tensor, miss after an in-place change / another tensor / another dtype), the flag-buffer reuse
+per stream, gradient shapes and which gradient buffers are requested, and that the real trampoline rejects a wrong argument count."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from dgpmp2_amd import _capi
+from dgpmp2_amd.gpmp2 import plan_layer as PL
+from dgpmp2_amd.robot_models import PointRobot2D
+
+
+class FakePycall(object):
+  """Records (entry point, args); fills nothing."""
+
+  def __init__(self):
+    self.calls = []
+
+  def _rec(self, name, n):
+    def f(*a):
+      assert len(a) == n, (name, len(a), n)
+      self.calls.append((name, a))
+      return 0
+    return f
+
+  def __getattr__(self, name):
+    n = {'gn_step': 18, 'gn_solve': 22, 'eval_errors': 19, 'gn_step_backward': 26, 'eval_errors_backward': 25}[name]
+    return self._rec(name, n)
+
+
+@pytest.fixture
+def layer(monkeypatch):
+  monkeypatch.setattr(PL, '_require_cuda', lambda t, name: None)
+  monkeypatch.setattr(PL, '_cur_dev', lambda: -1)
+  monkeypatch.setattr(PL, '_raw_stream', lambda i: 77)
+  t = lambda v: torch.tensor(v, dtype=torch.float64)
+  n = 16
+  gp = {'Q_c_inv': torch.eye(2, dtype=torch.float64), 'K_s': t(0.01), 'K_g': t(0.01)}
+  ob = {'cost_sigma': t(0.01), 'epsilon_dist': t(0.4)}
+  pp = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
+  op = {'method': 'gauss_newton', 'reg': 0.1, 'max_iters': 10, 'tol_err': 1e-3, 'tol_delta': 1e-4}
+  pl = PL.PlanLayer(gp, ob, pp, op, {'x_lims': [-5.0, 5.0], 'y_lims': [-5.0, 5.0]}, PointRobot2D(t(0.4), 1, n))
+  pl.__dict__['_pc'] = FakePycall()
+  return pl
+
+
+def _inputs(B=3, n=16, G=8, dtype=torch.float32):
+  th = torch.randn(B, n, 4, dtype=dtype)
+  st, go = torch.randn(B, 1, 4, dtype=dtype), torch.randn(B, 1, 4, dtype=dtype)
+  sdf = torch.randn(1, 1, G, G + 2, dtype=dtype)
+  return th, st, go, sdf
+
+
+def test_forward_static_shared_grid_arguments(layer):
+  th, st, go, sdf = _inputs()
+  sdfb = sdf.expand(3, 1, 8, 10)
+  dth, err, eex = layer(th, st, go, None, sdfb, None, None, None)
+  (name, a), = layer._pc.calls
+  assert name == 'gn_step'
+  h = layer._solvers[torch.float32].h
+  assert a[0] == h and a[1] == 3 and a[2:5] == (th.data_ptr(), st.data_ptr(), go.data_ptr())
+  assert a[5:9] == (sdf.data_ptr(), 8, 10, 0)                                   # shared grid: stride 0
+  assert a[9:13] == (_capi.DGP_QC_STATIC, None, None, None)
+  assert a[13:17] == (dth.data_ptr(), err.data_ptr(), eex.data_ptr(), layer.last_info.data_ptr()) and a[17] == 77
+  assert dth.shape == th.shape and err.shape == (3, 1, 1) and eex.shape == (3, 1, 1) and layer.last_info.dtype == torch.int32
+  assert dth.grad_fn is None                                                     # nothing requires grad: no autograd node
+
+
+def test_sdf_cache_hits_and_misses(layer):
+  th, st, go, sdf = _inputs()
+  sdfb = sdf.expand(3, 1, 8, 10)
+  layer(th, st, go, None, sdfb, None, None, None)
+  entry = layer._sdf_cache
+  assert entry is not None and entry[0]() is sdfb
+  layer(th, st, go, None, sdfb, None, None, None)
+  assert layer._sdf_cache is entry                                               # same tensor, same version: hit
+  i0 = layer.last_info
+  sdf.add_(1.0)                                                                  # in-place change of the storage: version bump -> miss
+  layer(th, st, go, None, sdfb, None, None, None)
+  assert layer._sdf_cache is not entry
+  assert layer.last_info is i0                                                   # flag buffer reused per (batch, device, stream)
+  # a float64 grid with float32 trajectories: converted copy owned by the cache entry, dropped when the tensor dies
+  sdf64 = torch.randn(3, 1, 8, 10, dtype=torch.float64)
+  layer(th, st, go, None, sdf64, None, None, None)
+  a = layer._pc.calls[-1][1]
+  assert a[5] != sdf64.data_ptr() and a[6:9] == (8, 10, 80)                      # per-sample grids: stride H*W elements
+  assert layer._sdf_cache[6][4] is not None and layer._sdf_cache[6][4].dtype == torch.float32
+  del sdf64
+  gc.collect()
+  assert layer._sdf_cache is None
+  # fewer grids than trajectories would be read out of bounds
+  with pytest.raises(ValueError):
+    layer(th, st, go, None, torch.randn(2, 1, 8, 10), None, None, None)
+
+
+def test_per_state_covariances_and_backward_arguments(layer):
+  B, n = 3, 16
+  th, st, go, sdf = _inputs(B)
+  th.requires_grad_(True)
+  sdfb = sdf.expand(B, 1, 8, 10).clone().requires_grad_(True)                     # per-sample grids with a gradient
+  qc = torch.eye(2).expand(B, n - 1, 2, 2).contiguous().requires_grad_(True)
+  ow = torch.full((B, n, 1, 1), 1e4, requires_grad=True)
+  eps = torch.full((B, n, 1, 1), 0.4)                                             # no gradient asked for eps
+  dth, err, eex = layer(th, st, go, None, sdfb, qc, ow, eps)
+  name, a = layer._pc.calls[-1]
+  assert name == 'gn_step' and a[9:13] == (_capi.DGP_QC_PERSTATE, qc.data_ptr(), ow.data_ptr(), eps.data_ptr())
+  assert dth.grad_fn is not None and not err.requires_grad and eex.requires_grad
+  (dth.sum() + eex.sum()).backward()
+  name, b = layer._pc.calls[-1]
+  assert name == 'gn_step_backward'
+  assert b[:13] == a[:13]                                                         # same inputs as the forward launch
+  assert b[13] == dth.data_ptr() and b[14] is not None and b[15] is not None     # dtheta, both cotangents
+  assert b[16] is not None and b[17] is None and b[18] is None                   # g_th only (start / goal do not require grad)
+  assert b[19] is not None and b[20] == 80 and b[21] == 1                        # per-sample SDF gradient: stride H*W, one copy
+  assert b[22] is not None and b[23] is not None and b[24] is None and b[25] == 77   # g_qc, g_ow, no g_eps; stream
+  assert th.grad.shape == th.shape and sdfb.grad.shape == sdfb.shape and qc.grad.shape == qc.shape and ow.grad.shape == ow.shape
+  assert eps.grad is None
+
+
+def test_shared_grid_gradient_uses_partial_copies(layer):
+  B = 3
+  th, st, go, sdf = _inputs(B)
+  sdf.requires_grad_(True)
+  dth, err, eex = layer(th, st, go, None, sdf.expand(B, 1, 8, 10), None, None, None)
+  dth.sum().backward()
+  name, b = layer._pc.calls[-1]
+  assert name == 'gn_step_backward' and b[14] is not None and b[15] is None     # err_ext unused: no cotangent materialised
+  assert b[16] is None and b[19] is not None and b[20] == 0 and b[21] == PL._SDF_GRAD_COPIES
+  assert sdf.grad.shape == sdf.shape
+
+
+def test_error_helpers_arguments(layer):
+  B = 3
+  th, st, go, sdf = _inputs(B)
+  with pytest.raises(RuntimeError):
+    layer.error_batch(th, sdf)                                                   # forward() first, like the reference
+  eps = torch.full((B, 16, 1, 1), 0.3, requires_grad=True)
+  layer(th, st, go, None, sdf, None, None, eps)
+  e = layer.error_batch(th, sdf)
+  name, a = layer._pc.calls[-1]
+  assert name == 'eval_errors' and a[12] == eps.data_ptr() and a[13] == e.data_ptr() and e.grad_fn is None
+  g = layer.gp_error(th)
+  name, a = layer._pc.calls[-1]
+  assert a[5] is None and a[13] is None and a[14] is None and a[17] is None and a[16] == g.data_ptr()    # no grid: none of the outputs that read it
+  sg, gp, ob = layer.unweighted_errors(th.clone().requires_grad_(True), sdf)
+  assert sg.shape == (B, 1) and gp.shape == (B, 1, 1) and ob.requires_grad
+  (sg.sum() + ob.sum()).backward()
+  name, b = layer._pc.calls[-1]
+  assert name == 'eval_errors_backward' and b[13] is None and b[14] is not None and b[15] is None and b[16] is not None
+  assert b[17] is not None and b[20] is None and b[23] is not None              # g_th, no SDF gradient, g_eps (the current eps carries a graph)
+  assert eps.grad is not None and eps.grad.shape == eps.shape
+
+
+def test_input_validation(layer):
+  th, st, go, sdf = _inputs()
+  with pytest.raises(ValueError):
+    layer(th[:, :5], st, go, None, sdf, None, None, None)
+  with pytest.raises(TypeError):
+    layer(th, st.double(), go, None, sdf, None, None, None)
+  with pytest.raises(ValueError):
+    layer(th, st, go, None, sdf, torch.eye(2).expand(2, 15, 2, 2), None, None)   # covariance batch != trajectory batch
+
+
+def test_real_trampoline_argument_counts():
+  pc = _capi.get_pycall()
+  for name, n in (('gn_step', 18), ('gn_solve', 22), ('eval_errors', 19), ('gn_step_backward', 26), ('eval_errors_backward', 25)):
+    with pytest.raises(TypeError):
+      getattr(pc, name)(*([0] * (n - 1)))
+  # a NULL handle comes back as the C-ABI's DGP_EINVAL, not as a crash
+  assert pc.gn_step(0, 1, 0, 0, 0, 0, 2, 2, 0, 0, None, None, None, 0, 0, 0, 0, 0) == _capi.DGP_EINVAL
+  assert b'null' in _capi.get_api().last_error()
