@@ -315,6 +315,34 @@ def extra_workloads(device, stream, reps=1500):
   return out
 
 
+def two_stream_rate(solver, B, th_ptrs, sp, gp, sdf_arg, device, reps=2000):
+  """Two INDEPENDENT whole-batch problems in flight (two planners, e.g. two environment sets): the headline launches alternating
+  between two HIP streams, each with its own output buffers.  A single GN loop is sequential (step k+1 needs step k), so this is NOT
+  the headline; it shows how much of the ~2 us between dependent launches (end-of-kernel release, dispatch) two streams hide."""
+  streams = [torch.cuda.Stream(device=device) for _ in range(2)]
+  outs = []
+  for _ in range(2):
+    outs.append((torch.empty(B, N_STATES, 2 * DOF, device=device), torch.empty(B, device=device), torch.empty(B, device=device),
+                 torch.zeros(B, dtype=torch.int32, device=device)))
+  raw = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams]
+  ptrs = [tuple(t.data_ptr() for t in o) for o in outs]
+
+  def launch(k):
+    i = k & 1
+    solver.gn_step(B, th_ptrs[k % GN_ITERS], sp, gp, sdf_arg, None, ptrs[i][0], ptrs[i][1], ptrs[i][2], ptrs[i][3], raw[i])
+
+  torch.cuda.synchronize()
+  for k in range(2000): launch(k)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for k in range(reps): launch(k)
+  torch.cuda.synchronize()
+  us = (time.perf_counter() - t0) / reps * 1e6
+  return {'us_per_step': us, 'gn_steps_per_s': 1e6 / us, 'streams': 2,
+          'note': 'two independent 4096-trajectory batches, launches alternating between two HIP streams (wall time over %d launches); not the headline: '
+                  'one GN loop is a chain of dependent launches' % reps}
+
+
 def planner_api_rate(device, reps=300):
   """DiffGPMP2Planner.step() through the Python mirror (reference param dicts, autograd Function, info buffer), no_grad:
   wall microseconds per call at B = 4096 -- what a caller of the reference API sees, next to the C-ABI kernel rate."""
@@ -376,7 +404,7 @@ def planner_api_backward_rate(device, reps=200):
 
   def wall(f):
     best = float('inf')
-    for _ in range(50): f()
+    for _ in range(30): f()
     for _ in range(3):
       torch.cuda.synchronize(); t0 = time.perf_counter()
       for _ in range(reps): f()
@@ -384,11 +412,20 @@ def planner_api_backward_rate(device, reps=200):
       best = min(best, (time.perf_counter() - t0) / reps * 1e6)
     return best
 
+  def tbptt_fb(K=10):      # a truncated-BPTT window as learning/train_planner.py:297-374 builds it: K chained steps, one backward
+    x = thr
+    for _ in range(K): x = x + planner.step(x, start, goal, None, sdfb)[0]
+    torch.autograd.grad(x, thr, g)
+
   a, b = wall(static_fb), wall(learned_fb)
-  return {'us_per_call': a, 'learned_covariances_us_per_call': b,
+  reps = max(20, reps // 10)
+  c = wall(tbptt_fb) / 10.0
+  return {'us_per_call': a, 'learned_covariances_us_per_call': b, 'tbptt_window10_us_per_step': c,
           'note': 'wall time of DiffGPMP2Planner.step() + torch.autograd.grad through it, B=4096: static covariances with the gradient w.r.t. the '
                   'trajectory (us_per_call), and per-state qc_inv / obscov_inv / eps tensors with gradients w.r.t. all four (learned_covariances_us_per_call); '
-                  'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine'}
+                  'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine.  tbptt_window10_us_per_step: ten chained steps '
+                  '(th <- th + dtheta) and ONE backward through all of them, per step -- the fixed cost of entering the autograd engine (~40 us for a '
+                  'trivial custom Function on this host) is paid once per window, as in the training loop'}
 
 
 def main():
@@ -526,6 +563,7 @@ def main():
                             'gn_steps_per_s_per_gpu': GN_ITERS / (fused_us * 1e-6),
                             'note': 'dgp_gn_solve: the 10 GN iterations of BASELINE configs[1] in one launch (rank 0, outside the timed region)'}
     if world == 1 and not args.no_extras:
+      out['two_streams'] = two_stream_rate(solver, B, th_ptrs, sp, gp, sdf_arg, device)
       out.update(extra_workloads(device, stream))
       out['planner_step_api'] = planner_api_rate(device)
       out['planner_step_backward_api'] = planner_api_backward_rate(device)

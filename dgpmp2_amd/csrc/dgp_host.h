@@ -10,6 +10,7 @@
 #include <new>
 #include "gn_lane.h"
 #include "gn_backward.h"
+#include "gn_long.h"
 #include "../../include/dgpmp2_hip.h"
 
 struct DgpHandle {
@@ -48,6 +49,11 @@ inline int fail(int code, const char* fmt, ...) {
 
 // Shapes the kernels are instantiated for (see DGP_FOR_EACH_SHAPE in dgpmp2_hip.hip): LPT in {16,32,64} x C in {1,2,4}.
 constexpr int kMaxStates = 256;
+// Longer trajectories run the loop kernels of gn_long.h (one trajectory per wavefront, ceil(n / 64) rows per lane), whose limit is the
+// wavefront's LDS block of (rows per lane - 1) parked (S_k^-1, z_k) slots: 16 rows per lane for d = 4 (105 KB), 10 for d = 6 (123 KB).
+constexpr int kMaxStatesLong4 = 1024, kMaxStatesLong6 = 640;
+inline int max_states(int dof) { return dof == 3 ? kMaxStatesLong6 : kMaxStatesLong4; }
+inline bool is_long(int n) { return n > kMaxStates; }
 inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || lpt == 64) && (c == 1 || c == 2 || c == 4); }
 
 // Pick (LPT, C) for n states and a batch of B trajectories: the cheapest supported shape under a two-parameter timing model
@@ -58,10 +64,16 @@ inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || 
 // More states per lane (larger C) means less arithmetic per trajectory (the local elimination is O(C) per lane while
 // every PCR round costs the same whatever LPT is) but fewer, longer wavefronts.  d = 6 has its own table (T6), every entry from the
 // round-2 sweep of the d = 6 kernels (profiles/r02_shape_sweep.txt: kernel time / turns at B = 4096, n = 16, 32, 64).
-inline DgpShape choose_shape(const DgpHandle* h, int B) {
+// `general`: the launch runs the general-covariance kernels (q_full tensors or a non-diagonal static Q_c_inv; dgp::QK_GENERAL).  For d = 6 they
+// have their own table: the sweep behind T6 timed the static (Woodbury) kernels only, and the general (16,4) kernel -- 1.4 KB of scratch per
+// lane -- is the slowest way to run q_full at B = 4096 (profiles/r03_shape_checks.txt: (16,4) 84.0 us, (32,2) 64.8 us, (32,4) 175 us, (64,1)
+// 117 us; per-state Kronecker kernels: (16,4) 47.1 vs (32,2) 46.4 us, block elimination with velocity limits: 30.3 vs 42.5 us -- T6 holds).
+inline DgpShape choose_shape(const DgpHandle* h, int B, bool general = false) {
+  if (is_long(h->cfg.num_states)) return DgpShape{64, (h->cfg.num_states + 63) / 64};      // gn_long.h: rows per lane reported as C
   if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
   static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
   static const double T6[3][3] = {{11.0, 14.2, 24.4}, {13.4, 17.1, 26.6}, {19.9, 26.1, 33.9}};  // d = 6
+  static const double T6G[3][3] = {{11.0, 14.2, 67.2}, {13.4, 25.9, 70.1}, {23.5, 26.1, 89.0}};  // d = 6, general kernels: the C = 4 / (32,2) / (64,1) entries from the round-3 check (time / turns), the rest as T6
   const int n = h->cfg.num_states;
   DgpShape best{64, 4};
   double best_cost = 1e300;
@@ -69,7 +81,7 @@ inline DgpShape choose_shape(const DgpHandle* h, int B) {
     for (int ci = 0; ci < 3; ++ci) {
       const int lpt = 16 << li, c = 1 << ci;
       if (lpt * c < n) continue;
-      const double t = h->cfg.dof == 3 ? T6[li][ci] : T4[li][ci];
+      const double t = h->cfg.dof == 3 ? (general ? T6G[li][ci] : T6[li][ci]) : T4[li][ci];
       const double waves = (double)((B + (64 / lpt) - 1) / (64 / lpt));
       const double turns = 1.25 * waves / 1024.0;
       const double cost = t * (turns > 1.0 ? turns : 1.0);
@@ -83,7 +95,7 @@ inline int step_kernel_variant(const DgpHandle* h, int B) {
   dgp::GnParams p = h->base;
   p.qc_mode = dgp::QC_STATIC;
   const DgpShape sh = choose_shape(h, B);
-  if (!dgp::use_static_kernels(p)) return dgp::QK_GENERAL;
+  if (is_long(p.n) || !dgp::use_static_kernels(p)) return dgp::QK_GENERAL;
   if (!dgp::wb_applies(p, sh.lpt, sh.c)) return dgp::QK_STATIC;
   return p.n == sh.lpt * sh.c ? dgp::QK_WB : dgp::QK_WBR;
 }
@@ -125,7 +137,9 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   if (cfg->dof != 2 && cfg->dof != 3) return fail(DGP_EUNSUPPORTED, "dof must be 2 or 3, got %d", cfg->dof);
   if (cfg->nlinks != 1) return fail(DGP_EUNSUPPORTED, "only nlinks == 1 (point robots) is implemented, got %d", cfg->nlinks);
   if (cfg->num_states < 2) return fail(DGP_EINVAL, "num_states must be >= 2, got %d", cfg->num_states);
-  if (cfg->num_states > kMaxStates) return fail(DGP_EUNSUPPORTED, "num_states > %d is not implemented, got %d", kMaxStates, cfg->num_states);
+  if (cfg->num_states > max_states(cfg->dof))
+    return fail(DGP_EUNSUPPORTED, "num_states > %d is not implemented for dof %d (LDS capacity of the long-trajectory kernels), got %d", max_states(cfg->dof),
+                cfg->dof, cfg->num_states);
   if (cfg->io_dtype != DGP_F32 && cfg->io_dtype != DGP_F64) return fail(DGP_EINVAL, "bad io_dtype %d", cfg->io_dtype);
   if ((cfg->flags & DGP_FLAG_NONHOLONOMIC) && cfg->dof != 3)
     return fail(DGP_EINVAL, "the non-holonomic factor needs the (x,y,theta) robot, dof == 3");
@@ -141,7 +155,7 @@ inline int create(const DgpConfig* cfg, DgpHandle** out) {
   const int n = cfg->num_states, dof = cfg->dof;
   h->d = 2 * dof;
   h->force_lpt = h->force_c = 0;
-  if (const char* fs = getenv("DGP_FORCE_SHAPE")) {
+  if (const char* fs = is_long(n) ? nullptr : getenv("DGP_FORCE_SHAPE")) {      // (long trajectories have one shape)
     int l = 0, c = 0;
     if (sscanf(fs, "%d,%d", &l, &c) == 2 && shape_supported(l, c) && l * c >= n) { h->force_lpt = l; h->force_c = c; }
     else { delete h; return fail(DGP_EINVAL, "DGP_FORCE_SHAPE=%s is not a supported LPT,C pair covering n=%d", fs, n); }

@@ -761,10 +761,11 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
 template <int DOF>
 DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
                        const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
-                       double (&r)[2 * DOF], ErrAcc& acc) {
+                       double (&r)[2 * DOF], ErrAcc& acc, int n_fixed = -1) {
   // priors + GP factors: everything of row g that does NOT depend on the SDF lookup (runs while the taps are in flight)
+  // n_fixed: the trajectory length when the caller knows it at compile time (exact-fit Woodbury kernels: n = 4 LPT), else -1
   constexpr int D = 2 * DOF;
-  const int n = p.n;
+  const int n = n_fixed >= 0 ? n_fixed : p.n;
   const double dt = p.dt;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
   const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
@@ -811,9 +812,9 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
 
 // diagonal block of row g without the single-state factors; m_next = 1 iff the row couples to row g+1
 template <int DOF>
-DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next) {
+DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next, int n_fixed = -1) {
   constexpr int D = 2 * DOF;
-  const int n = p.n;
+  const int n = n_fixed >= 0 ? n_fixed : p.n;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
   const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
   m_next = mN;
@@ -2526,7 +2527,11 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int j = lane_to_row<LPT>(lane & (LPT - 1));      // block row of the LPT-row system owned by this lane
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
+#if defined(DGP_ASSUME_FULL)      // experiment only (profiles/tools/kprobe.sh): what the masks of non-existent trajectories cost
+  const bool traj_ok = true;
+#else
   const bool traj_ok = b < p.B;
+#endif
   DGP_STAMP_NOWAIT(p, cx, 0);
 #if defined(__HIP_DEVICE_COMPILE__)
   // the scalars of the pixel-coordinate / tap-address arithmetic are fetched now, under the th load, instead of at their

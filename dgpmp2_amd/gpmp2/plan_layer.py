@@ -141,9 +141,13 @@ class _GNStep(torch.autograd.Function):
     dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
     ctx.layer = layer
     ctx.args = args                               # marshalled SDF / covariance arguments (and the converted copies they point into)
-    ctx.shapes = (start.shape, goal.shape, None if sdf is None else sdf.shape, None if qc is None else qc.shape,
-                  None if ow is None else ow.shape, None if eps is None else eps.shape)
-    ctx.save_for_backward(thc, stc, goc, sdf, qc, ow, eps, dth)     # (inputs saved so that an in-place change before backward() raises)
+    # Inputs: the backward needs their ADDRESSES (in ctx.args) and, for the gradient buffers, their shapes -- not SavedVariables, whose
+    # unpacking costs ~1.5 us per tensor.  What save_for_backward would add, the "modified by an inplace operation" check, is done
+    # by hand on the version counters.  (dth is an OUTPUT: it must go through save_for_backward, a plain reference would be a cycle.)
+    ctx.inputs = (thc, stc, goc, sdf, qc, ow, eps, start, goal)
+    ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, -1 if qc is None else qc._version,
+                    -1 if ow is None else ow._version, -1 if eps is None else eps._version)
+    ctx.save_for_backward(dth)
     ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
     ctx.set_materialize_grads(False)              # an unused output arrives as None: no adjoint solve for an err_ext-only loss
     return dth, err, eex
@@ -160,7 +164,9 @@ class _GNStep(torch.autograd.Function):
   @staticmethod
   def _backward_impl(ctx, g_dth, g_err, g_eex):
     layer = ctx.layer
-    th, start, goal, sdf, qc, ow, eps, dth = ctx.saved_tensors
+    dth, = ctx.saved_tensors
+    th, stc, goc, sdf, qc, ow, eps, start, goal = ctx.inputs
+    _check_versions(ctx.inputs, ctx.versions)
     sd, cv = ctx.args
     B, n, d = th.shape
     dtype = th.dtype
@@ -170,8 +176,8 @@ class _GNStep(torch.autograd.Function):
     if g_dth is not None and (g_dth.dtype is not dtype or not g_dth.is_contiguous()): g_dth = g_dth.contiguous().to(dtype)
     if g_eex is not None and (g_eex.dtype is not dtype or not g_eex.is_contiguous()): g_eex = g_eex.contiguous().to(dtype)
     g_th = torch.empty_like(th) if need[2] else None
-    g_st = torch.empty_like(start) if need[3] else None
-    g_go = torch.empty_like(goal) if need[4] else None
+    g_st = _grad_like(start, stc) if need[3] else None
+    g_go = _grad_like(goal, goc) if need[4] else None
     shared = sd[3] == 0
     g_sdf, copies, g_stride = None, 1, 0
     if need[5]:
@@ -179,17 +185,37 @@ class _GNStep(torch.autograd.Function):
       copies = _SDF_GRAD_COPIES if shared else 1  # shared grid: two partial grids per XCD (XCD-local atomics), summed below
       g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
       g_stride = 0 if shared else H * W
-    g_qc = th.new_empty(ctx.shapes[3]) if (need[6] and cv[1] is not None) else None
-    g_ow = th.new_empty((B, n)) if (need[7] and cv[2] is not None) else None
-    g_eps = th.new_empty((B, n)) if (need[8] and cv[3] is not None) else None
-    _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+    g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
+    g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
+    g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
+    _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
             cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf), g_stride, copies,
             _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _raw_stream(dev))
     if g_sdf is not None:
       g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
-    shp = ctx.shapes
-    r = lambda g, i, ref: None if g is None else (g.reshape(shp[i]) if ref.dtype is dtype else g.reshape(shp[i]).to(ref.dtype))
-    return (None, None, g_th, r(g_st, 0, start), r(g_go, 1, goal), g_sdf, r(g_qc, 3, qc), r(g_ow, 4, ow), r(g_eps, 5, eps))
+    return (None, None, g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
+
+
+def _check_versions(tensors, versions):
+  """What autograd does when a SavedVariable is unpacked: a tensor the backward reads must not have been modified in place since the forward."""
+  for t, v in zip(tensors, versions):
+    if t is not None and t._version != v:
+      raise RuntimeError('one of the variables needed for gradient computation has been modified by an inplace operation: a %s tensor '
+                         'is at version %d; expected version %d (dgpmp2_amd PlanLayer backward)' % (list(t.shape), t._version, v))
+
+
+def _grad_like(ref, like):
+  """Uninitialised gradient buffer for input `ref`, written by the kernel as a contiguous array of the launch dtype (that of `like`):
+  in ref's own shape when ref is contiguous and of that dtype (no reshape / cast afterwards), flat otherwise (see _grad_out)."""
+  if ref.dtype is like.dtype and ref.is_contiguous():
+    return torch.empty_like(ref)
+  return like.new_empty((ref.numel(),))
+
+
+def _grad_out(g, ref):
+  if g is None or g.shape == ref.shape: return g
+  g = g.reshape(ref.shape)
+  return g if g.dtype is ref.dtype else g.to(ref.dtype)
 
 
 _GNStep._backward_once = staticmethod(once_differentiable(_GNStep._backward_impl))
@@ -226,8 +252,8 @@ class _EvalErrors(torch.autograd.Function):
     o, thc, stc, goc, sd, cv = layer._eval_launch(th, sdf, start, goal, None, None, eps_arg)
     ctx.layer = layer
     ctx.args = (sd, cv)
-    ctx.shapes = (start.shape, goal.shape, None if eps_arg is None else eps_arg.shape)
-    ctx.save_for_backward(thc, stc, goc, sdf, eps_arg)
+    ctx.inputs = (thc, stc, goc, sdf, eps_arg, start, goal)      # (addresses in ctx.args; version counters checked by hand, see _GNStep.forward)
+    ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, -1 if eps_arg is None else eps_arg._version)
     ctx.set_materialize_grads(False)
     return o[1], o[2], o[3], o[4]            # (the three that read the grid are None without one)
 
@@ -240,7 +266,8 @@ class _EvalErrors(torch.autograd.Function):
   @staticmethod
   def _backward_impl(ctx, g_eex, g_usg, g_ugp, g_uobs):
     layer = ctx.layer
-    th, start, goal, sdf, eps = ctx.saved_tensors
+    th, stc, goc, sdf, eps, start, goal = ctx.inputs
+    _check_versions(ctx.inputs, ctx.versions)
     sd, cv = ctx.args
     B, n, d = th.shape
     dtype = th.dtype
@@ -249,8 +276,8 @@ class _EvalErrors(torch.autograd.Function):
     need = ctx.needs_input_grad                       # (layer, th, start, goal, sdf, eps)
     cot = [None if g is None else (g if (g.dtype is dtype and g.is_contiguous()) else g.contiguous().to(dtype)) for g in (g_eex, g_usg, g_ugp, g_uobs)]
     g_th = torch.empty_like(th) if need[1] else None
-    g_st = torch.empty_like(start) if need[2] else None
-    g_go = torch.empty_like(goal) if need[3] else None
+    g_st = _grad_like(start, stc) if need[2] else None
+    g_go = _grad_like(goal, goc) if need[3] else None
     shared = sd[3] == 0
     g_sdf, copies, g_stride = None, 1, 0
     if sdf is not None and need[4]:
@@ -258,15 +285,13 @@ class _EvalErrors(torch.autograd.Function):
       copies = _SDF_GRAD_COPIES if shared else 1
       g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
       g_stride = 0 if shared else H * W
-    g_eps = th.new_empty((B, n)) if (need[5] and eps is not None) else None
-    _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), start.data_ptr(), goal.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+    g_eps = _grad_like(eps, th) if (need[5] and eps is not None) else None
+    _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
             cv[0], cv[1], cv[2], cv[3], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf),
             g_stride, copies, _ptr(g_eps), _raw_stream(dev))
     if g_sdf is not None:
       g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
-    shp = ctx.shapes
-    r = lambda g, i, ref: None if g is None else (g.reshape(shp[i]) if ref.dtype is dtype else g.reshape(shp[i]).to(ref.dtype))
-    return (None, g_th, r(g_st, 0, start), r(g_go, 1, goal), g_sdf, r(g_eps, 2, eps))
+    return (None, g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_eps, eps))
 
 
 _EvalErrors._backward_once = staticmethod(once_differentiable(_EvalErrors._backward_impl))
@@ -404,7 +429,6 @@ class PlanLayer(nn.Module):
       if t.get_device() != dev: _same_device(dev, **{name: t})
       if t.shape[0] != B: raise ValueError('%s has batch %d, expected %d' % (name, t.shape[0], B))
       if t.numel() != B * count: raise ValueError('%s has %d elements, expected %d' % (name, t.numel(), B * count))
-      t = t.detach()
       if t.dtype is not dtype: t = t.to(dtype)
       t = t.contiguous()
       keep.append(t)

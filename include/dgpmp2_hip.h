@@ -55,7 +55,9 @@ extern "C" {
  * (plan_layer.py:14-81).  All lengths in the reference's units. */
 typedef struct DgpConfig {
   uint32_t struct_size;      /* = sizeof(DgpConfig), ABI guard                                           */
-  int32_t  num_states;       /* n = planner_params['total_time_step'] + 1          (plan_layer.py:30)    */
+  int32_t  num_states;       /* n = planner_params['total_time_step'] + 1          (plan_layer.py:30);   */
+                             /* 2 <= n <= 1024 (dof 2) / 640 (dof 3): up to 256 states the unrolled       */
+                             /* kernels, beyond that the loop kernels of csrc/gn_long.h (LDS-bounded)     */
   int32_t  dof;              /* planner_params['dof']: 2 (point robot) or 3 (x,y,theta); d = 2*dof       */
   int32_t  nlinks;           /* robot_model.nlinks; only 1 is implemented                                */
   int32_t  io_dtype;         /* DGP_F32 or DGP_F64                                                       */
@@ -106,7 +108,8 @@ void dgp_destroy(DgpHandle* h);
 int  dgp_num_factor_rows(const DgpHandle* h);
 
 /* Launch shape the library will use for a batch of `batch` trajectories: lanes per trajectory and consecutive states per
- * lane (reporting / tuning aid; the environment variable DGP_FORCE_SHAPE="LPT,C" read by dgp_create pins it). */
+ * lane (reporting / tuning aid; the environment variable DGP_FORCE_SHAPE="LPT,C" read by dgp_create pins it).  num_states > 256:
+ * (64, ceil(num_states / 64)) -- one trajectory per wavefront, the rows of a lane walked in a loop. */
 int  dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lanes_per_trajectory, int32_t* states_per_lane);
 
 /* Kernel variant dgp_gn_step / dgp_gn_solve launch for a batch of `batch` trajectories WITH STATIC covariances (covs == NULL):

@@ -111,7 +111,9 @@ def plan_layer_forward(th, start, goal, sdf, qc, ow, eps, p, q_full=False):
   A = torch.cat([H for _, _, H in rows], 1)
   b = torch.cat([e for _, e, _ in rows], 1)
   K = torch.stack([torch.block_diag(*[_weights(name, B, n, d, Q_inv, ow, p)[bb] for name, _, _ in rows]) for bb in range(B)], 0)
-  assert A.shape[1] == p.M, (A.shape, p.M)
+  # (M counts dof rows per state for the velocity-limit factor, plan_layer.py:45, the factor itself has two -- v_x, v_y,
+  #  velocity_limit_factor.py:17-29 -- so for the (x,y,theta) robot M, the normaliser of err, exceeds the row count by n)
+  assert A.shape[1] == p.M - ((d // 2 - 2) * n if p.use_vel_limits else 0), (A.shape, p.M)
   AtK = torch.bmm(A.transpose(1, 2), K)                                   # plan_layer.py:217-220
   LAM = torch.bmm(AtK, A) + p.reg * torch.eye(N, dtype=torch.float64)
   R = torch.bmm(AtK, b)

@@ -42,6 +42,8 @@ def main():
                         '-o', os.path.join(d, u + '.o')])
   d = os.path.join(work, 'abi'); os.makedirs(d)
   jobs.append(base + [os.path.join(CSRC, 'dgpmp2_hip.hip'), '-o', os.path.join(d, 'abi.o')])
+  d = os.path.join(work, 'long'); os.makedirs(d)
+  jobs.append(base + [os.path.join(CSRC, 'gn_long_inst.hip'), '-o', os.path.join(d, 'long.o')])      # the long-trajectory kernels (small: always built)
   stub = os.path.join(work, 'stubs.hip')
   with open(stub, 'w') as f:
     f.write('#include "%s"\n' % os.path.join(CSRC, 'gn_device.h'))

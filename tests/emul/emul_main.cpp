@@ -22,6 +22,8 @@ struct WaveShared {
   int islot[64];
   alignas(16) char lds[64 * (4 * 6 * 8 + 16) + 64 * 544];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64) + dgp::SinvStash
   alignas(16) char wb[dgp::kWbLdsBytes];                        // LDS copy of the Woodbury constant table
+  alignas(16) char park[64 * 512];                              // dgp::WbPark block (d = 6 Woodbury kernels)
+  alignas(16) char longb[160 * 1024];                           // gn_long.h: the dynamic LDS block of the long-trajectory kernels (gfx950: 160 KB per workgroup)
 };
 
 pthread_mutex_t g_atomic_mutex = PTHREAD_MUTEX_INITIALIZER;
@@ -34,6 +36,9 @@ struct HostCtx {
   char* lds() { return ws->lds; }
   char* stash() { return ws->lds + 64 * (4 * 6 * 8 + 16); }
   char* wb_lds() { return ws->wb; }
+  char* park() { return ws->park; }
+  char* long_lds() { return ws->longb; }
+  void mem_sync() { pthread_barrier_wait(&ws->bar); }
   const double* wb_source(const dgp::GnParams& p) const { return p.wb_tab; }
   void lds_sync() { pthread_barrier_wait(&ws->bar); }
   double fetch(double v, int src) {
@@ -156,8 +161,37 @@ void run_all(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, DgpSh
   }
 }
 
+// long trajectories (gn_long.h): one trajectory per wavefront, the same dispatch as gn_long_inst.hip
+template <int DOF, typename IO>
+void run_long(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
+  if (dgp::long_lds_bytes<2 * DOF>(p.n) > (int)sizeof(WaveShared::longb)) abort();
+  for (int w = 0; w < p.B; ++w) {
+    WaveShared* ws = new WaveShared();
+    pthread_barrier_init(&ws->bar, nullptr, 64);
+    std::vector<std::thread> th;
+    for (int l = 0; l < 64; ++l) {
+      th.emplace_back([&, l]() {
+        HostCtx cx{ws, l, w};
+        if (mode == dgp::MODE_STEP) dgp::gn_long_program<DOF, IO, dgp::MODE_STEP>(p, cx);
+        else if (mode == dgp::MODE_SOLVE) dgp::gn_long_program<DOF, IO, dgp::MODE_SOLVE>(p, cx);
+        else if (mode == dgp::MODE_EVAL) dgp::gn_long_program<DOF, IO, dgp::MODE_EVAL>(p, cx);
+        else dgp::gn_long_backward_program<DOF, IO>(p, *g, cx);
+      });
+    }
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&ws->bar);
+    delete ws;
+  }
+}
+
 void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
-  const DgpShape sh = dgp_host::choose_shape(h, p.B);
+  if (dgp_host::is_long(p.n)) {
+    const bool f64l = h->cfg.io_dtype == DGP_F64;
+    if (h->cfg.dof == 2) { if (f64l) run_long<2, double>(p, g, mode); else run_long<2, float>(p, g, mode); }
+    else { if (f64l) run_long<3, double>(p, g, mode); else run_long<3, float>(p, g, mode); }
+    return;
+  }
+  const DgpShape sh = dgp_host::choose_shape(h, p.B, mode != dgp::MODE_EVAL && dgp::kernel_variant(p) == dgp::QK_GENERAL);
   const bool f64 = h->cfg.io_dtype == DGP_F64;
   if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, sh); else run_all<2, float>(p, g, mode, sh); }
   else { if (f64) run_all<3, double>(p, g, mode, sh); else run_all<3, float>(p, g, mode, sh); }
@@ -178,7 +212,7 @@ int emul_time_next_launch(void*, void*) { return DGP_OK; }      // nothing to ti
 
 int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
   if (!h || batch <= 0) return DGP_EINVAL;
-  const DgpShape sh = dgp_host::choose_shape(h, batch);
+  const DgpShape sh = dgp_host::choose_shape(h, batch, h->base.qc_diag == 0);
   if (lpt) *lpt = sh.lpt;
   if (c) *c = sh.c;
   return DGP_OK;

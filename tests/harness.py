@@ -17,7 +17,7 @@ EMUL_LIB = os.path.join(EMUL_DIR, 'libgn_emul.so')
 
 def build_emulator(force=False):
   src = os.path.join(EMUL_DIR, 'emul_main.cpp')
-  deps = [src] + [os.path.join(ROOT, 'dgpmp2_amd', 'csrc', f) for f in ('gn_lane.h', 'gn_woodbury.h', 'gn_backward.h', 'dgp_host.h')] + \
+  deps = [src] + [os.path.join(ROOT, 'dgpmp2_amd', 'csrc', f) for f in ('gn_lane.h', 'gn_woodbury.h', 'gn_backward.h', 'gn_long.h', 'dgp_host.h')] + \
          [os.path.join(ROOT, 'include', 'dgpmp2_hip.h')]
   if force or not os.path.exists(EMUL_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMUL_LIB) for d in deps):
     subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-Wno-unknown-pragmas', '-fPIC', '-shared',

@@ -608,3 +608,95 @@ def case_eval_errors_backward(be, golden, io):
 
 
 ALL_CASES.append(case_eval_errors_backward)
+
+
+def case_long_trajectories(be, golden, io, configs=None):
+  """n > 256 (gn_long.h: one trajectory per wavefront, ceil(n / 64) rows per lane in a loop, interior state parked in LDS): the reference
+  accepts any total_time_step (plan_layer.py:30).  Every entry point -- step, the fused loop, the error evaluation, both backward kernels --
+  for both robots, velocity-limit / non-holonomic factors, static / per-state / q_full covariances, shared and per-sample grids, lengths that
+  fill the lanes (512 = 64 x 8), leave padding rows inside a lane (300) and padding lanes (257: five rows per lane, 12 lanes empty).
+  Forward against oracle/gn_blocktri.c (block-tridiagonal fp64), gradients against torch autograd over the dense restatement."""
+  from oracle import blocktri as BT, autograd_torch as AT
+  rs = np.random.RandomState(77)
+  if configs is None:
+    configs = [(2, 300, 'static', {}), (2, 512, 'perstate', dict(use_vel_limits=True, K_v=0.01, v_x=0.5, v_y=0.5)), (3, 257, 'static', dict(non_holonomic=True, K_d=0.05)),
+               (3, 320, 'qfull', {}), (2, 1024, 'static', {}), (3, 640, 'perstate', dict(non_holonomic=True, K_d=0.05))]
+  for dof, n, cov, kw in configs:
+    B, d, G = 2, 2 * dof, 48
+    p = O.OracleParams(dof=dof, total_time_step=n - 1, **kw)
+    per_sample = cov != 'static'
+    sdf = np.stack([O.circles_sdf(G, O.C2_CIRCLES + rs.uniform(-0.3, 0.3, np.shape(O.C2_CIRCLES))) for _ in range(B if per_sample else 1)])[:, None]
+    start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+    start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+    if dof == 3: goal[:, 0, 2] = rs.uniform(-1, 1, B)
+    th = O.straight_line_trajb(start[:, :, :dof], goal[:, :, :dof], 10.0, n - 1, dof) + rs.randn(B, n, d) * 0.05
+    qc = ow = eps = None; q_full = False
+    if cov != 'static':
+      ow = rs.uniform(50, 2e4, (B, n)); eps = rs.uniform(0.1, 0.6, (B, n))
+      if cov == 'perstate':
+        A = rs.randn(B, n - 1, dof, dof) * 0.2; qc = np.eye(dof) + A @ np.swapaxes(A, -1, -2)
+      else:
+        A = rs.randn(B, n - 1, d, d) * 0.2; qc = (np.eye(d) + A @ np.swapaxes(A, -1, -2)) * 1.5; q_full = True
+    r = lambda a: None if a is None else rnd(a, io)
+    th, start, goal, sdf, qc, ow, eps = r(th), r(start), r(goal), r(sdf), r(qc), r(ow), r(eps)
+    kwc = dict(qc=qc, ow=ow, eps=eps, q_full=q_full)
+    tag = 'long: dof %d n %d %s %s' % (dof, n, cov, io)
+    tol = TOL[io] * (10 if n > 512 else 1)               # cond(Lambda) grows with n (dt^-3 in Q^-1): the fp64 oracles themselves differ by that much
+    # ---- one step, every trajectory against the block-tridiagonal C oracle
+    dth, err, eex, info = be.step(p, th, start, goal, sdf, io=io, **kwc)
+    c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, **kwc)
+    assert not info.any() and not c_info.any() and np.all(np.isfinite(dth)), tag
+    assert rel_err_per_traj(dth, c_dth) < tol, (tag, 'step', rel_err_per_traj(dth, c_dth))
+    assert rel_err(err, c_err) < TOL_ERR[io] and rel_err(eex, c_eex) < TOL_ERR[io], (tag, 'errors of the step')
+    # ---- the error evaluation against the step's own errors and the oracle's unweighted errors
+    e = be.eval_errors(p, th, start, goal, sdf, io=io, **kwc)
+    assert rel_err(e[0], c_err) < TOL_ERR[io] and rel_err(e[1], c_eex) < TOL_ERR[io], (tag, 'eval_errors')
+    sdfB = np.broadcast_to(sdf, (B,) + sdf.shape[1:])
+    import torch
+    usg, ugp, uob = AT.unweighted_errors(*[torch.from_numpy(np.array(a, dtype=np.float64)) for a in
+                                           (th, start, goal, sdfB, (p.static_covs(B)[2] if eps is None else eps.reshape(B, n, 1, 1)))], p)
+    for got, want, name in ((e[2], usg, 'sg'), (e[3], ugp, 'gp'), (e[4], uob, 'obs')):
+      assert rel_err(got, want.numpy().reshape(-1)) < TOL_ERR[io] * 10, (tag, 'unweighted ' + name, rel_err(got, want.numpy().reshape(-1)))
+    # ---- the fused loop equals chained steps (3 iterations; fp64 I/O: chained fp32 steps would round the state in between)
+    if io == 'f64' and n <= 512:
+      tho, its, eh, eeh, ef, sinfo = be.solve(p, th, start, goal, sdf, 3, 0.0, io=io, **kwc)
+      cur = th.copy()
+      for k in range(3):
+        d_k, e_k, x_k, i_k = be.step(p, cur, start, goal, sdf, io=io, **kwc)
+        assert rel_err(eh[:, k], e_k) < 1e-10 and rel_err(eeh[:, k], x_k) < 1e-10, (tag, 'history', k)
+        cur = cur + d_k
+      assert np.all(its == 3) and not sinfo.any() and rel_err(tho, cur) < 1e-9, (tag, 'fused loop', rel_err(tho, cur))
+      assert rel_err(ef, be.eval_errors(p, cur, start, goal, sdf, io=io, **kwc)[0]) < 1e-9, (tag, 'err_final')
+    # ---- backward of the step against torch autograd over the dense restatement (N = n d up to 1 920 here)
+    if n <= 320:
+      gbar = r(rs.randn(B, n, d)); gext = r(rs.randn(B))
+      shared = sdf.shape[0] == 1
+      g_h = be.backward(p, th, start, goal, sdf, rnd(dth, io), gbar, gext, io=io, sdf_copies=(16 if shared else 1), **kwc)
+      g_o = AT.step_gradients(p, th, start, goal, sdf, gbar, gext, **kwc)
+      for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
+        if g_h[key] is None or (key == 'sdf' and io == 'f32'): continue
+        a_ = g_h[key]
+        if key == 'sdf' and shared: a_ = a_.sum(0, keepdims=True)
+        b_ = g_o[key].reshape(a_.shape)
+        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(g_o['th']).max() if key == 'sdf' else 0.0, 1e-300)
+        assert eb < (1e-6 if io == 'f64' else 2e-3), (tag, 'backward', key, eb)
+      # ... and of the error evaluation (unweighted errors + err_ext), against autograd over the same restatement
+      cot = [r(rs.randn(B)) for _ in range(4)]
+      g_e = be.eval_backward(p, th, start, goal, sdf, g_err_ext=cot[0], g_unw_sg=cot[1], g_unw_gp=cot[2], g_unw_obs=cot[3], eps=eps, io=io,
+                             sdf_copies=(16 if shared else 1))
+      T = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+      L = dict(th=T(th), start=T(start), goal=T(goal), sdf=T(sdf), eps=T(p.static_covs(B)[2] if eps is None else eps.reshape(B, n, 1, 1)))
+      for v in L.values(): v.requires_grad_(True)
+      sB = L['sdf'].expand(B, *L['sdf'].shape[1:]) if shared else L['sdf']
+      sq, so, se = p.static_covs(B)
+      _, _, eext = AT.plan_layer_forward(L['th'], L['start'], L['goal'], sB, T(sq), T(so), L['eps'], p)
+      usg, ugp, uob = AT.unweighted_errors(L['th'], L['start'], L['goal'], sB, L['eps'], p)
+      loss = (T(cot[0]) * eext.reshape(B)).sum() + (T(cot[1]) * usg.reshape(B)).sum() + (T(cot[2]) * ugp.reshape(B)).sum() + (T(cot[3]) * uob.reshape(B)).sum()
+      gr = dict(zip(L.keys(), torch.autograd.grad(loss, list(L.values()), allow_unused=True)))
+      for key in ('th', 'start', 'goal', 'sdf', 'eps'):
+        if g_e[key] is None or (key == 'sdf' and io == 'f32'): continue
+        a_ = g_e[key]
+        if key == 'sdf' and shared: a_ = a_.sum(0, keepdims=True)
+        b_ = gr[key].numpy().reshape(a_.shape)
+        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(gr['th'].numpy()).max() if key == 'sdf' else 0.0, 1e-300)
+        assert eb < (1e-8 if io == 'f64' else 1e-4), (tag, 'eval backward', key, eb)

@@ -95,6 +95,16 @@ def test_launch_shape_choice(api):
   s6 = _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]]))
   assert s6.launch_shape(4096) == (16, 4)                   # d = 6, BASELINE configs[3]: 29.0 us against 45.8 us with (32,2)
   assert s6.launch_shape(32768) == (16, 4)
+  # n > 256: the loop kernels of gn_long.h, one trajectory per wavefront, ceil(n / 64) rows per lane (reported as C), whatever the batch
+  assert _capi.Solver(_cfg(num_states=257)).launch_shape(4096) == (64, 5)
+  assert _capi.Solver(_cfg(num_states=512)).launch_shape(1) == (64, 8)
+  assert _capi.Solver(_cfg(num_states=1024)).launch_shape(7) == (64, 16)
+  assert _capi.Solver(_cfg(num_states=640, dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]])).launch_shape(7) == (64, 10)
+  assert _capi.Solver(_cfg(num_states=512)).step_kernel_variant(64) == 0             # (generic rows: no static / Woodbury specialisation)
+  for kw in (dict(num_states=1025), dict(num_states=641, dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]])):      # LDS capacity of those kernels
+    with pytest.raises(_capi.DgpError) as e:
+      _capi.Solver(_cfg(**kw))
+    assert e.value.code == _capi.DGP_EUNSUPPORTED
 
 
 def test_step_kernel_variant_choice(api, monkeypatch):
@@ -115,3 +125,23 @@ def test_step_kernel_variant_choice(api, monkeypatch):
   assert _capi.Solver(_cfg(dof=3, Q_c_inv=[[1, 0, 0], [0, 1, 0], [0, 0, 1]], non_holonomic=True, K_d=0.01)).step_kernel_variant(4096) == 3
   monkeypatch.setenv('DGP_NO_WOODBURY', '1')
   assert _capi.Solver(_cfg(num_states=64)).step_kernel_variant(4096) == 1
+
+
+def test_spill_guard_every_heavy_spiller_was_verified_on_a_gpu():
+  """hipcc 7.0 has miscompiled these kernels six times, every time among the heaviest spillers.  A kernel at that spill
+  level (profiles/tools/spill_guard.py: >= 300 spilled VGPRs, >= 150 spilled SGPRs or >= 1 KB scratch per lane) must be listed, with its spill
+  counts, in dgpmp2_amd/csrc/spill_baseline.json -- which is only ever rewritten after tests/test_hip_every_kernel.py ran green on a GPU
+  against the build that produced those counts.  A new or grown heavy spiller fails HERE, before it ships unverified."""
+  import json, os, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, os.path.join(root, 'profiles', 'tools'))
+  import spill_guard
+  stats = json.load(open(os.path.join(root, 'dgpmp2_amd', 'lib', 'kernel_stats.json')))
+  base = spill_guard.load_baseline()
+  assert base, 'dgpmp2_amd/csrc/spill_baseline.json is missing or empty'
+  bad = spill_guard.check(stats, base)
+  assert not bad, 'heavy spillers without a GPU-verified baseline entry:\n' + '\n'.join('%s %s (baseline %s)' % b for b in bad)
+  # the guard itself: a grown spill count and an unknown kernel are both reported
+  k = next(iter(base))
+  grown = {k: dict(scratch_bytes_per_lane=base[k][0] * 2 + 2048, vgpr_spill=base[k][1], sgpr_spill=base[k][2]), 'gn_kernel<9,9,9,float,0,0>': dict(scratch_bytes_per_lane=4096, vgpr_spill=0, sgpr_spill=0)}
+  assert len(spill_guard.check(grown, base)) == 2

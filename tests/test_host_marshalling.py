@@ -174,3 +174,17 @@ def test_real_trampoline_argument_counts():
   # a NULL handle comes back as the C-ABI's DGP_EINVAL, not as a crash
   assert pc.gn_step(0, 1, 0, 0, 0, 0, 2, 2, 0, 0, None, None, None, 0, 0, 0, 0, 0) == _capi.DGP_EINVAL
   assert b'null' in _capi.get_api().last_error()
+
+
+def test_inplace_change_between_forward_and_backward_raises(layer):
+  """The inputs are not SavedVariables (their unpacking costs more than the launch): the version-counter check autograd would do is
+  done by hand."""
+  th, st, go, sdf = _inputs()
+  th.requires_grad_(True)
+  dth, err, eex = layer(th, st, go, None, sdf, None, None, None)
+  st.add_(1.0)
+  with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+    dth.sum().backward()
+  dth, err, eex = layer(th, st, go, None, sdf, None, None, None)
+  dth.sum().backward()                                                            # untouched inputs: fine
+  assert th.grad.shape == th.shape

@@ -105,3 +105,13 @@ def test_emul_woodbury_kernels(be, golden):
 
 def test_emul_woodbury_kernels_f32_and_wide_shapes(be, golden):
   PC.case_woodbury_kernels(be, golden, 'f32', shapes=('32,4',), nb=1)
+
+
+def test_emul_long_trajectories(be, golden):
+  """n > 256 through the loop kernels of gn_long.h (see parity_cases.case_long_trajectories), trimmed for the thread-per-lane emulator."""
+  PC.case_long_trajectories(be, golden, 'f64', configs=[(2, 300, 'perstate', dict(use_vel_limits=True, K_v=0.01, v_x=0.5, v_y=0.5)),
+                                                        (3, 257, 'static', dict(non_holonomic=True, K_d=0.05)), (3, 320, 'qfull', {})])
+
+
+def test_emul_long_trajectories_f32(be, golden):
+  PC.case_long_trajectories(be, golden, 'f32', configs=[(2, 300, 'static', {})])
