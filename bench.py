@@ -487,6 +487,11 @@ def main():
     solver.gn_step(B, th_ptrs[k % GN_ITERS], sp, gp, sdf_arg, None, dp, ep, xp, ip, stream)
 
   prewarm_s = prewarm(step)
+  if dist is not None:
+    # untimed: the first call of a collective sets up RCCL's channels / loads its kernels (milliseconds), and the first 4 MB x world output
+    # buffer comes from hipMalloc instead of the caching allocator -- neither belongs to a 0.25 ms timed region
+    for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], world * B)
+    torch.cuda.synchronize()
   for k in range(args.warmup): step(k)
   ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
   ev0.record(); ev1.record()                        # (creates the events outside the timed region: a first record costs ~40 us of host time)

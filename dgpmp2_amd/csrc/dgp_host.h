@@ -68,7 +68,12 @@ inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || 
 // have their own table: the sweep behind T6 timed the static (Woodbury) kernels only, and the general (16,4) kernel -- 1.4 KB of scratch per
 // lane -- is the slowest way to run q_full at B = 4096 (profiles/r03_shape_checks.txt: (16,4) 84.0 us, (32,2) 64.8 us, (32,4) 175 us, (64,1)
 // 117 us; per-state Kronecker kernels: (16,4) 47.1 vs (32,2) 46.4 us, block elimination with velocity limits: 30.3 vs 42.5 us -- T6 holds).
-inline DgpShape choose_shape(const DgpHandle* h, int B, bool general = false) {
+// family 2 (FAM_KRON_BWD): the backward kernel for per-state Q_c^-1 tensors, d = 6: its four-states-per-lane instantiation keeps the three S_k^-1
+// of the adjoint solve AND the covariance blocks alive into the chain rule -- (16,4) 98.3 us against (32,2) 65.6 us at B = 4096 (the forward step
+// is indifferent, 47.4 vs 46.4 us, and the fused loop prefers (16,4), 76.0 vs 83.2 us per iteration, so only the backward changes family).
+enum { FAM_STATIC = 0, FAM_GENERAL = 1, FAM_KRON_BWD = 2 };
+inline DgpShape choose_shape(const DgpHandle* h, int B, int family = FAM_STATIC) {
+  const bool general = family == FAM_GENERAL;
   if (is_long(h->cfg.num_states)) return DgpShape{64, (h->cfg.num_states + 63) / 64};      // gn_long.h: rows per lane reported as C
   if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
   static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
@@ -81,13 +86,23 @@ inline DgpShape choose_shape(const DgpHandle* h, int B, bool general = false) {
     for (int ci = 0; ci < 3; ++ci) {
       const int lpt = 16 << li, c = 1 << ci;
       if (lpt * c < n) continue;
-      const double t = h->cfg.dof == 3 ? (general ? T6G[li][ci] : T6[li][ci]) : T4[li][ci];
+      double t = h->cfg.dof == 3 ? (general ? T6G[li][ci] : T6[li][ci]) : T4[li][ci];
+      if (h->cfg.dof == 3 && family == FAM_KRON_BWD) t = (ci == 2) ? t * 3.2 : t * 1.53;      // (16,4): 98.3 / 1.25 = 78.6 = 3.2 x 24.4;  (32,2): 65.6 / 2.5 = 26.2 = 1.53 x 17.1
       const double waves = (double)((B + (64 / lpt) - 1) / (64 / lpt));
       const double turns = 1.25 * waves / 1024.0;
       const double cost = t * (turns > 1.0 ? turns : 1.0);
       if (cost < best_cost) { best_cost = cost; best = DgpShape{lpt, c}; }
     }
   return best;
+}
+
+// kernel family of a launch for the shape choice (mode: dgp::MODE_* or 3 = backward)
+inline int shape_family(int mode, const dgp::GnParams& p) {
+  if (mode == dgp::MODE_EVAL) return FAM_STATIC;
+  const int qk = dgp::kernel_variant(p);
+  if (qk == dgp::QK_GENERAL) return FAM_GENERAL;
+  if (qk == dgp::QK_KRON && mode == 3) return FAM_KRON_BWD;
+  return FAM_STATIC;
 }
 
 // dgp_step_kernel_variant: the dgp::QK_* variant a static-covariance step of this batch size launches (mirrors launch_typed)

@@ -18,7 +18,7 @@ int drop_events(int rc) {
 
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   if (dgp_host::is_long(p.n)) return dgp_launch_long(h->cfg.dof, h->cfg.io_dtype == DGP_F64, mode, p, g, s);      // n > 256: gn_long.h
-  const DgpShape sh = dgp_host::choose_shape(h, p.B, mode != dgp::MODE_EVAL && dgp::kernel_variant(p) == dgp::QK_GENERAL);
+  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p));
   // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
   static const DgpLaunchFn table[2][2][dgp_dev::NUM_GROUPS] = {
       {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3},
@@ -48,7 +48,7 @@ int dgp_time_next_launch(void* start_event, void* stop_event) {
 
 int dgp_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
   if (!h || batch <= 0) return fail(DGP_EINVAL, "null handle or non-positive batch");
-  const DgpShape sh = dgp_host::choose_shape(h, batch, h->base.qc_diag == 0);      // (static covariances; per-call q_full tensors may pick another shape)
+  const DgpShape sh = dgp_host::choose_shape(h, batch, h->base.qc_diag == 0 ? dgp_host::FAM_GENERAL : dgp_host::FAM_STATIC);      // (static covariances; per-call q_full tensors may pick another shape)
   if (lpt) *lpt = sh.lpt;
   if (c) *c = sh.c;
   return DGP_OK;

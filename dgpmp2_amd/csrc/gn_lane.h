@@ -2516,6 +2516,44 @@ DGP_HD void lds_get_rows(Ctx& cx, double (&v)[C][D]) {
 #include "gn_woodbury.h"
 namespace dgp {
 
+// Makes the per-state covariance blocks of a lane opaque to the optimiser at the top of a GN iteration of the fused loop (emits no
+// instruction).  They ARE loop-invariant, and so is everything assembled from them alone -- the GP part of every diagonal block, the
+// coupling blocks, their products with the constant 2 x 2 factors: left alone, loop-invariant code motion hoists all of it out of the
+// loop and keeps it alive across the whole body (d = 6: ~100 doubles on top of a body that already needs every register), i.e. in
+// scratch (d = 6 per-state fused loop: 2 052 -> 1 428 B per lane with the blocks opaque), reloaded with exposed latency.  Recomputing those few
+// hundred FMAs per iteration is cheaper than the reloads.
+// Measured (profiles/r03_kernel_variants.txt, B = 4096, 10 iterations): d = 6 per-state 761.9 -> 717.5 us, d = 6 q_full 1 410 -> 1 365 us, d = 4 per-state
+// 103.7 -> 103.3 us (no spill to begin with) -- used for d = 6 only.
+#ifndef DGP_SOLVE_OPAQUE_Q
+#define DGP_SOLVE_OPAQUE_Q 6      // the state dimension it applies to (0: never, 1: every dimension)
+#endif
+DGP_HD void opaque(double& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#else
+  (void)v;
+#endif
+}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_GENERAL>& L) {
+#pragma unroll
+  for (int i = 0; i < D * (D + 1) / 2; ++i) {
+    opaque(L.qm0.v[i]);
+#pragma unroll
+    for (int k = 0; k < C; ++k) opaque(L.q[k].v[i]);
+  }
+}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_KRON>& L) {
+#pragma unroll
+  for (int i = 0; i < (D / 2) * (D / 2 + 1) / 2; ++i) {
+    opaque(L.cm0.v[i]);
+#pragma unroll
+    for (int k = 0; k < C; ++k) opaque(L.c[k].v[i]);
+  }
+}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_STATIC>&) {}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_WB>&) {}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_WBR>&) {}
+
 // ---------------------------------------------------------------------------------------------------
 // the lane program: LPT lanes per trajectory, C consecutive states per lane (n <= LPT * C)
 // ---------------------------------------------------------------------------------------------------
@@ -2589,11 +2627,28 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   // the fused loop; the d = 6 fused kernels therefore keep their state in registers, as in round 1.
   constexpr bool kPark = (MODE == MODE_SOLVE) && (D == 4);
   if constexpr (kPark) lds_put_rows<C, D>(cx, x);
+  // d = 6 fused loop: the state waits out the elimination + PCR in th_out itself (global memory, L2-resident: a lane re-reads only the rows
+  // it wrote) instead of in 2 C d vector registers -- the LDS variant of this is what hipcc miscompiled (above); I/O-typed, so only for
+  // fp64 I/O is the state carried at full precision: fp32 I/O keeps it in registers
+#ifndef DGP_SOLVE_PARK_GLOBAL
+#define DGP_SOLVE_PARK_GLOBAL 0
+#endif
+  constexpr bool kParkG = (MODE == MODE_SOLVE) && (D == 6) && (DGP_SOLVE_PARK_GLOBAL != 0) && (DGP_SOLVE_PARK_GLOBAL == 2 || sizeof(IO) == 8);
+  auto put_global = [&](const double (&v)[C][D]) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const int g = j * C + k;
+      if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, v[k]);
+    }
+  };
+  if constexpr (kParkG) put_global(x);
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
+    if constexpr (MODE == MODE_SOLVE && (DGP_SOLVE_OPAQUE_Q == 1 || DGP_SOLVE_OPAQUE_Q == D)) lane_q_opaque<D, C>(lq);
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);       // the state comes back from LDS
+    if constexpr (kParkG) load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, x);
     double e = 0.0, ee = 0.0;
     auto before_pcr = [&](const ErrAcc& a) {
       e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
@@ -2604,7 +2659,10 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     };
     if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
+#ifndef DGP_WB_COLWISE_D6_STEP
+#define DGP_WB_COLWISE_D6_STEP 0      // order of the d = 6 step kernel's Schur assembly (tuning aid; see gn_linear_solve_wb)
+#endif
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE || DGP_WB_COLWISE_D6_STEP != 0), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
@@ -2656,6 +2714,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 #pragma unroll
             for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;   // th_new = th_curr + dtheta (:144)
           lds_put_rows<C, D>(cx, xc);
+        } else if constexpr (kParkG) {
+          double xc[C][D];
+          load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, xc);
+#pragma unroll
+          for (int k = 0; k < C; ++k)
+#pragma unroll
+            for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;
+          put_global(xc);
         } else {
 #pragma unroll
           for (int k = 0; k < C; ++k)
@@ -2677,10 +2743,13 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   DGP_STAMP(p, cx, 6);
   if (MODE == MODE_SOLVE) {
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);
+    if constexpr (kParkG) load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, x);
+    if constexpr (!kParkG) {
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const int g = j * C + k;
-      if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, x[k]);
+      for (int k = 0; k < C; ++k) {
+        const int g = j * C + k;
+        if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, x[k]);
+      }
     }
     if (traj_ok && j == 0 && p.iters) p.iters[b] = my_iters;
     if (p.err_final) {

@@ -281,9 +281,12 @@ struct WbSolver<3> {
 #ifndef DGP_WB_PARK
 #define DGP_WB_PARK 0      // experiment (profiles/tools/kprobe.sh -DDGP_WB_PARK=1): measured worse, see DESIGN.md section 5
 #endif
+// DGP_WB_PARK: 0 nothing parked; 1 everything (t, hh, the factorisation); 2 the factorisation only (L, dinv: 21 doubles); 3 t only (18 doubles)
 template <int DOF, int R> struct WbPark {
-  static constexpr bool kUse = (DOF == 3) && (R == 6) && (DGP_WB_PARK != 0);
-  static constexpr int kDoubles = 3 * 2 * DOF + 3 * 5 + R * (R - 1) / 2 + R;      // 18 + 15 + 15 + 6 = 54
+  static constexpr int kMode = DGP_WB_PARK;
+  static constexpr bool kUse = (DOF == 3) && (R == 6) && (kMode != 0);
+  static constexpr bool kT = kMode == 1 || kMode == 3, kH = kMode == 1, kS = kMode == 1 || kMode == 2;
+  static constexpr int kDoubles = (kT ? 3 * 2 * DOF : 0) + (kH ? 3 * 5 : 0) + (kS ? R * (R - 1) / 2 + R : 0);
   static constexpr int kCells = (kDoubles + 1) / 2;
   static constexpr int kStride = ((kCells % 2) ? kCells : kCells + 1) * 16;        // bytes per lane
   static constexpr int kBytes = kUse ? 64 * kStride : 0;
@@ -291,53 +294,67 @@ template <int DOF, int R> struct WbPark {
 template <int DOF, int R, typename Ctx, typename SV>
 DGP_HD void wb_park_put(Ctx& cx, const double (&t)[3][2 * DOF], const double (&hh)[R][2 * DOF], const SV& sv) {
   typedef double V2 __attribute__((vector_size(16)));
-  constexpr int N = WbPark<DOF, R>::kDoubles;
-  double v[N + 1];
+  typedef WbPark<DOF, R> P;
+  constexpr int N = P::kDoubles;
+  double v[N + 2];
   int q = 0;
+  if constexpr (P::kT) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int a = 0; a < 2 * DOF; ++a) v[q++] = t[k][a];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    v[q++] = hh[2 * k][0]; v[q++] = hh[2 * k][1];
-    v[q++] = hh[2 * k + 1][2]; v[q++] = hh[2 * k + 1][DOF]; v[q++] = hh[2 * k + 1][DOF + 1];
+      for (int a = 0; a < 2 * DOF; ++a) v[q++] = t[k][a];
   }
+  if constexpr (P::kH) {
 #pragma unroll
-  for (int i = 1; i < R; ++i)
+    for (int k = 0; k < 3; ++k) {
+      v[q++] = hh[2 * k][0]; v[q++] = hh[2 * k][1];
+      v[q++] = hh[2 * k + 1][2]; v[q++] = hh[2 * k + 1][DOF]; v[q++] = hh[2 * k + 1][DOF + 1];
+    }
+  }
+  if constexpr (P::kS) {
 #pragma unroll
-    for (int k = 0; k < i; ++k) v[q++] = sv.L[i][k];
+    for (int i = 1; i < R; ++i)
 #pragma unroll
-  for (int i = 0; i < R; ++i) v[q++] = sv.dinv[i];
+      for (int k = 0; k < i; ++k) v[q++] = sv.L[i][k];
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[q++] = sv.dinv[i];
+  }
   v[N] = 0.0;
-  char* l = cx.park() + cx.lane() * WbPark<DOF, R>::kStride;
+  char* l = cx.park() + cx.lane() * P::kStride;
 #pragma unroll
-  for (int i = 0; i < WbPark<DOF, R>::kCells; ++i) { V2 c; c[0] = v[2 * i]; c[1] = v[2 * i + 1 <= N ? 2 * i + 1 : N]; *(V2*)(l + i * 16) = c; }
+  for (int i = 0; i < P::kCells; ++i) { V2 c; c[0] = v[2 * i]; c[1] = v[2 * i + 1 <= N ? 2 * i + 1 : N]; *(V2*)(l + i * 16) = c; }
 }
 template <int DOF, int R, typename Ctx, typename SV>
 DGP_HD void wb_park_get(Ctx& cx, double (&t)[3][2 * DOF], double (&hh)[R][2 * DOF], SV& sv) {
   typedef double V2 __attribute__((vector_size(16)));
-  constexpr int N = WbPark<DOF, R>::kDoubles;
+  typedef WbPark<DOF, R> P;
+  constexpr int N = P::kDoubles;
   double v[N + 2];
-  const char* l = cx.park() + cx.lane() * WbPark<DOF, R>::kStride;
+  const char* l = cx.park() + cx.lane() * P::kStride;
 #pragma unroll
-  for (int i = 0; i < WbPark<DOF, R>::kCells; ++i) { const V2 c = *(const V2*)(l + i * 16); v[2 * i] = c[0]; v[2 * i + 1] = c[1]; }
+  for (int i = 0; i < P::kCells; ++i) { const V2 c = *(const V2*)(l + i * 16); v[2 * i] = c[0]; v[2 * i + 1] = c[1]; }
   int q = 0;
+  if constexpr (P::kT) {
 #pragma unroll
-  for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 3; ++k)
 #pragma unroll
-    for (int a = 0; a < 2 * DOF; ++a) t[k][a] = v[q++];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    hh[2 * k][0] = v[q++]; hh[2 * k][1] = v[q++];
-    hh[2 * k + 1][2] = v[q++]; hh[2 * k + 1][DOF] = v[q++]; hh[2 * k + 1][DOF + 1] = v[q++];
+      for (int a = 0; a < 2 * DOF; ++a) t[k][a] = v[q++];
   }
+  if constexpr (P::kH) {
 #pragma unroll
-  for (int i = 1; i < R; ++i)
+    for (int k = 0; k < 3; ++k) {
+      hh[2 * k][0] = v[q++]; hh[2 * k][1] = v[q++];
+      hh[2 * k + 1][2] = v[q++]; hh[2 * k + 1][DOF] = v[q++]; hh[2 * k + 1][DOF + 1] = v[q++];
+    }
+  }
+  if constexpr (P::kS) {
 #pragma unroll
-    for (int k = 0; k < i; ++k) sv.L[i][k] = v[q++];
+    for (int i = 1; i < R; ++i)
 #pragma unroll
-  for (int i = 0; i < R; ++i) sv.dinv[i] = v[q++];
+      for (int k = 0; k < i; ++k) sv.L[i][k] = v[q++];
+#pragma unroll
+    for (int i = 0; i < R; ++i) sv.dinv[i] = v[q++];
+  }
 }
 
 // `staged`: the table cells this lane still has to commit to LDS (first solve of a launch), or null.

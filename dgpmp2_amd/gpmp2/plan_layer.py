@@ -137,9 +137,15 @@ class _GNStep(torch.autograd.Function):
     return dth, err, eex, (thc, stc, goc), (sd, cv)
 
   @staticmethod
-  def forward(ctx, layer, static, th, start, goal, sdf, qc, ow, eps):
+  def forward(ctx, layer, static, slots, ts, box, *diff):
+    """ts = (th, start, goal, sdf, qc, ow, eps), every input; diff = those of them that require grad, ts[i] for i in slots.  Only `diff` are
+    tensor ARGUMENTS of the Function (the bookkeeping of Function.apply is paid per tensor argument: ~1 us each, and a TBPTT link
+    differentiates one of the seven); err -- never differentiable, plan_layer.py:275 -- leaves through `box` instead of as an output."""
+    th, start, goal, sdf, qc, ow, eps = ts
     dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
+    box.append(err)
     ctx.layer = layer
+    ctx.slots = slots
     ctx.args = args                               # marshalled SDF / covariance arguments (and the converted copies they point into)
     # Inputs: the backward needs their ADDRESSES (in ctx.args) and, for the gradient buffers, their shapes -- not SavedVariables, whose
     # unpacking costs ~1.5 us per tensor.  What save_for_backward would add, the "modified by an inplace operation" check, is done
@@ -148,21 +154,20 @@ class _GNStep(torch.autograd.Function):
     ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, -1 if qc is None else qc._version,
                     -1 if ow is None else ow._version, -1 if eps is None else eps._version)
     ctx.save_for_backward(dth)
-    ctx.mark_non_differentiable(err)              # plan_layer.py:275: error_batch runs under no_grad
     ctx.set_materialize_grads(False)              # an unused output arrives as None: no adjoint solve for an err_ext-only loss
-    return dth, err, eex
+    return dth, eex
 
   @staticmethod
-  def backward(ctx, g_dth, g_err, g_eex):
+  def backward(ctx, g_dth, g_eex):
     # The backward is a raw kernel: a double backward must raise instead of silently returning zeros.  torch's once_differentiable
     # does that, at ~8 us of wrapper per call; grad mode is only enabled inside backward() under create_graph=True, so the wrapper
     # is only paid there.
     if torch.is_grad_enabled():
-      return _GNStep._backward_once(ctx, g_dth, g_err, g_eex)
-    return _GNStep._backward_impl(ctx, g_dth, g_err, g_eex)
+      return _GNStep._backward_once(ctx, g_dth, g_eex)
+    return _GNStep._backward_impl(ctx, g_dth, g_eex)
 
   @staticmethod
-  def _backward_impl(ctx, g_dth, g_err, g_eex):
+  def _backward_impl(ctx, g_dth, g_eex):
     layer = ctx.layer
     dth, = ctx.saved_tensors
     th, stc, goc, sdf, qc, ow, eps, start, goal = ctx.inputs
@@ -172,7 +177,10 @@ class _GNStep(torch.autograd.Function):
     dtype = th.dtype
     solver = layer._solvers[dtype]
     dev = th.get_device()
-    need = ctx.needs_input_grad                   # (layer, static, th, start, goal, sdf, qc, ow, eps)
+    slots = ctx.slots
+    nig = ctx.needs_input_grad                    # (layer, static, slots, ts, box, *diff)
+    need = [False] * 9                            # indexed like the old fixed signature: [2 + i] <-> ts[i]
+    for q, i in enumerate(slots): need[2 + i] = nig[5 + q]
     if g_dth is not None and (g_dth.dtype is not dtype or not g_dth.is_contiguous()): g_dth = g_dth.contiguous().to(dtype)
     if g_eex is not None and (g_eex.dtype is not dtype or not g_eex.is_contiguous()): g_eex = g_eex.contiguous().to(dtype)
     g_th = torch.empty_like(th) if need[2] else None
@@ -193,7 +201,8 @@ class _GNStep(torch.autograd.Function):
             _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _raw_stream(dev))
     if g_sdf is not None:
       g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
-    return (None, None, g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
+    grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
+    return (None, None, None, None, None) + tuple(grads[i] for i in slots)
 
 
 def _check_versions(tensors, versions):
@@ -247,10 +256,13 @@ class _EvalErrors(torch.autograd.Function):
   forward(), plan_layer.py:88-94).  None of them depends on qc_inv / obscov_inv (fixed or unit weights)."""
 
   @staticmethod
-  def forward(ctx, layer, th, start, goal, sdf, eps):
+  def forward(ctx, layer, slots, ts, *diff):
+    """ts = (th, start, goal, sdf, eps); diff = ts[i] for i in slots, the inputs that require grad (see _GNStep.forward)."""
+    th, start, goal, sdf, eps = ts
     eps_arg = None if (eps is None or '_dgp_static' in eps.__dict__) else eps
     o, thc, stc, goc, sd, cv = layer._eval_launch(th, sdf, start, goal, None, None, eps_arg)
     ctx.layer = layer
+    ctx.slots = slots
     ctx.args = (sd, cv)
     ctx.inputs = (thc, stc, goc, sdf, eps_arg, start, goal)      # (addresses in ctx.args; version counters checked by hand, see _GNStep.forward)
     ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, -1 if eps_arg is None else eps_arg._version)
@@ -273,7 +285,9 @@ class _EvalErrors(torch.autograd.Function):
     dtype = th.dtype
     solver = layer._solvers[dtype]
     dev = th.get_device()
-    need = ctx.needs_input_grad                       # (layer, th, start, goal, sdf, eps)
+    nig = ctx.needs_input_grad                        # (layer, slots, ts, *diff)
+    need = [False] * 6                                # indexed like the old fixed signature: [1 + i] <-> ts[i]
+    for q, i in enumerate(ctx.slots): need[1 + i] = nig[3 + q]
     cot = [None if g is None else (g if (g.dtype is dtype and g.is_contiguous()) else g.contiguous().to(dtype)) for g in (g_eex, g_usg, g_ugp, g_uobs)]
     g_th = torch.empty_like(th) if need[1] else None
     g_st = _grad_like(start, stc) if need[2] else None
@@ -291,7 +305,8 @@ class _EvalErrors(torch.autograd.Function):
             g_stride, copies, _ptr(g_eps), _raw_stream(dev))
     if g_sdf is not None:
       g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
-    return (None, g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_eps, eps))
+    grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_eps, eps))
+    return (None, None, None) + tuple(grads[i] for i in ctx.slots)
 
 
 _EvalErrors._backward_once = staticmethod(once_differentiable(_EvalErrors._backward_impl))
@@ -469,9 +484,13 @@ class PlanLayer(nn.Module):
       det = lambda t, st: None if (t is None or st) else t.detach()
       self.__dict__['_last'] = (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
                                 None if (eps_trajb is None or static[2]) else eps_trajb)
-    if torch.is_grad_enabled() and (thb.requires_grad or startb.requires_grad or goalb.requires_grad or (sdfb is not None and sdfb.requires_grad) or
-                                    any(t is not None and t.requires_grad for t in (qc_inv_trajb, obscov_inv_trajb, eps_trajb))):
-      return _GNStep.apply(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+    if torch.is_grad_enabled():
+      ts = (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+      slots = tuple([i for i in range(7) if ts[i] is not None and ts[i].requires_grad])
+      if slots:
+        box = []
+        dth, eex = _GNStep.apply(self, static, slots, ts, box, *[ts[i] for i in slots])
+        return dth, box[0], eex
     # planning / validation loops: no autograd node, one launch
     return _GNStep.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:3]
 
@@ -520,8 +539,11 @@ class PlanLayer(nn.Module):
   def _eval_diff(self, thb, sdfb, st, go, eps):
     """(err_ext, start_goal_error, gp_error, obs_error) at thb, each (B,1,1) (None where a grid is needed and sdfb is None), carrying
     the autograd graph the reference's plain torch ops would carry: w.r.t. thb, sdfb, the start / goal means and the current eps."""
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (thb, sdfb, st, go, eps)):
-      return _EvalErrors.apply(self, thb, st, go, sdfb, eps)
+    if torch.is_grad_enabled():
+      ts = (thb, st, go, sdfb, eps)
+      slots = tuple([i for i in range(5) if ts[i] is not None and ts[i].requires_grad])
+      if slots:
+        return _EvalErrors.apply(self, slots, ts, *[ts[i] for i in slots])
     o = self._eval(thb, sdfb, st, go, None, None, eps)
     return o[1], o[2], o[3], o[4]
 

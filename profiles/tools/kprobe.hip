@@ -75,11 +75,44 @@ int main(int argc, char** argv) {
   hipMemcpy(d_st, st.data(), st.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(d_go, go.data(), go.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_sdf, sdf.data(), sdf.size() * 4, hipMemcpyHostToDevice);
   DgpSdf sa; sa.data = d_sdf; sa.rows = G; sa.cols = G; sa.batch_stride = 0;
+  // -DPROBE_QK=2 (per-state Q_c^-1, Kronecker kernels) / 0 with -DPROBE_QFULL (full Q^-1): covariance tensors as the learned modes pass them
+  DgpCovs cv; cv.qc_mode = DGP_QC_STATIC; cv.qc_inv = nullptr; cv.obs_w = nullptr; cv.eps = nullptr;
+  const DgpCovs* covs = nullptr;
+#if PROBE_QK == 2 || defined(PROBE_QFULL)
+  {
+#if defined(PROBE_QFULL)
+    const int q = D;
+#else
+    const int q = DOF;
+#endif
+    std::vector<float> qc((size_t)B * (n - 1) * q * q, 0.f), ow((size_t)B * n, 1e4f), ep((size_t)B * n, DOF == 3 ? 0.2f : 0.4f);
+    const double dt = 10.0 / (n - 1), qa = 12.0 / (dt * dt * dt), qb = -6.0 / (dt * dt), qcc = 4.0 / dt;
+    for (size_t f = 0; f < (size_t)B * (n - 1); ++f)
+      for (int i = 0; i < q; ++i) {
+#if defined(PROBE_QFULL)
+        qc[f * q * q + i * q + i] = (float)(i < DOF ? qa : qcc);
+        qc[f * q * q + i * q + (i + DOF) % q] = (float)qb;
+#else
+        qc[f * q * q + i * q + i] = 1.f;
+#endif
+      }
+    float *d_qc, *d_ow, *d_ep;
+    hipMalloc(&d_qc, qc.size() * 4); hipMalloc(&d_ow, ow.size() * 4); hipMalloc(&d_ep, ep.size() * 4);
+    hipMemcpy(d_qc, qc.data(), qc.size() * 4, hipMemcpyHostToDevice); hipMemcpy(d_ow, ow.data(), ow.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(d_ep, ep.data(), ep.size() * 4, hipMemcpyHostToDevice);
+#if defined(PROBE_QFULL)
+    cv.qc_mode = DGP_QC_QFULL;
+#else
+    cv.qc_mode = DGP_QC_PERSTATE;
+#endif
+    cv.qc_inv = d_qc; cv.obs_w = d_ow; cv.eps = d_ep; covs = &cv;
+  }
+#endif
   dgp::GnParams p;
 #if PROBE_MODE == 1
-  if (dgp_host::fill_solve(h, B, d_th, d_st, d_go, &sa, nullptr, 10, 0.0, d_dth, d_iters, d_err, d_eex, nullptr, d_info, p) != DGP_OK) { printf("fill failed: %s\n", dgp_host::err_buf()); return 1; }
+  if (dgp_host::fill_solve(h, B, d_th, d_st, d_go, &sa, covs, 10, 0.0, d_dth, d_iters, d_err, d_eex, nullptr, d_info, p) != DGP_OK) { printf("fill failed: %s\n", dgp_host::err_buf()); return 1; }
 #else
-  if (dgp_host::fill_step(h, B, d_th, d_st, d_go, &sa, nullptr, d_dth, d_err, d_eex, d_info, p) != DGP_OK) { printf("fill failed: %s\n", dgp_host::err_buf()); return 1; }
+  if (dgp_host::fill_step(h, B, d_th, d_st, d_go, &sa, covs, d_dth, d_err, d_eex, d_info, p) != DGP_OK) { printf("fill failed: %s\n", dgp_host::err_buf()); return 1; }
 #endif
   if (dgp::is_wb(PROBE_QK) && !dgp::wb_applies(p, PROBE_LPT, PROBE_C)) { printf("Woodbury kernel does not apply to this configuration\n"); return 1; }
   const int tpw = 64 / PROBE_LPT;

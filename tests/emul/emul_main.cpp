@@ -191,7 +191,7 @@ void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g,
     else { if (f64l) run_long<3, double>(p, g, mode); else run_long<3, float>(p, g, mode); }
     return;
   }
-  const DgpShape sh = dgp_host::choose_shape(h, p.B, mode != dgp::MODE_EVAL && dgp::kernel_variant(p) == dgp::QK_GENERAL);
+  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p));
   const bool f64 = h->cfg.io_dtype == DGP_F64;
   if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, sh); else run_all<2, float>(p, g, mode, sh); }
   else { if (f64) run_all<3, double>(p, g, mode, sh); else run_all<3, float>(p, g, mode, sh); }
@@ -212,7 +212,7 @@ int emul_time_next_launch(void*, void*) { return DGP_OK; }      // nothing to ti
 
 int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {
   if (!h || batch <= 0) return DGP_EINVAL;
-  const DgpShape sh = dgp_host::choose_shape(h, batch, h->base.qc_diag == 0);
+  const DgpShape sh = dgp_host::choose_shape(h, batch, h->base.qc_diag == 0 ? dgp_host::FAM_GENERAL : dgp_host::FAM_STATIC);
   if (lpt) *lpt = sh.lpt;
   if (c) *c = sh.c;
   return DGP_OK;
