@@ -483,8 +483,15 @@ def main():
   th_ptrs = [t.data_ptr() for t in th_hist]
   sp, gp, dp, ep, xp, ip = start.data_ptr(), goal.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr()
 
-  def step(k):      # exactly what PlanLayer.forward launches (plan_layer.py: _GNStep.forward), info buffer included
-    solver.gn_step(B, th_ptrs[k % GN_ITERS], sp, gp, sdf_arg, None, dp, ep, xp, ip, stream)
+  # exactly what PlanLayer.forward launches (plan_layer.py: _GNStep.launch), info buffer included, through the same binding: the METH_FASTCALL
+  # trampoline onto the C-ABI's dgp_gn_step (csrc/dgp_pycall.c; the ctypes binding of the same entry point costs 4 us more host time per call, which a
+  # 20-launch region sees once, as the delay of its first launch)
+  pc, hnd, raw_stream = _capi.get_pycall(), solver.h, stream.value or 0
+  sdf_ptr = sdf.data_ptr()
+
+  def step(k):
+    rc = pc.gn_step(hnd, B, th_ptrs[k % GN_ITERS], sp, gp, sdf_ptr, GRID, GRID, 0, 0, None, None, None, dp, ep, xp, ip, raw_stream)
+    if rc: solver.api.check(rc)
 
   prewarm_s = prewarm(step)
   if dist is not None:

@@ -1385,7 +1385,10 @@ template <int LPT> DGP_HD int row_to_lane(int j) {
 // their own value (bpermute); both are harmless because the coupling block that multiplies the fetched data is zero there.
 template <int LPT, int S, typename Ctx>
 struct Nbr {
-  static constexpr bool kDpp = (LPT == 16) || (LPT == 32 && S >= 2);     // DPP path: missing neighbours read as 0
+#ifndef DGP_NBR_BPERMUTE_MASK
+#define DGP_NBR_BPERMUTE_MASK 0      // experiment: bit log2(S) set -> the exchanges of PCR stride S go through ds_bpermute (LDS crossbar) instead of DPP moves
+#endif
+  static constexpr bool kDpp = ((LPT == 16) || (LPT == 32 && S >= 2)) && !((DGP_NBR_BPERMUTE_MASK) & S);     // DPP path: missing neighbours read as 0
   static constexpr int kShift = (LPT == 32) ? S / 2 : S;                  // lane distance inside the DPP row
   Ctx& cx;
   int src_lo, src_hi, src_par;
@@ -1675,6 +1678,224 @@ DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D]
   sched_fence();
 }
 
+// ---------------------------------------------------------------------------------------------------
+// EXPERIMENT (-DDGP_PCR_LDL=<d> | 1: every dimension; default off): the PCR round on the LDL^T factors of D instead of on D^-1.
+//   D = L Dg L^T (unit lower L);  Z = L^-1 U,  Zs = Dg^-1 Z,  q = L^-1 r,  qs = Dg^-1 q
+//   to the right neighbour (owner computes):  W = U^T D^-1 U = Z^T Zs,   v = U^T D^-1 r = Z^T qs
+//   from the right neighbour (L_R, Dg_R^-1, qs_R, Zs_R -- as many values as D_R^-1, y_R, G_R):
+//       Zt = U L_R^-T (D forward substitutions),  D -= (Zt Dg_R^-1) Zt^T,  r -= Zt qs_R,  U' = -Zt Zs_R
+// Triangular solves instead of products with explicit inverses: per round 310 instead of 365 multiply-adds for d = 4, ~960 instead of
+// ~1 160 for d = 6 -- at the price of d dependent pivots where the block inverse has two.  Stage order as in pcr_round_lean.
+// ---------------------------------------------------------------------------------------------------
+#ifndef DGP_PCR_LDL
+#define DGP_PCR_LDL 0
+#endif
+template <int D> struct Ldl {
+  double L[D][D], dinv[D];            // strict lower part of L used
+  template <typename OK>
+  DGP_HD void factor(const Sym<D>& S, OK& ok) {
+    double dd[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      double v = S(j, j);
+      double w[D];
+#pragma unroll
+      for (int k = 0; k < j; ++k) { w[k] = L[j][k] * dd[k]; v -= L[j][k] * w[k]; }
+      dd[j] = v;
+      ok.require(v > 0.0);
+      dinv[j] = pivot_rcp(v);
+#pragma unroll
+      for (int i = j + 1; i < D; ++i) {
+        double u = S(i, j);
+#pragma unroll
+        for (int k = 0; k < j; ++k) u -= L[i][k] * w[k];
+        L[i][j] = u * dinv[j];
+      }
+    }
+  }
+  // x <- L^-1 x
+  DGP_HD void fwd(double (&x)[D]) const {
+#pragma unroll
+    for (int f = 1; f < D; ++f) {
+      double v = x[f];
+#pragma unroll
+      for (int g = 0; g < f; ++g) v -= L[f][g] * x[g];
+      x[f] = v;
+    }
+  }
+  DGP_HD void solve(const double (&c)[D], double (&m)[D]) const {      // m = D^-1 c
+    double y[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) y[f] = c[f];
+    fwd(y);
+#pragma unroll
+    for (int f = D - 1; f >= 0; --f) {
+      double v = dinv[f] * y[f];
+#pragma unroll
+      for (int g = f + 1; g < D; ++g) v -= L[g][f] * m[g];
+      m[f] = v;
+    }
+  }
+};
+
+template <int D, int LPT, int S, typename Ctx>
+DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
+  typedef Nbr<LPT, S, Ctx> NB;
+  const NB nb(cx, i);
+  const bool has_l = (i >= S);
+  constexpr bool kFence = (D == 6);
+  if constexpr (kFence) sched_fence();
+  Ldl<D> F;
+  F.factor(Dm, ok);
+  double qs[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) qs[a] = r[a];
+  F.fwd(qs);
+#pragma unroll
+  for (int a = 0; a < D; ++a) qs[a] *= F.dinv[a];
+  if constexpr (kFence) sched_fence();
+  // ---- right neighbour: its factor and qs
+  Mat<D> Zt;                        // Zt = U L_R^-T  (row a: L_R^-1 applied to row a of U)
+  {
+    Ldl<D> FR;
+    double qR[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) {
+      FR.dinv[f] = nb.hi(F.dinv[f]);
+      qR[f] = nb.hi(qs[f]);
+#pragma unroll
+      for (int g = 0; g < f; ++g) FR.L[f][g] = nb.hi(F.L[f][g]);
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double row[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) row[c] = U.v[a][c];
+      FR.fwd(row);
+      double t = r[a];
+#pragma unroll
+      for (int f = 0; f < D; ++f) { Zt.v[a][f] = row[f]; t -= row[f] * qR[f]; }
+      r[a] = t;
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double zs[D];
+#pragma unroll
+      for (int f = 0; f < D; ++f) zs[f] = Zt.v[a][f] * FR.dinv[f];
+#pragma unroll
+      for (int c = a; c < D; ++c) {
+        double w = Dm(a, c);
+#pragma unroll
+        for (int f = 0; f < D; ++f) w -= zs[f] * Zt.v[c][f];
+        Dm(a, c) = w;
+      }
+    }
+  }
+  if constexpr (kFence) sched_fence();
+  // ---- own Z = L^-1 U (in place of U, which is dead now), column by column; v and W to the right neighbour
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double col[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) col[a] = U.v[a][c];
+    F.fwd(col);
+#pragma unroll
+    for (int a = 0; a < D; ++a) U.v[a][c] = col[a];
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double v = 0.0;
+#pragma unroll
+    for (int f = 0; f < D; ++f) v += U.v[f][a] * qs[f];
+    const double vL = nb.lo(v);
+    r[a] -= (NB::kDpp || has_l) ? vL : 0.0;
+  }
+  if constexpr (kFence) sched_fence();
+  Mat<D> Un;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double zsc[D];                  // column c of Zs = Dg^-1 Z
+#pragma unroll
+    for (int f = 0; f < D; ++f) zsc[f] = F.dinv[f] * U.v[f][c];
+#pragma unroll
+    for (int a = 0; a <= c; ++a) {
+      double w = 0.0;
+#pragma unroll
+      for (int f = 0; f < D; ++f) w += U.v[f][a] * zsc[f];
+      const double wL = nb.lo(w);
+      Dm(a, c) -= (NB::kDpp || has_l) ? wL : 0.0;
+    }
+    double zR[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) zR[f] = nb.hi(zsc[f]);
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+      double t = 0.0;
+#pragma unroll
+      for (int f = 0; f < D; ++f) t -= Zt.v[a][f] * zR[f];
+      Un.v[a][c] = t;
+    }
+    if constexpr (kFence) { if (c % 2 == 1) sched_fence(); }
+  }
+  U = Un;
+  if constexpr (kFence) sched_fence();
+}
+
+// the last round (one partner, see pcr_last_round) and the final solve on the factors
+template <int D, int LPT, int S, typename Ctx>
+DGP_HD void pcr_last_round_ldl(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
+  const Nbr<LPT, S, Ctx> nb(cx, i);
+  Ldl<D> F, FP;
+  F.factor(Dm, ok);
+  double qs[D], qP[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) qs[a] = r[a];
+  F.fwd(qs);
+#pragma unroll
+  for (int a = 0; a < D; ++a) qs[a] *= F.dinv[a];
+#pragma unroll
+  for (int f = 0; f < D; ++f) {
+    FP.dinv[f] = nb.partner(F.dinv[f]);
+    qP[f] = nb.partner(qs[f]);
+#pragma unroll
+    for (int g = 0; g < f; ++g) FP.L[f][g] = nb.partner(F.L[f][g]);
+  }
+  Mat<D> K;
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) K.v[c][a] = nb.partner(U.v[a][c]);            // U_partner^T
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = 0; c < D; ++c) K.v[a][c] += U.v[a][c];
+  Mat<D> Kt;
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double row[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) row[c] = K.v[a][c];
+    FP.fwd(row);
+    double t = r[a];
+#pragma unroll
+    for (int f = 0; f < D; ++f) { Kt.v[a][f] = row[f]; t -= row[f] * qP[f]; }
+    r[a] = t;
+  }
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    double zs[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) zs[f] = Kt.v[a][f] * FP.dinv[f];
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double w = Dm(a, c);
+#pragma unroll
+      for (int f = 0; f < D; ++f) w -= zs[f] * Kt.v[c][f];
+      Dm(a, c) = w;
+    }
+  }
+}
+
 // which dimension gets the register-lean round (tuning aid: -DDGP_PCR_LEAN_ALL=1 / -DDGP_PCR_LEAN_NONE=1)
 #if defined(DGP_PCR_LEAN_ALL)
 #define DGP_PCR_LEAN_D(D) true
@@ -1692,7 +1913,10 @@ DGP_HD void pcr_round_any(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
   // And not in the general-covariance kernels (LEAN = false there): <3,16,4,double,STEP,general> -- 355 spilled VGPRs, 1.4 KB of scratch
   // per lane -- came out wrong (O(1) errors) with the lean rounds, again only on the GPU (tests/test_hip_every_kernel.py pins every
   // instantiation against the C oracle since).
-  if constexpr (LEAN && DGP_PCR_LEAN_D(D) && !last && Nbr<LPT, S, Ctx>::kDpp && LPT != 64) pcr_round_lean<D, LPT, S>(cx, i, Dm, U, r, ok);
+  constexpr bool kLdl = LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && Nbr<LPT, S, Ctx>::kDpp && LPT != 64;
+  if constexpr (kLdl && !last) pcr_round_ldl<D, LPT, S>(cx, i, Dm, U, r, ok);
+  else if constexpr (kLdl && last) pcr_last_round_ldl<D, LPT, S>(cx, i, Dm, U, r, ok);
+  else if constexpr (LEAN && DGP_PCR_LEAN_D(D) && !last && Nbr<LPT, S, Ctx>::kDpp && LPT != 64) pcr_round_lean<D, LPT, S>(cx, i, Dm, U, r, ok);
   else pcr_round<D, LPT, S>(cx, i, Dm, U, r, ok);
 }
 
@@ -1705,6 +1929,12 @@ DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], dou
   if constexpr (LPT > 16) pcr_round_any<D, LPT, 16, LEAN>(cx, i, Dm, U, r, ok);
   if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN>(cx, i, Dm, U, r, ok);
   if constexpr (LEAN && DGP_PCR_LEAN_D(D) && LPT != 64) sched_fence();
+  if constexpr (LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && LPT == 16) {
+    Ldl<D> F;
+    F.factor(Dm, ok);
+    F.solve(r, x);
+    return;
+  }
   Sym<D> Di;
   sym_inverse<D>(Dm, Di, ok);                   // (block inverse: two reciprocals deep, against d sequential pivots of a solve)
   sym_times_vec<D>(Di, r, x);

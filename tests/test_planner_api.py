@@ -420,3 +420,34 @@ def test_learned_covariance_modes(golden, mode, learn_eps):
 
 def PC_P2d(n):
   return O.OracleParams(dof=2, total_time_step=n - 1)
+
+
+def test_planner_api_long_trajectory():
+  """total_time_step = 299 (n = 300 > 256: the loop kernels of csrc/gn_long.h) through the reference API: step() against the block-tridiagonal C oracle,
+  forward() (the fused loop) equal to chained step() calls, and the backward of step() against torch autograd over the dense restatement."""
+  from oracle import blocktri as BT, autograd_torch as AT
+  B, n, G = 3, 300, 64
+  planner = make_planner(n, B, max_iters=3, tol_delta=0.0)
+  p = O.OracleParams(dof=2, total_time_step=n - 1)
+  rs = np.random.RandomState(5)
+  start = np.zeros((B, 1, 4)); goal = np.zeros((B, 1, 4))
+  start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+  th = O.straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + rs.randn(B, n, 4) * 0.03
+  sdf_np = O.circles_sdf(G, O.C2_CIRCLES)[None, None]
+  sdf = T(sdf_np).expand(B, 1, G, G)
+  dth, _, err, eex, _, _, _ = planner.step(T(th), T(start), T(goal), None, sdf)
+  c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf_np)
+  assert rel_err(dth.cpu().numpy(), c_dth) < 1e-9 and rel_err(err.cpu().numpy().reshape(-1), c_err) < 1e-11 and not c_info.any()
+  assert planner.plan_layer._solver(torch.float64).launch_shape(B) == (64, 5)
+  # forward(): three fused iterations == three chained steps
+  th_f, _, e0, ef, eh, eeh, k, _ = planner.forward(T(th), T(start), T(goal), None, sdf)
+  cur = T(th)
+  for _ in range(3): cur = cur + planner.step(cur, T(start), T(goal), None, sdf)[0]
+  assert k == [3] * B and rel_err(th_f.cpu().numpy(), cur.cpu().numpy()) < 1e-9
+  # backward of one step
+  thr = T(th).requires_grad_(True)
+  gbar = rs.randn(B, n, 4)
+  d2 = planner.step(thr, T(start), T(goal), None, sdf)[0]
+  (gth,) = torch.autograd.grad(d2, thr, T(gbar))
+  g_o = AT.step_gradients(p, th, start, goal, sdf_np, gbar, np.zeros(B))
+  assert rel_err(gth.cpu().numpy(), g_o['th']) < 1e-6
