@@ -1679,16 +1679,20 @@ DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D]
 }
 
 // ---------------------------------------------------------------------------------------------------
-// EXPERIMENT (-DDGP_PCR_LDL=<d> | 1: every dimension; default off): the PCR round on the LDL^T factors of D instead of on D^-1.
+// The PCR round on the LDL^T factors of D instead of on D^-1 (-DDGP_PCR_LDL=<d>: for state dimension d; 1: every dimension; 0: never).
 //   D = L Dg L^T (unit lower L);  Z = L^-1 U,  Zs = Dg^-1 Z,  q = L^-1 r,  qs = Dg^-1 q
 //   to the right neighbour (owner computes):  W = U^T D^-1 U = Z^T Zs,   v = U^T D^-1 r = Z^T qs
 //   from the right neighbour (L_R, Dg_R^-1, qs_R, Zs_R -- as many values as D_R^-1, y_R, G_R):
 //       Zt = U L_R^-T (D forward substitutions),  D -= (Zt Dg_R^-1) Zt^T,  r -= Zt qs_R,  U' = -Zt Zs_R
 // Triangular solves instead of products with explicit inverses: per round 310 instead of 365 multiply-adds for d = 4, ~960 instead of
 // ~1 160 for d = 6 -- at the price of d dependent pivots where the block inverse has two.  Stage order as in pcr_round_lean.
+// Measured (round 3, profiles/r03_kernel_variants.txt, B = 4096): d = 4 step 3 718 -> 3 436 instructions, 10.23 -> 10.10 us, fused loop 8.02 -> 7.58 us
+// per iteration; d = 6 8 793 instead of 9 511 instructions but 26.5-27.2 against 26.9-27.1 us (the six dependent pivots and 260 more AGPR moves eat the
+// saving).  A variant with two BLOCK pivots (BlockLdl: the chain of the block inverse, the flops of the LDL^T) is slower than the scalar one
+// for d = 4 (10.14 us) and for the d = 6 step (27.5 us).  Hence: d = 4 only, scalar pivots.
 // ---------------------------------------------------------------------------------------------------
 #ifndef DGP_PCR_LDL
-#define DGP_PCR_LDL 0
+#define DGP_PCR_LDL 4
 #endif
 template <int D> struct Ldl {
   double L[D][D], dinv[D];            // strict lower part of L used
@@ -1723,6 +1727,10 @@ template <int D> struct Ldl {
       x[f] = v;
     }
   }
+  DGP_HD void scale(const double (&x)[D], double (&xs)[D]) const {      // xs = Dg^-1 x
+#pragma unroll
+    for (int f = 0; f < D; ++f) xs[f] = dinv[f] * x[f];
+  }
   DGP_HD void solve(const double (&c)[D], double (&m)[D]) const {      // m = D^-1 c
     double y[D];
 #pragma unroll
@@ -1736,36 +1744,123 @@ template <int D> struct Ldl {
       m[f] = v;
     }
   }
+  // the factor of another lane, fetched value by value with `get` (nb.hi / nb.partner)
+  template <typename Get> DGP_HD void fetch(const Ldl& own, Get&& get) {
+#pragma unroll
+    for (int f = 0; f < D; ++f) {
+      dinv[f] = get(own.dinv[f]);
+#pragma unroll
+      for (int g = 0; g < f; ++g) L[f][g] = get(own.L[f][g]);
+    }
+  }
 };
+
+// The same with 2 x 2 BLOCK pivots of size H = D / 2 (-DDGP_PCR_LDL_BLOCK=1):  D = L B L^T,  L = [[I, 0],[L21, I]],  B = diag(B1, B2),
+// B1 = D11, L21 = D21 B1^-1, B2 = D22 - L21 D12; the H x H blocks are inverted by their adjugates (inv2 / inv3): TWO reciprocals and a
+// dependency chain like the block inverse's, the flop count of the scalar LDL^T (the scalings become H x H products).
+template <int D> struct BlockLdl {
+  static constexpr int H = D / 2;
+  Sym<H> B1i, B2i;
+  double L21[H][H];
+  template <typename OK>
+  DGP_HD void factor(const Sym<D>& S, OK& ok) {
+    Sym<H> P;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int c = a; c < H; ++c) P(a, c) = S(a, c);
+    sym_inverse<H>(P, B1i, ok);
+#pragma unroll
+    for (int i = 0; i < H; ++i)                     // L21 = D21 B1^-1,  D21[i][k] = S(k, H + i)
+#pragma unroll
+      for (int j = 0; j < H; ++j) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < H; ++k) t += S(k, H + i) * B1i(k, j);
+        L21[i][j] = t;
+      }
+    Sym<H> Q;
+#pragma unroll
+    for (int a = 0; a < H; ++a)
+#pragma unroll
+      for (int c = a; c < H; ++c) {                 // B2 = D22 - L21 D12
+        double t = S(H + a, H + c);
+#pragma unroll
+        for (int k = 0; k < H; ++k) t -= L21[a][k] * S(k, H + c);
+        Q(a, c) = t;
+      }
+    sym_inverse<H>(Q, B2i, ok);
+  }
+  DGP_HD void fwd(double (&x)[D]) const {           // x <- L^-1 x
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      double v = x[H + i];
+#pragma unroll
+      for (int k = 0; k < H; ++k) v -= L21[i][k] * x[k];
+      x[H + i] = v;
+    }
+  }
+  DGP_HD void scale(const double (&x)[D], double (&xs)[D]) const {      // xs = B^-1 x
+#pragma unroll
+    for (int a = 0; a < H; ++a) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < H; ++k) { t1 += B1i(a, k) * x[k]; t2 += B2i(a, k) * x[H + k]; }
+      xs[a] = t1; xs[H + a] = t2;
+    }
+  }
+  DGP_HD void solve(const double (&c)[D], double (&m)[D]) const {       // m = D^-1 c = L^-T B^-1 L^-1 c
+    double y[D];
+#pragma unroll
+    for (int f = 0; f < D; ++f) y[f] = c[f];
+    fwd(y);
+    scale(y, m);
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+      double v = m[k];
+#pragma unroll
+      for (int i = 0; i < H; ++i) v -= L21[i][k] * m[H + i];
+      m[k] = v;
+    }
+  }
+  template <typename Get> DGP_HD void fetch(const BlockLdl& own, Get&& get) {
+#pragma unroll
+    for (int i = 0; i < H * (H + 1) / 2; ++i) { B1i.v[i] = get(own.B1i.v[i]); B2i.v[i] = get(own.B2i.v[i]); }
+#pragma unroll
+    for (int i = 0; i < H; ++i)
+#pragma unroll
+      for (int k = 0; k < H; ++k) L21[i][k] = get(own.L21[i][k]);
+  }
+};
+#ifndef DGP_PCR_LDL_BLOCK
+#define DGP_PCR_LDL_BLOCK 0
+#endif
+template <int D> struct PcrFactor { typedef typename std::conditional<(DGP_PCR_LDL_BLOCK != 0), BlockLdl<D>, Ldl<D>>::type type; };
 
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   typedef Nbr<LPT, S, Ctx> NB;
+  typedef typename PcrFactor<D>::type FT;
   const NB nb(cx, i);
   const bool has_l = (i >= S);
   constexpr bool kFence = (D == 6);
   if constexpr (kFence) sched_fence();
-  Ldl<D> F;
+  FT F;
   F.factor(Dm, ok);
-  double qs[D];
+  double q[D], qs[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) qs[a] = r[a];
-  F.fwd(qs);
-#pragma unroll
-  for (int a = 0; a < D; ++a) qs[a] *= F.dinv[a];
+  for (int a = 0; a < D; ++a) q[a] = r[a];
+  F.fwd(q);
+  F.scale(q, qs);
   if constexpr (kFence) sched_fence();
   // ---- right neighbour: its factor and qs
   Mat<D> Zt;                        // Zt = U L_R^-T  (row a: L_R^-1 applied to row a of U)
   {
-    Ldl<D> FR;
+    FT FR;
     double qR[D];
+    FR.fetch(F, [&](double v) { return nb.hi(v); });
 #pragma unroll
-    for (int f = 0; f < D; ++f) {
-      FR.dinv[f] = nb.hi(F.dinv[f]);
-      qR[f] = nb.hi(qs[f]);
-#pragma unroll
-      for (int g = 0; g < f; ++g) FR.L[f][g] = nb.hi(F.L[f][g]);
-    }
+    for (int f = 0; f < D; ++f) qR[f] = nb.hi(qs[f]);
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       double row[D];
@@ -1780,8 +1875,7 @@ DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
 #pragma unroll
     for (int a = 0; a < D; ++a) {
       double zs[D];
-#pragma unroll
-      for (int f = 0; f < D; ++f) zs[f] = Zt.v[a][f] * FR.dinv[f];
+      FR.scale(Zt.v[a], zs);
 #pragma unroll
       for (int c = a; c < D; ++c) {
         double w = Dm(a, c);
@@ -1814,9 +1908,10 @@ DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
   Mat<D> Un;
 #pragma unroll
   for (int c = 0; c < D; ++c) {
-    double zsc[D];                  // column c of Zs = Dg^-1 Z
+    double zc[D], zsc[D];           // column c of Z and of Zs = B^-1 Z
 #pragma unroll
-    for (int f = 0; f < D; ++f) zsc[f] = F.dinv[f] * U.v[f][c];
+    for (int f = 0; f < D; ++f) zc[f] = U.v[f][c];
+    F.scale(zc, zsc);
 #pragma unroll
     for (int a = 0; a <= c; ++a) {
       double w = 0.0;
@@ -1844,22 +1939,18 @@ DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
 // the last round (one partner, see pcr_last_round) and the final solve on the factors
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_last_round_ldl(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
+  typedef typename PcrFactor<D>::type FT;
   const Nbr<LPT, S, Ctx> nb(cx, i);
-  Ldl<D> F, FP;
+  FT F, FP;
   F.factor(Dm, ok);
-  double qs[D], qP[D];
+  double q[D], qs[D], qP[D];
 #pragma unroll
-  for (int a = 0; a < D; ++a) qs[a] = r[a];
-  F.fwd(qs);
+  for (int a = 0; a < D; ++a) q[a] = r[a];
+  F.fwd(q);
+  F.scale(q, qs);
+  FP.fetch(F, [&](double v) { return nb.partner(v); });
 #pragma unroll
-  for (int a = 0; a < D; ++a) qs[a] *= F.dinv[a];
-#pragma unroll
-  for (int f = 0; f < D; ++f) {
-    FP.dinv[f] = nb.partner(F.dinv[f]);
-    qP[f] = nb.partner(qs[f]);
-#pragma unroll
-    for (int g = 0; g < f; ++g) FP.L[f][g] = nb.partner(F.L[f][g]);
-  }
+  for (int f = 0; f < D; ++f) qP[f] = nb.partner(qs[f]);
   Mat<D> K;
 #pragma unroll
   for (int a = 0; a < D; ++a)
@@ -1884,8 +1975,7 @@ DGP_HD void pcr_last_round_ldl(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, doub
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double zs[D];
-#pragma unroll
-    for (int f = 0; f < D; ++f) zs[f] = Kt.v[a][f] * FP.dinv[f];
+    FP.scale(Kt.v[a], zs);
 #pragma unroll
     for (int c = a; c < D; ++c) {
       double w = Dm(a, c);
@@ -1930,7 +2020,7 @@ DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], dou
   if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN>(cx, i, Dm, U, r, ok);
   if constexpr (LEAN && DGP_PCR_LEAN_D(D) && LPT != 64) sched_fence();
   if constexpr (LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && LPT == 16) {
-    Ldl<D> F;
+    typename PcrFactor<D>::type F;
     F.factor(Dm, ok);
     F.solve(r, x);
     return;
