@@ -1578,6 +1578,20 @@ DGP_HD void sched_fence() {
 #endif
 }
 
+// Scheduling fences at the PHASE boundaries of the program (where profiles/tools/phase_probe.hip puts its time stamps): with them the Woodbury STEP kernels
+// come out with fewer AGPR parking moves (d = 4: 134 -> 55) and run 0.7 % (d = 4: 10.14 -> 10.07 us) / 1.8 % (d = 6: 27.04 -> 26.54 us) faster
+// (profiles/r03_kernel_variants.txt, "marks" builds); the fused loop gets SLOWER with them (76.2 -> 77.3 us per 10 iterations), so only MODE_STEP of the
+// QK_WB / QK_WBR kernels has them (-DDGP_PHASE_FENCES=0: none).
+#ifndef DGP_PHASE_FENCES
+#define DGP_PHASE_FENCES 1
+#endif
+#ifndef DGP_PHASE_FENCES_BLOCK
+#define DGP_PHASE_FENCES_BLOCK 0      // phase fences in the block-elimination STEP kernels too (experiment)
+#endif
+template <bool ON> DGP_HD void phase_fence() {
+  if constexpr (ON && DGP_PHASE_FENCES != 0) sched_fence();
+}
+
 // pcr_round in a register-lean order (same arithmetic, same results as pcr_round): stage by stage, each block dies before the
 // next one is born -- peak 117 doubles for d = 6 (D, U, r, D^-1, y, D_R^-1, y_R) instead of ~200:
 //   1. D^-1, y = D^-1 r                       2. fetch D_R^-1, y_R;  row by row: T_a = U_a D_R^-1,  r_a -= U_a y_R,  D_a. -= T_a U^T
@@ -1672,7 +1686,10 @@ DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D]
       for (int k = 0; k < D; ++k) t -= U.v[a][k] * GRc[k];
       Un.v[a][c] = t;
     }
-    if (c % 2 == 1) sched_fence();
+#ifndef DGP_LEAN_COLFENCE
+#define DGP_LEAN_COLFENCE 2      // a fence after every DGP_LEAN_COLFENCE-th column of the last stage (0: none)
+#endif
+    if (DGP_LEAN_COLFENCE != 0 && c % (DGP_LEAN_COLFENCE ? DGP_LEAN_COLFENCE : 1) == (DGP_LEAN_COLFENCE ? DGP_LEAN_COLFENCE : 1) - 1) sched_fence();
   }
   U = Un;
   sched_fence();
@@ -2390,7 +2407,7 @@ DGP_HD void stash_get(Ctx& cx, int slot, Sym<D>& S) {
 // ---------------------------------------------------------------------------------------------------
 // `before_pcr(acc)` is called once every factor of the lane has been evaluated (the error partials are complete) and before
 // the PCR rounds: MODE_STEP reduces and stores err / err_ext there, off the tail of the kernel.
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, typename Ctx, typename Hook>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, bool PF = false, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
@@ -2412,6 +2429,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
     DGP_STAMP_NOWAIT(p, cx, 8);
+    phase_fence<PF>();
     // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
     double mu_ga[D];
 #pragma unroll
@@ -2432,11 +2450,14 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
     for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
     DGP_STAMP_NOWAIT(p, cx, 9);
+    phase_fence<PF>();
     lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
     DGP_STAMP_NOWAIT(p, cx, 10);
+    phase_fence<PF>();
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
+  phase_fence<PF>();
 #if defined(DGP_PHASE_STOP)     // profiles/tools/phase_probe.hip: cut the program short after a phase (timing aid, never in the product build)
   if (DGP_PHASE_STOP == 1 || DGP_PHASE_STOP == 2) {
 #pragma unroll
@@ -2617,6 +2638,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   }
 #endif
   DGP_STAMP_NOWAIT(p, cx, 3);
+  phase_fence<PF>();
   before_pcr(acc);
   double xs[D];
   pcr_solve<D, LPT, (QK != QK_GENERAL)>(cx, j, Ds, Us, rs, xs, ok);
@@ -2760,7 +2782,12 @@ DGP_HD void store_rows_through_lds(Ctx& cx, void* out, int64_t wave_first_elem, 
   typedef WaveStore<IO, C, D> WS;
   typedef IO V16 __attribute__((vector_size(16)));
   constexpr int EPV = 16 / (int)sizeof(IO);                       // elements per 16-byte cell
-  const int lane = cx.lane();
+  int lane = cx.lane();
+#if defined(__HIP_DEVICE_COMPILE__) && defined(DGP_EPILOGUE_OPAQUE_LANE)
+  // experiment: the store offsets are the load offsets of load_rows_through_lds -- left alone the compiler computes them once in the prologue and keeps
+  // them alive (in scratch, for d = 6) until here; an opaque lane index makes it recompute them
+  asm volatile("" : "+v"(lane));
+#endif
   char* l = cx.lds();
 #pragma unroll
   for (int i = 0; i < WS::kCells; ++i) {
@@ -2891,6 +2918,8 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const bool traj_ok = b < p.B;
 #endif
   DGP_STAMP_NOWAIT(p, cx, 0);
+  constexpr bool kPF = (is_wb(QK) || DGP_PHASE_FENCES_BLOCK != 0) && MODE == MODE_STEP;      // phase fences (see phase_fence)
+  phase_fence<kPF>();
 #if defined(__HIP_DEVICE_COMPILE__)
   // the scalars of the pixel-coordinate / tap-address arithmetic are fetched now, under the th load, instead of at their
   // first use right after it (the compiler places scalar loads in the block that first needs them)
@@ -2919,6 +2948,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
   DGP_STAMP(p, cx, 1);
+  phase_fence<kPF>();
 
   if (MODE == MODE_EVAL) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
@@ -2982,7 +3012,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 #ifndef DGP_WB_COLWISE_D6_STEP
 #define DGP_WB_COLWISE_D6_STEP 0      // order of the d = 6 step kernel's Schur assembly (tuning aid; see gn_linear_solve_wb)
 #endif
-      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE || DGP_WB_COLWISE_D6_STEP != 0), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE || DGP_WB_COLWISE_D6_STEP != 0), (QK == QK_WBR), (MODE == MODE_STEP)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
@@ -2993,10 +3023,11 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         }
       });
 #else
-      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, before_pcr);
+      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value, (MODE == MODE_STEP && DGP_PHASE_FENCES_BLOCK != 0)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, before_pcr);
 #endif
     }
     DGP_STAMP_NOWAIT(p, cx, 4);
+    phase_fence<kPF>();
     if (MODE == MODE_STEP) {
       // wave-uniform: the wavefront's dtheta rows are one contiguous, fully populated block -> full-line stores via LDS
       bool block_store = false;
@@ -3055,12 +3086,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     }
   }
   DGP_STAMP_NOWAIT(p, cx, 5);
+  phase_fence<kPF>();
   if (p.info) {                                        // (wave-uniform)
     const int base = lane & ~(LPT - 1);                // first lane of this trajectory's group
     const uint64_t grp = (LPT == 64) ? ok.bad : ((ok.bad >> base) & ((uint64_t(1) << (LPT & 63)) - 1));
     if (traj_ok && j == 0) p.info[b] = grp != 0 ? 1 : 0;
   }
   DGP_STAMP(p, cx, 6);
+  phase_fence<kPF>();
   if (MODE == MODE_SOLVE) {
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);
     if constexpr (kParkG) load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, x);

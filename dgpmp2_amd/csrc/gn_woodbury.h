@@ -364,7 +364,8 @@ DGP_HD void wb_park_get(Ctx& cx, double (&t)[3][2 * DOF], double (&hh)[R][2 * DO
 // d = 4 step 10.08 / 9.92 us) -- the callers choose.
 // RAGGED: the trajectory does not fill the shape (n < 4 LPT): the lane picks one of four table versions from g0 and n; otherwise
 // (every row of every lane exists) the first lane of a trajectory reads version 1, all others version 0.
-template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, bool RAGGED, typename Ctx, typename Hook>
+// PF: scheduling fences at the phase boundaries (phase_fence in gn_lane.h: the STEP kernels only).
+template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, bool RAGGED, bool PF = false, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[4][2 * DOF],
                                const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[4][2 * DOF],
                                double (&dx)[4][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, const WbStaged* staged, Hook&& before_pcr) {
@@ -389,6 +390,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
     DGP_STAMP_NOWAIT(p, cx, 8);
+    phase_fence<PF>();
     double mu_ga[D];
 #pragma unroll
     for (int a = 0; a < D; ++a) mu_ga[a] = mu_g[a];
@@ -403,13 +405,16 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
 #pragma unroll
     for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
     DGP_STAMP_NOWAIT(p, cx, 9);
+    phase_fence<PF>();
     lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
     DGP_STAMP_NOWAIT(p, cx, 10);
+    phase_fence<PF>();
     // the table: its loads were issued before the tap loads and vector loads return in order, so the cells are here
     if (staged) wb_stage_commit<RAGGED>(cx, *staged);
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
+  phase_fence<PF>();
   constexpr bool kFence = (D == 6);      // d = 6: keep the scheduler from interleaving the phases (see sched_fence)
   if constexpr (kFence) sched_fence();
   // this lane's version of the constants (ordinary rows / first lane / goal row inside / padding only)
@@ -621,6 +626,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
     }
   }
   DGP_STAMP_NOWAIT(p, cx, 3);
+  phase_fence<PF>();
   if constexpr (kFence) sched_fence();
   before_pcr(acc);
   // d = 6: what the interior recovery needs (t, the non-zeros of hh, the factorisation of S: WbPark<DOF>::kDoubles values) waits out the
