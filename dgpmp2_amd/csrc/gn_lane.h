@@ -2343,13 +2343,23 @@ DGP_HD void coup_get(const GnParams& p, const Coupling<D, N, QK_KRON>& cp, int k
 // slots of 11 x 16 bytes per block, lane stride a multiple of 16 bytes whose dword count / 4 is odd -> conflict-free 128-bit accesses.
 // NS = number of blocks the kernel's LDS budget allows (0: no stash; the rest stays in registers).
 // ---------------------------------------------------------------------------------------------------
-// how many S_k^-1 blocks a kernel parks in LDS.  Measured on d = 6, (16,4), B = 4096: the backward kernel (whose chain rule
-// follows the adjoint solve and needs every register again) 91.3 -> 71.2 us with all three blocks stashed; the step kernel is
-// indifferent (30.2 -> 30.1 us) and the fused loop LOSES (34.2 -> 38.7 us per iteration with two blocks) -- so only the backward does.
+// how many S_k^-1 blocks a kernel parks in LDS.  Measured on d = 6, (16,4), B = 4096, round 2: the backward kernel (whose chain rule
+// follows the adjoint solve and needs every register again) 91.3 -> 71.2 us with all three blocks stashed; the static step kernel of that
+// round was indifferent to three blocks (30.2 -> 30.1 us) and the fused loop LOST (34.2 -> 38.7 us per iteration with two blocks).
 enum { MODE_BACKWARD_SOLVE = 3 };
 template <int D, int C, int MODE> struct SinvStashBlocks {
   static constexpr int kInterior = (C > 1) ? C - 1 : 0;
-  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : 0;
+  // Round 3, STEP kernels with four states per lane (block elimination: static with velocity limits, per-state, general): TWO blocks parked --
+  // per-state 48.1 -> 44.7 us (one block 45.5, three 48.3), static + velocity limits 30.6 -> 29.3 us, q_full (16,4) 85.4 -> 83.7 us; the two-states-per-lane
+  // shapes do not react (profiles/r03_kernel_variants.txt).
+#ifndef DGP_STASH_STEP_D6
+#define DGP_STASH_STEP_D6 2
+#endif
+#ifndef DGP_STASH_SOLVE_D6
+#define DGP_STASH_SOLVE_D6 0      // experiment: the same for the fused loop
+#endif
+  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : ((D == 6 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D6 :
+                               ((D == 6 && MODE == MODE_SOLVE && C == 4) ? DGP_STASH_SOLVE_D6 : 0));
   static constexpr int value = kWant < kInterior ? kWant : kInterior;
 };
 template <int D, int NS> struct SinvStash {
@@ -2502,8 +2512,12 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   };
 
   // ---- a. + b. forward sweep over the interior rows
+#ifndef DGP_SWEEP_FENCES
+#define DGP_SWEEP_FENCES 0      // experiment: a scheduling fence between the rows of the d = 6 sweep
+#endif
 #pragma unroll
   for (int k = 0; k < C - 1; ++k) {
+    if constexpr (D == 6 && DGP_SWEEP_FENCES != 0) sched_fence();
     Sym<D> Dk; double rk[D];
     assemble(k, Dk, rk);
     if (k == 0) {
