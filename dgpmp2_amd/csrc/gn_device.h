@@ -12,18 +12,10 @@ namespace dgp_dev {
 
 // Device lane context: cross-lane fetches are ds_bpermute (any lane -> any lane inside the wavefront; the LDS
 // crossbar is used, no LDS memory is touched).
-// Wavefronts per workgroup of gn_kernel (experiment: -DDGP_WPB=4 packs four wavefronts -- one per SIMD of a CU -- into a workgroup, a
-// quarter of the workgroups for the dispatcher to place; the product launches one wavefront per workgroup)
-#ifndef DGP_WPB
-#define DGP_WPB 1
-#endif
-
 struct DevCtx {
   char* lds_;      // the workgroup's (= wavefront's) LDS staging block, dgp::WaveStore<...>::kLdsBytes
   char* stash_;    // dgp::SinvStash block (d = 6 kernels), or null
   char* wb_;       // LDS copy of the Woodbury constant table (QK_WB kernels), dgp::kWbLdsBytes
-  char* park_;     // dgp::WbPark block (d = 6 Woodbury kernels: the interior-recovery state across the PCR rounds), or null
-  __device__ __forceinline__ char* park() const { return park_; }
   char* long_;     // gn_long.h: the wavefront's dynamic LDS block (per-row S_k^-1, z_k slots), or null
   __device__ __forceinline__ char* long_lds() const { return long_; }
   // writes of this wavefront to global memory become visible to its own later loads (gn_long.h: MODE_SOLVE keeps the state in th_out)
@@ -35,15 +27,7 @@ struct DevCtx {
   __device__ __forceinline__ const double* wb_source(const dgp::GnParams&) const {
     return (const double*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(dgp::GnParams, wb_tab));
   }
-  // the LDS blocks are private to a wavefront: with one wavefront per workgroup __syncthreads() is elided by the compiler down to the
-  // waitcnt; with several (DGP_WPB > 1, experiment) only the compiler must be kept from reordering the LDS accesses across this point
-  __device__ __forceinline__ void lds_sync() const {
-#if DGP_WPB > 1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#else
-    __syncthreads();
-#endif
-  }
+  __device__ __forceinline__ void lds_sync() const { __syncthreads(); }      // one wavefront per workgroup
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
   __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
   __device__ __forceinline__ int fetch_i(int v, int src) const { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
@@ -123,7 +107,7 @@ __device__ __forceinline__ void warm_kernarg() {
 
 // QK: kernel variant by covariance representation, dgp::QK_* (static: the constant GP blocks are scalar operands; see gn_lane.h).
 template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
-__global__ void __launch_bounds__(64 * DGP_WPB, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
+__global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
   warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();      // (the Woodbury table behind it is read with vector loads)
   // STEP: staging block of the full-line th / dtheta accesses; SOLVE: the fp64 trajectory rows parked between iterations
   // (+ an S_k^-1 stash where SinvStashBlocks asks for one -- currently only the backward kernel does: in STEP mode it would ALIAS
@@ -132,15 +116,11 @@ __global__ void __launch_bounds__(64 * DGP_WPB, (WavesPerSimd<DOF, LPT, C, MODE>
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;
   constexpr int kLds = (MODE == dgp::MODE_SOLVE) ? kRows + kStash : (kRows > kStash ? kRows : kStash);
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
-  constexpr int kPark = dgp::is_wb(QK) ? dgp::WbPark<DOF, dgp::WbF<DOF>::R>::kBytes : 0;
-  constexpr int kPerWave = ((kLds + kWb + kPark + 15) / 16) * 16;
-  __shared__ __attribute__((aligned(16))) char lds_all[kPerWave * DGP_WPB];
-  char* lds = lds_all + (DGP_WPB > 1 ? (int)(threadIdx.x >> 6) * kPerWave : 0);
+  __shared__ __attribute__((aligned(16))) char lds[kLds + kWb];
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = (MODE == dgp::MODE_SOLVE) ? lds + kRows : lds;
   cx.wb_ = lds + kLds;
-  cx.park_ = lds + kLds + kWb;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
@@ -154,13 +134,11 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, 
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
-  constexpr int kPark = dgp::is_wb(QK) ? dgp::WbPark<DOF, dgp::WbF<DOF>::R>::kBytes : 0;
-  __shared__ __attribute__((aligned(16))) char lds[kAll + kWb + kPark];
+  __shared__ __attribute__((aligned(16))) char lds[kAll + kWb];
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = lds;
   cx.wb_ = lds + kAll;
-  cx.park_ = lds + kAll + kWb;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
 }
 
@@ -169,7 +147,7 @@ template <int DOF, typename IO, int MODE>
 __global__ void __launch_bounds__(64) gn_long_kernel(const dgp::GnParams p) {
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   DevCtx cx;
-  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr; cx.park_ = nullptr;
+  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr;
   cx.long_ = dyn_lds;
   dgp::gn_long_program<DOF, IO, MODE>(p, cx);
 }
@@ -177,7 +155,7 @@ template <int DOF, typename IO>
 __global__ void __launch_bounds__(64) gn_long_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   DevCtx cx;
-  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr; cx.park_ = nullptr;
+  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr;
   cx.long_ = dyn_lds;
   dgp::gn_long_backward_program<DOF, IO>(p, g, cx);
 }

@@ -761,11 +761,10 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
 template <int DOF>
 DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
                        const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
-                       double (&r)[2 * DOF], ErrAcc& acc, int n_fixed = -1) {
+                       double (&r)[2 * DOF], ErrAcc& acc) {
   // priors + GP factors: everything of row g that does NOT depend on the SDF lookup (runs while the taps are in flight)
-  // n_fixed: the trajectory length when the caller knows it at compile time (exact-fit Woodbury kernels: n = 4 LPT), else -1
   constexpr int D = 2 * DOF;
-  const int n = n_fixed >= 0 ? n_fixed : p.n;
+  const int n = p.n;
   const double dt = p.dt;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
   const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
@@ -812,9 +811,9 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
 
 // diagonal block of row g without the single-state factors; m_next = 1 iff the row couples to row g+1
 template <int DOF>
-DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next, int n_fixed = -1) {
+DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next) {
   constexpr int D = 2 * DOF;
-  const int n = n_fixed >= 0 ? n_fixed : p.n;
+  const int n = p.n;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
   const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
   m_next = mN;
@@ -1385,10 +1384,7 @@ template <int LPT> DGP_HD int row_to_lane(int j) {
 // their own value (bpermute); both are harmless because the coupling block that multiplies the fetched data is zero there.
 template <int LPT, int S, typename Ctx>
 struct Nbr {
-#ifndef DGP_NBR_BPERMUTE_MASK
-#define DGP_NBR_BPERMUTE_MASK 0      // experiment: bit log2(S) set -> the exchanges of PCR stride S go through ds_bpermute (LDS crossbar) instead of DPP moves
-#endif
-  static constexpr bool kDpp = ((LPT == 16) || (LPT == 32 && S >= 2)) && !((DGP_NBR_BPERMUTE_MASK) & S);     // DPP path: missing neighbours read as 0
+  static constexpr bool kDpp = (LPT == 16) || (LPT == 32 && S >= 2);     // DPP path: missing neighbours read as 0
   static constexpr int kShift = (LPT == 32) ? S / 2 : S;                  // lane distance inside the DPP row
   Ctx& cx;
   int src_lo, src_hi, src_par;
@@ -1585,9 +1581,6 @@ DGP_HD void sched_fence() {
 #ifndef DGP_PHASE_FENCES
 #define DGP_PHASE_FENCES 1
 #endif
-#ifndef DGP_PHASE_FENCES_BLOCK
-#define DGP_PHASE_FENCES_BLOCK 0      // phase fences in the block-elimination STEP kernels too (experiment)
-#endif
 template <bool ON> DGP_HD void phase_fence() {
   if constexpr (ON && DGP_PHASE_FENCES != 0) sched_fence();
 }
@@ -1686,10 +1679,7 @@ DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D]
       for (int k = 0; k < D; ++k) t -= U.v[a][k] * GRc[k];
       Un.v[a][c] = t;
     }
-#ifndef DGP_LEAN_COLFENCE
-#define DGP_LEAN_COLFENCE 2      // a fence after every DGP_LEAN_COLFENCE-th column of the last stage (0: none)
-#endif
-    if (DGP_LEAN_COLFENCE != 0 && c % (DGP_LEAN_COLFENCE ? DGP_LEAN_COLFENCE : 1) == (DGP_LEAN_COLFENCE ? DGP_LEAN_COLFENCE : 1) - 1) sched_fence();
+    if (c % 2 == 1) sched_fence();
   }
   U = Un;
   sched_fence();
@@ -1705,8 +1695,8 @@ DGP_HD void pcr_round_lean(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D]
 // ~1 160 for d = 6 -- at the price of d dependent pivots where the block inverse has two.  Stage order as in pcr_round_lean.
 // Measured (round 3, profiles/r03_kernel_variants.txt, B = 4096): d = 4 step 3 718 -> 3 436 instructions, 10.23 -> 10.10 us, fused loop 8.02 -> 7.58 us
 // per iteration; d = 6 8 793 instead of 9 511 instructions but 26.5-27.2 against 26.9-27.1 us (the six dependent pivots and 260 more AGPR moves eat the
-// saving).  A variant with two BLOCK pivots (BlockLdl: the chain of the block inverse, the flops of the LDL^T) is slower than the scalar one
-// for d = 4 (10.14 us) and for the d = 6 step (27.5 us).  Hence: d = 4 only, scalar pivots.
+// saving).  A variant with two BLOCK pivots (the chain of the block inverse, the flops of the LDL^T; profiles/tools/r03_experiments.patch) is slower
+// than the scalar one for d = 4 (10.14 us) and for the d = 6 step (27.5 us).  Hence: d = 4 only, scalar pivots.
 // ---------------------------------------------------------------------------------------------------
 #ifndef DGP_PCR_LDL
 #define DGP_PCR_LDL 4
@@ -1772,92 +1762,10 @@ template <int D> struct Ldl {
   }
 };
 
-// The same with 2 x 2 BLOCK pivots of size H = D / 2 (-DDGP_PCR_LDL_BLOCK=1):  D = L B L^T,  L = [[I, 0],[L21, I]],  B = diag(B1, B2),
-// B1 = D11, L21 = D21 B1^-1, B2 = D22 - L21 D12; the H x H blocks are inverted by their adjugates (inv2 / inv3): TWO reciprocals and a
-// dependency chain like the block inverse's, the flop count of the scalar LDL^T (the scalings become H x H products).
-template <int D> struct BlockLdl {
-  static constexpr int H = D / 2;
-  Sym<H> B1i, B2i;
-  double L21[H][H];
-  template <typename OK>
-  DGP_HD void factor(const Sym<D>& S, OK& ok) {
-    Sym<H> P;
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int c = a; c < H; ++c) P(a, c) = S(a, c);
-    sym_inverse<H>(P, B1i, ok);
-#pragma unroll
-    for (int i = 0; i < H; ++i)                     // L21 = D21 B1^-1,  D21[i][k] = S(k, H + i)
-#pragma unroll
-      for (int j = 0; j < H; ++j) {
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < H; ++k) t += S(k, H + i) * B1i(k, j);
-        L21[i][j] = t;
-      }
-    Sym<H> Q;
-#pragma unroll
-    for (int a = 0; a < H; ++a)
-#pragma unroll
-      for (int c = a; c < H; ++c) {                 // B2 = D22 - L21 D12
-        double t = S(H + a, H + c);
-#pragma unroll
-        for (int k = 0; k < H; ++k) t -= L21[a][k] * S(k, H + c);
-        Q(a, c) = t;
-      }
-    sym_inverse<H>(Q, B2i, ok);
-  }
-  DGP_HD void fwd(double (&x)[D]) const {           // x <- L^-1 x
-#pragma unroll
-    for (int i = 0; i < H; ++i) {
-      double v = x[H + i];
-#pragma unroll
-      for (int k = 0; k < H; ++k) v -= L21[i][k] * x[k];
-      x[H + i] = v;
-    }
-  }
-  DGP_HD void scale(const double (&x)[D], double (&xs)[D]) const {      // xs = B^-1 x
-#pragma unroll
-    for (int a = 0; a < H; ++a) {
-      double t1 = 0.0, t2 = 0.0;
-#pragma unroll
-      for (int k = 0; k < H; ++k) { t1 += B1i(a, k) * x[k]; t2 += B2i(a, k) * x[H + k]; }
-      xs[a] = t1; xs[H + a] = t2;
-    }
-  }
-  DGP_HD void solve(const double (&c)[D], double (&m)[D]) const {       // m = D^-1 c = L^-T B^-1 L^-1 c
-    double y[D];
-#pragma unroll
-    for (int f = 0; f < D; ++f) y[f] = c[f];
-    fwd(y);
-    scale(y, m);
-#pragma unroll
-    for (int k = 0; k < H; ++k) {
-      double v = m[k];
-#pragma unroll
-      for (int i = 0; i < H; ++i) v -= L21[i][k] * m[H + i];
-      m[k] = v;
-    }
-  }
-  template <typename Get> DGP_HD void fetch(const BlockLdl& own, Get&& get) {
-#pragma unroll
-    for (int i = 0; i < H * (H + 1) / 2; ++i) { B1i.v[i] = get(own.B1i.v[i]); B2i.v[i] = get(own.B2i.v[i]); }
-#pragma unroll
-    for (int i = 0; i < H; ++i)
-#pragma unroll
-      for (int k = 0; k < H; ++k) L21[i][k] = get(own.L21[i][k]);
-  }
-};
-#ifndef DGP_PCR_LDL_BLOCK
-#define DGP_PCR_LDL_BLOCK 0
-#endif
-template <int D> struct PcrFactor { typedef typename std::conditional<(DGP_PCR_LDL_BLOCK != 0), BlockLdl<D>, Ldl<D>>::type type; };
-
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   typedef Nbr<LPT, S, Ctx> NB;
-  typedef typename PcrFactor<D>::type FT;
+  typedef Ldl<D> FT;
   const NB nb(cx, i);
   const bool has_l = (i >= S);
   constexpr bool kFence = (D == 6);
@@ -1956,7 +1864,7 @@ DGP_HD void pcr_round_ldl(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
 // the last round (one partner, see pcr_last_round) and the final solve on the factors
 template <int D, int LPT, int S, typename Ctx>
 DGP_HD void pcr_last_round_ldl(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
-  typedef typename PcrFactor<D>::type FT;
+  typedef Ldl<D> FT;
   const Nbr<LPT, S, Ctx> nb(cx, i);
   FT F, FP;
   F.factor(Dm, ok);
@@ -2037,7 +1945,7 @@ DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], dou
   if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN>(cx, i, Dm, U, r, ok);
   if constexpr (LEAN && DGP_PCR_LEAN_D(D) && LPT != 64) sched_fence();
   if constexpr (LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && LPT == 16) {
-    typename PcrFactor<D>::type F;
+    Ldl<D> F;
     F.factor(Dm, ok);
     F.solve(r, x);
     return;
@@ -2351,15 +2259,11 @@ template <int D, int C, int MODE> struct SinvStashBlocks {
   static constexpr int kInterior = (C > 1) ? C - 1 : 0;
   // Round 3, STEP kernels with four states per lane (block elimination: static with velocity limits, per-state, general): TWO blocks parked --
   // per-state 48.1 -> 44.7 us (one block 45.5, three 48.3), static + velocity limits 30.6 -> 29.3 us, q_full (16,4) 85.4 -> 83.7 us; the two-states-per-lane
-  // shapes do not react (profiles/r03_kernel_variants.txt).
+  // shapes do not react, and the fused loop loses with one block or two (profiles/r03_kernel_variants.txt).
 #ifndef DGP_STASH_STEP_D6
 #define DGP_STASH_STEP_D6 2
 #endif
-#ifndef DGP_STASH_SOLVE_D6
-#define DGP_STASH_SOLVE_D6 0      // experiment: the same for the fused loop
-#endif
-  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : ((D == 6 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D6 :
-                               ((D == 6 && MODE == MODE_SOLVE && C == 4) ? DGP_STASH_SOLVE_D6 : 0));
+  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : ((D == 6 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D6 : 0);
   static constexpr int value = kWant < kInterior ? kWant : kInterior;
 };
 template <int D, int NS> struct SinvStash {
@@ -2417,7 +2321,7 @@ DGP_HD void stash_get(Ctx& cx, int slot, Sym<D>& S) {
 // ---------------------------------------------------------------------------------------------------
 // `before_pcr(acc)` is called once every factor of the lane has been evaluated (the error partials are complete) and before
 // the PCR rounds: MODE_STEP reduces and stores err / err_ext there, off the tail of the kernel.
-template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, bool PF = false, typename Ctx, typename Hook>
+template <int DOF, int LPT, int C, typename IO, bool RHS_OVERRIDE, int QK, int NS, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF],
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
@@ -2439,7 +2343,6 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
     LaneTaps<C, IO> taps;
     lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
     DGP_STAMP_NOWAIT(p, cx, 8);
-    phase_fence<PF>();
     // (the goal mean, which every row's arithmetic reads, is tied to the tap ADDRESSES, so that the loads are issued first)
     double mu_ga[D];
 #pragma unroll
@@ -2460,14 +2363,11 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
 #pragma unroll
     for (int k = 0; k < C; ++k) { anchor[2 * k] = rgp[k][0]; anchor[2 * k + 1] = rgp[k][D - 1]; }
     DGP_STAMP_NOWAIT(p, cx, 9);
-    phase_fence<PF>();
     lane_taps_use_after<C, IO, 2 * C>(taps, anchor);
     DGP_STAMP_NOWAIT(p, cx, 10);
-    phase_fence<PF>();
     lane_obstacle_finish<C, IO>(p, g0, traj_ok, taps, lf);
   }
   DGP_STAMP_NOWAIT(p, cx, 2);
-  phase_fence<PF>();
 #if defined(DGP_PHASE_STOP)     // profiles/tools/phase_probe.hip: cut the program short after a phase (timing aid, never in the product build)
   if (DGP_PHASE_STOP == 1 || DGP_PHASE_STOP == 2) {
 #pragma unroll
@@ -2512,12 +2412,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   };
 
   // ---- a. + b. forward sweep over the interior rows
-#ifndef DGP_SWEEP_FENCES
-#define DGP_SWEEP_FENCES 0      // experiment: a scheduling fence between the rows of the d = 6 sweep
-#endif
 #pragma unroll
   for (int k = 0; k < C - 1; ++k) {
-    if constexpr (D == 6 && DGP_SWEEP_FENCES != 0) sched_fence();
     Sym<D> Dk; double rk[D];
     assemble(k, Dk, rk);
     if (k == 0) {
@@ -2652,7 +2548,6 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   }
 #endif
   DGP_STAMP_NOWAIT(p, cx, 3);
-  phase_fence<PF>();
   before_pcr(acc);
   double xs[D];
   pcr_solve<D, LPT, (QK != QK_GENERAL)>(cx, j, Ds, Us, rs, xs, ok);
@@ -2796,12 +2691,7 @@ DGP_HD void store_rows_through_lds(Ctx& cx, void* out, int64_t wave_first_elem, 
   typedef WaveStore<IO, C, D> WS;
   typedef IO V16 __attribute__((vector_size(16)));
   constexpr int EPV = 16 / (int)sizeof(IO);                       // elements per 16-byte cell
-  int lane = cx.lane();
-#if defined(__HIP_DEVICE_COMPILE__) && defined(DGP_EPILOGUE_OPAQUE_LANE)
-  // experiment: the store offsets are the load offsets of load_rows_through_lds -- left alone the compiler computes them once in the prologue and keeps
-  // them alive (in scratch, for d = 6) until here; an opaque lane index makes it recompute them
-  asm volatile("" : "+v"(lane));
-#endif
+  const int lane = cx.lane();
   char* l = cx.lds();
 #pragma unroll
   for (int i = 0; i < WS::kCells; ++i) {
@@ -2926,13 +2816,9 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   const int j = lane_to_row<LPT>(lane & (LPT - 1));      // block row of the LPT-row system owned by this lane
   const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
   const int n = p.n;
-#if defined(DGP_ASSUME_FULL)      // experiment only (profiles/tools/kprobe.sh): what the masks of non-existent trajectories cost
-  const bool traj_ok = true;
-#else
   const bool traj_ok = b < p.B;
-#endif
   DGP_STAMP_NOWAIT(p, cx, 0);
-  constexpr bool kPF = (is_wb(QK) || DGP_PHASE_FENCES_BLOCK != 0) && MODE == MODE_STEP;      // phase fences (see phase_fence)
+  constexpr bool kPF = is_wb(QK) && MODE == MODE_STEP;      // phase fences (see phase_fence)
   phase_fence<kPF>();
 #if defined(__HIP_DEVICE_COMPILE__)
   // the scalars of the pixel-coordinate / tap-address arithmetic are fetched now, under the th load, instead of at their
@@ -2991,28 +2877,12 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   // the fused loop; the d = 6 fused kernels therefore keep their state in registers, as in round 1.
   constexpr bool kPark = (MODE == MODE_SOLVE) && (D == 4);
   if constexpr (kPark) lds_put_rows<C, D>(cx, x);
-  // d = 6 fused loop: the state waits out the elimination + PCR in th_out itself (global memory, L2-resident: a lane re-reads only the rows
-  // it wrote) instead of in 2 C d vector registers -- the LDS variant of this is what hipcc miscompiled (above); I/O-typed, so only for
-  // fp64 I/O is the state carried at full precision: fp32 I/O keeps it in registers
-#ifndef DGP_SOLVE_PARK_GLOBAL
-#define DGP_SOLVE_PARK_GLOBAL 0
-#endif
-  constexpr bool kParkG = (MODE == MODE_SOLVE) && (D == 6) && (DGP_SOLVE_PARK_GLOBAL != 0) && (DGP_SOLVE_PARK_GLOBAL == 2 || sizeof(IO) == 8);
-  auto put_global = [&](const double (&v)[C][D]) {
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-      const int g = j * C + k;
-      if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, v[k]);
-    }
-  };
-  if constexpr (kParkG) put_global(x);
 #pragma unroll 1
   for (int it = 0; it < iters_max; ++it) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
     double dx[C][D];
     if constexpr (MODE == MODE_SOLVE && (DGP_SOLVE_OPAQUE_Q == 1 || DGP_SOLVE_OPAQUE_Q == D)) lane_q_opaque<D, C>(lq);
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);       // the state comes back from LDS
-    if constexpr (kParkG) load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, x);
     double e = 0.0, ee = 0.0;
     auto before_pcr = [&](const ErrAcc& a) {
       e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);
@@ -3023,10 +2893,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     };
     if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-#ifndef DGP_WB_COLWISE_D6_STEP
-#define DGP_WB_COLWISE_D6_STEP 0      // order of the d = 6 step kernel's Schur assembly (tuning aid; see gn_linear_solve_wb)
-#endif
-      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE || DGP_WB_COLWISE_D6_STEP != 0), (QK == QK_WBR), (MODE == MODE_STEP)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE), (QK == QK_WBR), (MODE == MODE_STEP)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {
@@ -3037,7 +2904,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         }
       });
 #else
-      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value, (MODE == MODE_STEP && DGP_PHASE_FENCES_BLOCK != 0)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, before_pcr);
+      gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, before_pcr);
 #endif
     }
     DGP_STAMP_NOWAIT(p, cx, 4);
@@ -3079,14 +2946,6 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 #pragma unroll
             for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;   // th_new = th_curr + dtheta (:144)
           lds_put_rows<C, D>(cx, xc);
-        } else if constexpr (kParkG) {
-          double xc[C][D];
-          load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, xc);
-#pragma unroll
-          for (int k = 0; k < C; ++k)
-#pragma unroll
-            for (int a = 0; a < D; ++a) xc[k][a] += (j * C + k < n) ? dx[k][a] : 0.0;
-          put_global(xc);
         } else {
 #pragma unroll
           for (int k = 0; k < C; ++k)
@@ -3110,13 +2969,10 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   phase_fence<kPF>();
   if (MODE == MODE_SOLVE) {
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);
-    if constexpr (kParkG) load_lane_rows<DOF, C, IO>(p, p.th_out, b, j * C, traj_ok, vec, x);
-    if constexpr (!kParkG) {
 #pragma unroll
-      for (int k = 0; k < C; ++k) {
-        const int g = j * C + k;
-        if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, x[k]);
-      }
+    for (int k = 0; k < C; ++k) {
+      const int g = j * C + k;
+      if (traj_ok && g < n) st_row<IO, D>(p.th_out, b * n + g, vec, x[k]);
     }
     if (traj_ok && j == 0 && p.iters) p.iters[b] = my_iters;
     if (p.err_final) {

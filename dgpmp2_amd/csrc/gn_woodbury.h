@@ -275,88 +275,6 @@ struct WbSolver<3> {
   }
 };
 
-// LDS parking of the state a lane keeps across the PCR rounds (d = 6 only): lane-private slots, 16-byte cells, lane stride an odd
-// number of cells (conflict-free 128-bit accesses).  Packed: t (3 x d), per interior state the 2 + 3 non-zeros of hh (obstacle x, y;
-// non-holonomic theta, v_x, v_y), L (strict lower, R (R - 1) / 2) and dinv (R) of the LDL^T factorisation.
-#ifndef DGP_WB_PARK
-#define DGP_WB_PARK 0      // experiment (profiles/tools/kprobe.sh -DDGP_WB_PARK=1): measured worse, see DESIGN.md section 5
-#endif
-// DGP_WB_PARK: 0 nothing parked; 1 everything (t, hh, the factorisation); 2 the factorisation only (L, dinv: 21 doubles); 3 t only (18 doubles)
-template <int DOF, int R> struct WbPark {
-  static constexpr int kMode = DGP_WB_PARK;
-  static constexpr bool kUse = (DOF == 3) && (R == 6) && (kMode != 0);
-  static constexpr bool kT = kMode == 1 || kMode == 3, kH = kMode == 1, kS = kMode == 1 || kMode == 2;
-  static constexpr int kDoubles = (kT ? 3 * 2 * DOF : 0) + (kH ? 3 * 5 : 0) + (kS ? R * (R - 1) / 2 + R : 0);
-  static constexpr int kCells = (kDoubles + 1) / 2;
-  static constexpr int kStride = ((kCells % 2) ? kCells : kCells + 1) * 16;        // bytes per lane
-  static constexpr int kBytes = kUse ? 64 * kStride : 0;
-};
-template <int DOF, int R, typename Ctx, typename SV>
-DGP_HD void wb_park_put(Ctx& cx, const double (&t)[3][2 * DOF], const double (&hh)[R][2 * DOF], const SV& sv) {
-  typedef double V2 __attribute__((vector_size(16)));
-  typedef WbPark<DOF, R> P;
-  constexpr int N = P::kDoubles;
-  double v[N + 2];
-  int q = 0;
-  if constexpr (P::kT) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int a = 0; a < 2 * DOF; ++a) v[q++] = t[k][a];
-  }
-  if constexpr (P::kH) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      v[q++] = hh[2 * k][0]; v[q++] = hh[2 * k][1];
-      v[q++] = hh[2 * k + 1][2]; v[q++] = hh[2 * k + 1][DOF]; v[q++] = hh[2 * k + 1][DOF + 1];
-    }
-  }
-  if constexpr (P::kS) {
-#pragma unroll
-    for (int i = 1; i < R; ++i)
-#pragma unroll
-      for (int k = 0; k < i; ++k) v[q++] = sv.L[i][k];
-#pragma unroll
-    for (int i = 0; i < R; ++i) v[q++] = sv.dinv[i];
-  }
-  v[N] = 0.0;
-  char* l = cx.park() + cx.lane() * P::kStride;
-#pragma unroll
-  for (int i = 0; i < P::kCells; ++i) { V2 c; c[0] = v[2 * i]; c[1] = v[2 * i + 1 <= N ? 2 * i + 1 : N]; *(V2*)(l + i * 16) = c; }
-}
-template <int DOF, int R, typename Ctx, typename SV>
-DGP_HD void wb_park_get(Ctx& cx, double (&t)[3][2 * DOF], double (&hh)[R][2 * DOF], SV& sv) {
-  typedef double V2 __attribute__((vector_size(16)));
-  typedef WbPark<DOF, R> P;
-  constexpr int N = P::kDoubles;
-  double v[N + 2];
-  const char* l = cx.park() + cx.lane() * P::kStride;
-#pragma unroll
-  for (int i = 0; i < P::kCells; ++i) { const V2 c = *(const V2*)(l + i * 16); v[2 * i] = c[0]; v[2 * i + 1] = c[1]; }
-  int q = 0;
-  if constexpr (P::kT) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-      for (int a = 0; a < 2 * DOF; ++a) t[k][a] = v[q++];
-  }
-  if constexpr (P::kH) {
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      hh[2 * k][0] = v[q++]; hh[2 * k][1] = v[q++];
-      hh[2 * k + 1][2] = v[q++]; hh[2 * k + 1][DOF] = v[q++]; hh[2 * k + 1][DOF + 1] = v[q++];
-    }
-  }
-  if constexpr (P::kS) {
-#pragma unroll
-    for (int i = 1; i < R; ++i)
-#pragma unroll
-      for (int k = 0; k < i; ++k) sv.L[i][k] = v[q++];
-#pragma unroll
-    for (int i = 0; i < R; ++i) sv.dinv[i] = v[q++];
-  }
-}
-
 // `staged`: the table cells this lane still has to commit to LDS (first solve of a launch), or null.
 // COLWISE: order of the Schur assembly.  true: one column of S^-1 B at a time (no Z arrays); false: Z_p, Z_s formed up front, entries
 // row by row.  Same arithmetic; which one the compiler turns into the better d = 6 kernel depends on the surrounding program
@@ -372,13 +290,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   constexpr int D = 2 * DOF, C = 4;
   typedef WbF<DOF> F;
   constexpr int NF = F::NF, R = F::R;
-#ifndef DGP_WB_NFIX
-#define DGP_WB_NFIX 0
-#endif
-  // exact-fit kernels (RAGGED = false: host-checked n == 4 LPT): the length is a compile-time constant, so the row-existence tests
-  // (g < n, g == n - 1) of the lane's rows fold into comparisons of the lane index
-  const int n = (!RAGGED && DGP_WB_NFIX) ? LPT * C : p.n;
-  const int nfix = (!RAGGED && DGP_WB_NFIX) ? LPT * C : -1;
+  const int n = p.n;
   const Nbr<LPT, 1, Ctx> nb(cx, j);
   double x_prev[D], x_next[D];
 #pragma unroll
@@ -399,7 +311,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
     for (int k = 0; k < C; ++k) {
       const double (&xm)[D] = (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0];
       const double (&xp)[D] = (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0];
-      static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, rgp[k], acc, nfix);
+      static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, rgp[k], acc);
     }
     double anchor[2 * C];
 #pragma unroll
@@ -455,7 +367,7 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   // ---- separator row (block elimination form: D_s, r_s with every factor of the state)
   Sym<D> Ds; Mat<D> Us; double rs[D];
   double m_s;
-  static_diag<DOF>(p, g0 + C - 1, traj_ok && g0 + C - 1 < n, Ds, m_s, nfix);
+  static_diag<DOF>(p, g0 + C - 1, traj_ok && g0 + C - 1 < n, Ds, m_s);
 #pragma unroll
   for (int a = 0; a < D; ++a) rs[a] = rgp[C - 1][a];
   eval_state_local<DOF, true>(p, x[C - 1], lf.ow[C - 1], lf.oc[C - 1], lf.ohx[C - 1], lf.ohy[C - 1], Ds, rs, acc);
@@ -629,13 +541,9 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   phase_fence<PF>();
   if constexpr (kFence) sched_fence();
   before_pcr(acc);
-  // d = 6: what the interior recovery needs (t, the non-zeros of hh, the factorisation of S: WbPark<DOF>::kDoubles values) waits out the
-  // PCR rounds in LDS instead of in AGPRs / scratch -- the rounds need every register (a lean round peaks at 117 live doubles).
-  if constexpr (WbPark<DOF, R>::kUse) wb_park_put<DOF, R>(cx, t, hh, sv);
   double xs[D];
   pcr_solve<D, LPT, true>(cx, j, Ds, Us, rs, xs, ok);
   if constexpr (kFence) sched_fence();
-  if constexpr (WbPark<DOF, R>::kUse) wb_park_get<DOF, R>(cx, t, hh, sv);
 #pragma unroll
   for (int a = 0; a < D; ++a) dx[C - 1][a] = xs[a];
   // ---- interior rows: y = K q - K H M H^T K q,  K q = t - (K Cp) x_ps - (K Cs) x_s

@@ -117,7 +117,7 @@ int main(int argc, char** argv) {
   if (dgp::is_wb(PROBE_QK) && !dgp::wb_applies(p, PROBE_LPT, PROBE_C)) { printf("Woodbury kernel does not apply to this configuration\n"); return 1; }
   const int tpw = 64 / PROBE_LPT;
   const int waves = (B + tpw - 1) / tpw;
-  const dim3 grid((waves + DGP_WPB - 1) / DGP_WPB), block(64 * DGP_WPB);      // -DDGP_WPB=4: four wavefronts per workgroup (gn_device.h)
+  const dim3 grid(waves), block(64);
   int launch_no = 0;
   auto launch = [&]() {
     p.th = d_th + (size_t)(launch_no++ % NBUF) * th.size();
