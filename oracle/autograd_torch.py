@@ -129,6 +129,19 @@ def plan_layer_forward(th, start, goal, sdf, qc, ow, eps, p, q_full=False):
   return dth, err, err_ext
 
 
+def normal_equations(th, start, goal, sdf, qc, ow, eps, p, q_full=False):
+  """(Lambda (B,N,N), eta (B,N,1)) = (A^T K A + delta I, A^T K b) of plan_layer.py:217-220 as fp64 torch tensors, every factor row present (velocity-limit AND
+  non-holonomic rows side by side; the reference's own mask layout would let them overlap) -- the dense system the kernels solve."""
+  B, n, d = th.shape
+  Q_inv = qc if q_full else DT._q_inv(qc, p.dt)
+  rows = factors(th, start, goal, sdf, eps, p)
+  A = torch.cat([H for _, _, H in rows], 1)
+  b = torch.cat([e for _, e, _ in rows], 1)
+  K = torch.stack([torch.block_diag(*[_weights(name, B, n, d, Q_inv, ow, p)[bb] for name, _, _ in rows]) for bb in range(B)], 0)
+  AtK = torch.bmm(A.transpose(1, 2), K)
+  return torch.bmm(AtK, A) + p.reg * torch.eye(n * d, dtype=torch.float64), torch.bmm(AtK, b)
+
+
 def unweighted_errors(th, start, goal, sdf, eps, p):
   """plan_layer.py:374-388 -> (err_sg (B,1), err_gp (B,1,1), err_obs (B,1,1))."""
   B, n, d = th.shape
