@@ -205,17 +205,21 @@ class DiffGPMP2Planner(nn.Module):
     sd = pl._sdf_args(sdfb, dt, B, idx)
     th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
     th_out = torch.empty_like(th0)
-    iters = torch.empty(B, dtype=torch.int32, device=dev)
-    eh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
-    eeh = torch.full((B, max_iters), float('nan'), dtype=dt, device=dev)
-    ef = torch.empty(B, dtype=dt, device=dev)
+    # the per-sample outputs share ONE device buffer -- err history | err_ext history | final error | iteration counts -- so that one fill (NaN: entries
+    # past a sample's last iteration stay untouched) and ONE device-to-host copy serve all four (each separate copy costs a synchronisation of its own)
+    m = max_iters
+    buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dt, device=dev)
+    eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
+    iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts in the last B elements' storage
     info = torch.empty(B, dtype=torch.int32, device=dev)
     _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
             max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
     pl.last_info = info
     pl._last = (st, go, None, None, None)
-    jb = iters.cpu().tolist()                       # synchronises
-    eh_c, eeh_c, ef_c = eh.cpu().numpy(), eeh.cpu().numpy(), ef.cpu().numpy()
+    host = buf.cpu()                                # synchronises
+    eh_c, eeh_c = host[:B * m].view(B, m).numpy(), host[B * m:2 * B * m].view(B, m).numpy()
+    ef_c = host[2 * B * m:2 * B * m + B].numpy()
+    jb = host[2 * B * m + B:].view(torch.int32)[:B].tolist()
     t = time.time() - start_t
     return (th_out, None, eh_c[:, 0].tolist(), ef_c.tolist(), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), jb, [t] * B)
 
