@@ -29,7 +29,9 @@ struct DevCtx {
   }
   __device__ __forceinline__ void lds_sync() const { __syncthreads(); }      // one wavefront per workgroup
   __device__ __forceinline__ int lane() const { return (int)(threadIdx.x & 63u); }
-  __device__ __forceinline__ int wave() const { return (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); }
+  // one wavefront per workgroup: every launch uses block(64).  (blockDim.x is a scalar load from the HIDDEN kernel arguments, behind the lines
+  // warm_kernarg touches: one more exposed miss in front of the first row load -- 0.25 us of the d = 4 step.)
+  __device__ __forceinline__ int wave() const { return (int)blockIdx.x; }
   __device__ __forceinline__ int fetch_i(int v, int src) const { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
   __device__ __forceinline__ double fetch(double v, int src) const {
     int lo = __double2loint(v), hi = __double2hiint(v);

@@ -15,7 +15,7 @@
 // Nothing is unrolled over rows, so the kernels are small (no spills) whatever n is; they are ~3x slower per state than the
 // unrolled ones (memory round trips per row instead of once per launch) -- a correctness path for lengths the benchmark
 // configurations never reach, not a tuned one.  Limit: the LDS block, (Cn - 1) (d (d + 1) / 2 + d) doubles per lane:
-// n <= 1024 for d = 4, n <= 768 for d = 6 (dgp_host::kMaxStatesLong*).
+// n <= 1024 for d = 4, n <= 640 for d = 6 (dgp_host::kMaxStatesLong*).
 #pragma once
 #include "gn_lane.h"
 #include "gn_backward.h"

@@ -303,3 +303,10 @@ class DiffGPMP2Planner(nn.Module):
     if mode == 'fix_dynamics':
       return obscov_inv_traj
     return qc_inv_traj, obscov_inv_traj
+
+  def get_obs_covariance(self, out):
+    """Learn-module output (num_obs_factors values) -> per-state obstacle information blocks (num_obs_factors, nlinks, nlinks):
+    out_k^2 on the diagonal (diff_gpmp2_planner.py:293-297)."""
+    nl = self.robot_model.nlinks
+    w = (out * out).reshape(self.num_obs_factors, 1, 1)
+    return w * torch.eye(nl, device=out.device, dtype=out.dtype)

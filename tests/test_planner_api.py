@@ -197,6 +197,9 @@ def test_get_covariances_shapes():
   out = torch.randn(2, 1, (n - 1) + 2 * n, device=DEV, dtype=torch.float64)
   qc, ow, eps = planner.get_covariances(out, 'diag_identity', learn_eps=True)
   assert qc.shape == (2, n - 1, 2, 2) and eps.shape == (2, n, 1, 1) and float(qc[0, 0, 0, 1]) == 0.0
+  o = torch.randn(n, device=DEV, dtype=torch.float64)
+  w = planner.get_obs_covariance(o)                                            # diff_gpmp2_planner.py:293-297
+  assert w.shape == (n, 1, 1) and torch.equal(w[:, 0, 0], o * o)
 
 
 # ---- autograd through the planner API: reference = torch autograd over plan_layer.py:152-234 ----------
