@@ -223,13 +223,17 @@ def prewarm(launch, seconds=PREWARM_S, chunk=400):
 
 
 def time_launches(launch, reps, warm_s=0.3):
-  """Steady-clock average per-launch time in microseconds over `reps` launches, HIP events on the launch stream."""
+  """Steady-clock average per-launch time in microseconds over `reps` launches, HIP events on the launch stream; the median of three
+  such passes (a pass that shares the GPU with some one-off -- an allocator trim, a clock excursion -- used to land in the JSON as is)."""
   prewarm(launch, warm_s, 100)
   e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  torch.cuda.synchronize(); e0.record()
-  for k in range(reps): launch(k)
-  e1.record(); torch.cuda.synchronize()
-  return e0.elapsed_time(e1) / reps * 1e3
+  us = []
+  for _ in range(3):
+    torch.cuda.synchronize(); e0.record()
+    for k in range(reps): launch(k)
+    e1.record(); torch.cuda.synchronize()
+    us.append(e0.elapsed_time(e1) / reps * 1e3)
+  return sorted(us)[1]
 
 
 def roofline_block(bytes_per_launch, us, kernel, traffic_key=None, note=None):
