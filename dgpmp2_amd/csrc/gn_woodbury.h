@@ -337,13 +337,26 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
 
   // ---- the single-state factors of the three interior states: hh_f = sqrt(w_f) h_f, ch_f = sqrt(w_f) cost_f
   double hh[R][D], ch[R];
+  // sqrt(w) of the obstacle factors: a per-state tensor only in the learned modes.  A real (wave-uniform) branch: written as a select the
+  // compiler computes the three fp64 square roots speculatively and selects afterwards -- 65 VALU instructions of the static step for nothing.
+  double sws[3];
+  if (p.obs_w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::: "memory");                           // (keeps the branch a branch)
+#endif
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sws[k] = sqrt(lf.ow[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sws[k] = p.obs_w_sqrt;
+  }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const double oc = lf.oc[k], ow = lf.ow[k];
     acc.e += 0.5 * ow * oc * oc;                           // obstacle factor (as eval_state_local)
     acc.eext += 0.5 * p.obs_w_fix * oc * oc;               // plan_layer.py:329-332
     acc.uobs += 0.5 * oc * oc;
-    const double sw = p.obs_w ? sqrt(ow) : p.obs_w_sqrt;   // (wave-uniform; invalid rows have oc = h = 0)
+    const double sw = sws[k];                              // (invalid rows have oc = h = 0)
 #pragma unroll
     for (int a = 0; a < D; ++a) hh[k * NF][a] = 0.0;
     hh[k * NF][0] = sw * lf.ohx[k]; hh[k * NF][1] = sw * lf.ohy[k];
