@@ -98,7 +98,21 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   typename std::conditional<is_wb(QK), WbStaged, NoStage>::type wbv;
   const bool vec = p.vec_io != 0;
   double x[C][D], gbar[C][D], lam[C][D], mu_s[D], mu_g[D];
-  load_lane_rows<DOF, C, IO>(p, p.th, b, g0, traj_ok, vec, x);
+  // d = 4: a fully populated wavefront block whose length fills the shape moves its row tensors (th, the dtheta cotangent, dtheta in;
+  // g_th out) as full cache lines through the LDS staging block, as the forward step does (load / store_rows_through_lds; the output
+  // write-through) instead of 16 bytes per lane at a 64-byte stride.  Wave-uniform.
+  constexpr bool kBlockRows = WaveStore<IO, C, D>::kUsable && LPT != 32 && DOF == 2;
+  bool block_rows = false;
+  if constexpr (kBlockRows) block_rows = vec && n == LPT * C && ((int64_t)cx.wave() + 1) * TPW <= (int64_t)p.B;
+  const int64_t wave_first_elem = (int64_t)cx.wave() * TPW * n * D;
+  auto load_rows = [&](const void* src, double (&dst)[C][D]) {
+    if (block_rows) {
+      if constexpr (kBlockRows) load_rows_through_lds<IO, C, D>(cx, src, wave_first_elem, dst);
+    } else {
+      load_lane_rows<DOF, C, IO>(p, src, b, g0, traj_ok, vec, dst);
+    }
+  };
+  load_rows(p.th, x);
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
@@ -106,7 +120,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   for (int k = 0; k < C; ++k)
 #pragma unroll
     for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
-  if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.g_dtheta, b, g0, traj_ok, vec, gbar);
+  if (gp.g_dtheta) load_rows(gp.g_dtheta, gbar);
   LaneQ<D, C, QK> lq;              // generic covariances: Q^-1 of the lane's C + 1 GP factors, shared by the adjoint solve and the chain rule
   load_lane_Q<DOF, C, IO>(p, b, g0, traj_ok, lq);
   // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
@@ -146,7 +160,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   for (int k = 0; k < C; ++k)
 #pragma unroll
     for (int a = 0; a < D; ++a) dthr[k][a] = 0.0;
-  if (gp.g_dtheta) load_lane_rows<DOF, C, IO>(p, gp.dtheta, b, g0, traj_ok, vec, dthr);
+  if (gp.g_dtheta) load_rows(gp.dtheta, dthr);
 #pragma unroll
   for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
   LaneTaps<C, IO> taps;
@@ -155,6 +169,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   // row) and value for the four taps (x1,y1), (x2,y1), (x1,y2), (x2,y2)
   int32_t tap_i[C][4];
   IO tap_v[C][4];
+  double gxs[kBlockRows ? C : 1][D];              // block_rows: the g_th rows, stored together behind the row loop
 #pragma unroll
   for (int k = 0; k < C; ++k)
 #pragma unroll
@@ -339,7 +354,19 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       gx[DOF] += a2 * cs + ae * (-sn);                             // d/dvx: h2 -> cos, e -> -sin
       gx[DOF + 1] += a2 * (-sn) + ae * cs;                         // d/dvy: h2 -> -sin, e -> cos
     }
-    if (gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gx);
+    if (gp.g_th) {
+      if (block_rows) {
+        if constexpr (kBlockRows) {
+#pragma unroll
+          for (int a = 0; a < D; ++a) gxs[k][a] = gx[a];
+        }
+      } else {
+        st_row<IO, D>(gp.g_th, b * n + g, vec, gx);
+      }
+    }
+  }
+  if constexpr (kBlockRows) {
+    if (block_rows && gp.g_th) store_rows_through_lds_wt<IO, C, D>(cx, gp.g_th, wave_first_elem, gxs);
   }
   if (gp.g_sdf) sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);      // wave-uniform
 }

@@ -2710,6 +2710,40 @@ DGP_HD void store_rows_through_lds(Ctx& cx, void* out, int64_t wave_first_elem, 
   }
 }
 
+// The same block stored WRITE-THROUGH (`buffer_store_dwordx4 ... sc0 sc1`, system scope): the lines do not stay dirty in the XCD's L2,
+// so the release at the end of the kernel has nothing to write back and the next launch of an in-order stream starts ~0.2 us earlier
+// (DESIGN.md section 5 "(j)").  A raw buffer store because that is the 16-byte store whose cache-scope bits HIP source can set without
+// inline asm (which would hide the store from the compiler's hazard and wait-count bookkeeping); the wavefront's block is the buffer.
+template <typename IO, int C, int D, typename Ctx>
+DGP_HD void store_rows_through_lds_wt(Ctx& cx, void* out, int64_t wave_first_elem, const double (&v)[C][D]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef WaveStore<IO, C, D> WS;
+  typedef IO V16 __attribute__((vector_size(16)));
+  typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+  constexpr int EPV = 16 / (int)sizeof(IO);
+  const int lane = cx.lane();
+  char* l = cx.lds();
+#pragma unroll
+  for (int i = 0; i < WS::kCells; ++i) {
+    V16 t;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) t[e] = (IO)v[(i * EPV + e) / D][(i * EPV + e) % D];
+    *(V16*)(l + lane * WS::kStride + i * 16) = t;
+  }
+  cx.lds_sync();
+  char* o = (char*)out + wave_first_elem * (int64_t)sizeof(IO);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(o, 0, WS::kCells * 64 * 16, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < WS::kCells; ++i) {
+    const int c = i * 64 + lane;                                  // cell index inside the wavefront's block
+    const U4 t = *(const U4*)(l + (c / WS::kCells) * WS::kStride + (c % WS::kCells) * 16);
+    __builtin_amdgcn_raw_buffer_store_b128(t, rs, c * 16, 0, /* sc0 | sc1 */ 1 | 16);
+  }
+#else
+  store_rows_through_lds<IO, C, D>(cx, out, wave_first_elem, v);
+#endif
+}
+
 // The mirror image for loads: the wavefront's block is read as full lines (lane l reads the l-th 16 bytes of each 1 KB),
 // staged in LDS and picked up by the owning lanes (a load instruction that reads 16 bytes at a 64-byte lane stride makes 64
 // partial-line requests; four of them per lane cost ~0.3 us more than the same bytes as 16 full lines per instruction).
@@ -2916,7 +2950,13 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         block_store = vec && n == LPT * C && ((int64_t)cx.wave() + 1) * TPW <= (int64_t)p.B;
       if (block_store) {
         if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32)
-          store_rows_through_lds<IO, C, D>(cx, p.dtheta, (int64_t)cx.wave() * TPW * n * D, dx);
+        {
+          // write-through for d = 4 only: on d = 6 it is worth 0.2 of 26 us, and with it hipcc 7.0 miscompiled <3,64,2,float,STEP,per-state>
+          // (wrong by O(1) for every n, found by tests/test_hip_every_kernel.py) -- the d = 6 kernels keep the code of
+          // the build they were verified on
+          if constexpr (D == 4) store_rows_through_lds_wt<IO, C, D>(cx, p.dtheta, (int64_t)cx.wave() * TPW * n * D, dx);
+          else store_rows_through_lds<IO, C, D>(cx, p.dtheta, (int64_t)cx.wave() * TPW * n * D, dx);
+        }
       } else {
 #pragma unroll
         for (int k = 0; k < C; ++k) {
