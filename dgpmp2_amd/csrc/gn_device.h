@@ -107,10 +107,36 @@ __device__ __forceinline__ void warm_kernarg() {
 #endif
 }
 
+// The same warm-up with the segment pointer coming back THROUGH the asm statement: every argument field read through the returned pointer is
+// read behind the warm-up and -- the point here -- is re-loadable: the fused loop (MODE_SOLVE) otherwise keeps a hundred argument scalars live in
+// SGPRs across its iterations and spills them into VGPR lanes (124 spilled SGPRs in <2,16,4,float,SOLVE,Woodbury>; 22 this way).
+template <int LINES>
+__device__ __forceinline__ const char* warm_kernarg_laundered() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const char* KP;
+  KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile(".set dgp_ka_off, 0\n\t.rept %1\n\ts_load_dword s90, %0, dgp_ka_off\n\t.set dgp_ka_off, dgp_ka_off + 64\n\t.endr\n\t"
+               "s_waitcnt lgkmcnt(0)" : "+s"(ka) : "n"(LINES) : "s90", "memory");
+  return (const char*)ka;       // (address-space cast: the loads stay scalar loads from the constant address space)
+#else
+  return nullptr;
+#endif
+}
+
+#ifndef DGP_LAUNDER_KERNARG
+// measured (profiles/r03_kernel_variants_late.txt, 10 fused iterations at B = 4096): d = 4 Woodbury 74.6 -> 70.8 us, d = 4 block elimination 85.1 -> 80.7 us,
+// d = 6 Woodbury 219 -> 213 us; per-state Kronecker 98.4 -> 100.7 us (worse: left alone, like the general kernels and every STEP kernel -- 9.86 against 9.82 us)
+#define DGP_LAUNDER_KERNARG(DOF, MODE, QK) ((MODE) == dgp::MODE_SOLVE && (dgp::is_wb(QK) || (QK) == dgp::QK_STATIC))
+#endif
 // QK: kernel variant by covariance representation, dgp::QK_* (static: the constant GP blocks are scalar operands; see gn_lane.h).
 template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
-__global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p) {
-  warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();      // (the Woodbury table behind it is read with vector loads)
+__global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p_arg) {
+  // (the Woodbury table behind the warmed lines is read with vector loads)
+  constexpr bool kLaunder = DGP_LAUNDER_KERNARG(DOF, MODE, QK);
+  const dgp::GnParams* pp = &p_arg;
+  if constexpr (kLaunder) pp = (const dgp::GnParams*)warm_kernarg_laundered<((int)offsetof(dgp::GnParams, wb_tab) + 63) / 64>();
+  else warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();
+  const dgp::GnParams& p = *pp;
   // STEP: staging block of the full-line th / dtheta accesses; SOLVE: the fp64 trajectory rows parked between iterations
   // (+ an S_k^-1 stash where SinvStashBlocks asks for one -- currently only the backward kernel does: in STEP mode it would ALIAS
   // the staging block, th being loaded before the sweep and dtheta stored after the recovery; in SOLVE mode follow the trajectory)
