@@ -366,7 +366,12 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
   }
   if constexpr (kBlockRows) {
-    if (block_rows && gp.g_th) store_rows_through_lds_wt<IO, C, D>(cx, gp.g_th, wave_first_elem, gxs);
+    if (block_rows && gp.g_th) {
+      store_rows_through_lds_wt<IO, C, D>(cx, gp.g_th, wave_first_elem, gxs);
+#if !defined(__HIP_DEVICE_COMPILE__)
+      cx.lds_sync();      // host emulator: its lanes are threads, and the pair staging below reuses the block the others may still be reading
+#endif                    // (a wavefront issues its LDS instructions in order: nothing to wait for on the device)
+    }
   }
   if (gp.g_sdf) sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);      // wave-uniform
 }
