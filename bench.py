@@ -504,8 +504,8 @@ def main():
     for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], world * B)
     torch.cuda.synchronize()
   for k in range(args.warmup): step(k)
-  ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True); ev2 = torch.cuda.Event()
-  ev0.record(); ev1.record(); ev2.record()          # (creates the events outside the timed region: a first record costs ~40 us of host time)
+  ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+  ev0.record(); ev1.record()                        # (creates the events outside the timed region: a first record costs ~40 us of host time)
   torch.cuda.synchronize()
   if dist is not None: dist.barrier()
   torch.cuda.synchronize()
@@ -515,9 +515,7 @@ def main():
   ev1.record()
   gathered = None
   if dist is not None:      # collect final trajectories (the only collective of the path), through the product's helper
-    gathered = parallel.all_gather_trajectories(th_hist[-1], world * B)
-    ev2.record()                                    # (the current stream waits for the collective before this event)
-    while not ev2.query(): pass
+    gathered = parallel.all_gather_trajectories(th_hist[-1], world * B)      # (profiles/tools/dist_parts.py: 25 us at a world size of one, the closing barrier 27 us)
   else:
     while not ev1.query(): pass                     # spin until the last launch is done: synchronize() then returns at once instead of after an interrupt wake-up
   torch.cuda.synchronize()
