@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 B_PER_GPU, N_STATES, DOF, GRID = 4096, 64, 2, 256
 GN_ITERS = 10
-PREWARM_S = 0.6
+PREWARM_S = float(os.environ.get("DGP_BENCH_PREWARM_S", 0.6))      # (override: tuning only; 0.6 against 2.5 s makes no difference to the 20-step runs)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X vector FP64 (spec)
 
