@@ -110,13 +110,14 @@ __device__ __forceinline__ void warm_kernarg() {
 // The same warm-up with the segment pointer coming back THROUGH the asm statement: every argument field read through the returned pointer is
 // read behind the warm-up and -- the point here -- is re-loadable: the fused loop (MODE_SOLVE) otherwise keeps a hundred argument scalars live in
 // SGPRs across its iterations and spills them into VGPR lanes (124 spilled SGPRs in <2,16,4,float,SOLVE,Woodbury>; 22 this way).
-template <int LINES>
+template <int LINES, int L1 = 0, int N1 = 0>      // lines [0, LINES) and [L1, L1 + N1) of the segment
 __device__ __forceinline__ const char* warm_kernarg_laundered() {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((address_space(4))) const char* KP;
   KP ka = (KP)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile(".set dgp_ka_off, 0\n\t.rept %1\n\ts_load_dword s90, %0, dgp_ka_off\n\t.set dgp_ka_off, dgp_ka_off + 64\n\t.endr\n\t"
-               "s_waitcnt lgkmcnt(0)" : "+s"(ka) : "n"(LINES) : "s90", "memory");
+               ".set dgp_ka_off, %2\n\t.rept %3\n\ts_load_dword s90, %0, dgp_ka_off\n\t.set dgp_ka_off, dgp_ka_off + 64\n\t.endr\n\t"
+               "s_waitcnt lgkmcnt(0)" : "+s"(ka) : "n"(LINES), "n"(L1 * 64), "n"(N1) : "s90", "memory");
   return (const char*)ka;       // (address-space cast: the loads stay scalar loads from the constant address space)
 #else
   return nullptr;
@@ -153,9 +154,23 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
 }
 
 template <int DOF, int LPT, int C, typename IO, int QK>
-__global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
-  warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();
-  warm_kernarg_lines<((int)sizeof(dgp::GnGradParams) + 63) / 64>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(dgp::GnParams));
+__global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_arg, const dgp::GnGradParams g_arg) {
+  // d = 4 static-covariance kernels: both argument structs read through the laundered pointer, as the fused loop does (static backward 15.0 -> 14.6 us;
+  // the per-state kernel gets slower that way, 19.4 -> 19.7 us, and d = 6 was not measured: both keep the by-value reads)
+  constexpr bool kLaunder = DOF == 2 && (dgp::is_wb(QK) || QK == dgp::QK_STATIC);
+  constexpr int kGOff = (int)sizeof(dgp::GnParams);                          // GnGradParams follows GnParams (both 8-byte aligned)
+  static_assert(sizeof(dgp::GnParams) % 8 == 0 && alignof(dgp::GnGradParams) <= 8, "argument layout");
+  const dgp::GnParams* pp = &p_arg;
+  const dgp::GnGradParams* gg = &g_arg;
+  if constexpr (kLaunder) {
+    const char* ka = warm_kernarg_laundered<((int)offsetof(dgp::GnParams, wb_tab) + 63) / 64, kGOff / 64, (kGOff % 64 + (int)sizeof(dgp::GnGradParams) + 63) / 64>();
+    pp = (const dgp::GnParams*)ka; gg = (const dgp::GnGradParams*)(ka + kGOff);
+  } else {
+    warm_kernarg<(int)offsetof(dgp::GnParams, wb_tab)>();
+    warm_kernarg_lines<((int)sizeof(dgp::GnGradParams) + 63) / 64>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(dgp::GnParams));
+  }
+  const dgp::GnParams& p = *pp;
+  const dgp::GnGradParams& g = *gg;
   constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;

@@ -3,6 +3,7 @@
    python profiles/tools/isa_lines.py /tmp/kp/NAME/*gfx950.s [regex of mnemonics, default: all VALU]   -> instruction counts per file:line, most first
 Found with it (round 3): three speculated fp64 square roots in the static Woodbury step (DESIGN.md section 5 "(i)")."""
 import collections
+import os
 import re
 import sys
 
@@ -14,7 +15,7 @@ def main():
   for l in open(path):
     m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
     if m: files[int(m.group(1))] = (m.group(3) or m.group(2)).split('/')[-1]
-    if re.match(r'_ZN7dgp_dev\w+:', l): infn = True
+    if re.match(r'_ZN7dgp_dev\w+:', l): infn = os.environ.get('ISA_KERNEL', '') in l      # ISA_KERNEL=<mangled-name substring>: one kernel of a unit with many
     if infn and 's_endpgm' in l: infn = False
     m = re.match(r'\s*\.loc\s+(\d+)\s+(\d+)', l)
     if m: cur = (files.get(int(m.group(1)), m.group(1)), int(m.group(2)))
