@@ -12,9 +12,16 @@ before the timed region and resident in HBM.
   python bench.py [--gpus N] [--steps K] [--warmup W]
 Before the W warm-up steps the GPU is brought to its steady clocks by a TIME-based pre-warm (>= 0.6 s of the same launches,
 reported as `prewarm_s`): a cold MI355X runs the first milliseconds ~12 % slower, and K = 20 steps last 0.2 ms.
+The timed region -- synchronise, EXACTLY K launches, synchronise -- is repeated R times (9 <= R <= 41, about 0.4 s in all; each
+repetition is the whole region, nothing skipped) and `value` is K / the MEDIAN region: one 0.2 ms window right after an idling
+synchronisation is decided by a single 40-70 us hiccup (`regions` in the JSON holds min / quartiles / max and the first region).
+`roofline` is computed from the dominant kernel's own average duration (per-launch begin / end HIP events on the launch stream,
+`kernel_avg_ms`), which is what rocprofv3 --kernel-trace reports; the region's event span per launch is a separate field.
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU (RCCL): every rank owns its own 4096
 trajectories (weak scaling, no data-path collective); the only collective is one all-gather of the final trajectories
-at the end of the timed region, through the product's helper dgpmp2_amd.parallel.all_gather_trajectories.
+at the end of each timed region, through the product's helper dgpmp2_amd.parallel.all_gather_trajectories into a
+buffer allocated once; a region opens with barrier + synchronise and closes when the (stream-ordered) all-gather has completed --
+it cannot before every rank has contributed -- and the slowest rank's clock counts (all-reduce MAX per region).
 Rank 0 prints ONE JSON line.  Beside the headline it carries (rank 0, N = 1, outside the timed region): the fused 10-iteration
 launch, BASELINE configs[2] and [3], the per-sample-SDF and learned-covariance regimes of configs[1], each with its own
 roofline block, the planner-API call rate, and the CPU baselines.
@@ -498,43 +505,85 @@ def main():
     if rc: solver.api.check(rc)
 
   prewarm_s = prewarm(step)
+  gather_out = None
   if dist is not None:
-    # untimed: the first call of a collective sets up RCCL's channels / loads its kernels (milliseconds), and the first 4 MB x world output
-    # buffer comes from hipMalloc instead of the caching allocator -- neither belongs to a 0.25 ms timed region
-    for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], world * B)
+    # untimed: the first call of a collective sets up RCCL's channels / loads its kernels (milliseconds); the 4 MB x world output buffer is
+    # allocated ONCE here and handed to the product's helper as `out=` (a GN loop that gathers every outer iteration does the same)
+    gather_out = parallel.gather_buffer(th_hist[-1], world * B)
+    for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)
     torch.cuda.synchronize()
   for k in range(args.warmup): step(k)
-  ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-  ev0.record(); ev1.record()                        # (creates the events outside the timed region: a first record costs ~40 us of host time)
   torch.cuda.synchronize()
-  if dist is not None: dist.barrier()
-  torch.cuda.synchronize()
-  t0 = time.perf_counter()
-  ev0.record()
-  for k in range(args.steps): step(k)
-  ev1.record()
+
+  # ---- the timed regions -------------------------------------------------------------------------------------------------------------
+  # ONE region is the contract's measurement: synchronised (N > 1: barrier + synchronise) -> EXACTLY K launches [-> the one all-gather of
+  # the final trajectories] -> synchronised, wall clock around it, max over ranks.  With the driver's K = 20 a region lasts 0.2 ms on a GPU
+  # the opening synchronisation has just idled, and a single 40-70 us hiccup (BENCH_r03: -24 %) decides it.  So the SAME region is repeated
+  # R times, each with its own synchronisations and nothing skipped, and `value` is the MEDIAN region; min / quartiles / max and the first
+  # region (what a single-shot measurement would have reported) are in the JSON.  Regions follow each other directly: the GPU idles for
+  # microseconds between them and keeps its clocks.
+  K = args.steps
+  R = int(os.environ.get('DGP_BENCH_REGIONS', 0)) or max(9, min(41, int(0.4 / max(K * 10e-6, 1e-6))))
+  cur_stream = torch.cuda.current_stream()
   gathered = None
-  if dist is not None:      # collect final trajectories (the only collective of the path), through the product's helper
-    gathered = parallel.all_gather_trajectories(th_hist[-1], world * B)      # (profiles/tools/dist_parts.py: 25 us at a world size of one, the closing barrier 27 us)
-  else:
-    while not ev1.query(): pass                     # spin until the last launch is done: synchronize() then returns at once instead of after an interrupt wake-up
+
+  def region(ev=None):
+    """One timed region; `ev` = (begin, end) HIP events recorded around the launches (only in the extra span regions below: two event
+    records cost a 20-launch region ~13 us, profiles/r04_region_parts.txt)."""
+    nonlocal gathered
+    if dist is not None:
+      torch.cuda.synchronize(); dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if ev: ev[0].record()
+    for k in range(K): step(k)
+    if dist is not None:      # collect the final trajectories -- the only collective of the path -- through the product's helper; it is stream-ordered
+      gathered = parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)      # behind the K launches and cannot complete before every rank has contributed
+    if ev: ev[1].record()
+    while not cur_stream.query(): pass              # spin until the stream has drained: synchronize() then returns at once, not after an interrupt wake-up
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+  walls = np.asarray([region() for _ in range(R)])
+  # a few more regions WITH events around the launches: the device-side span of a region (start-up of the first launch and gaps included)
+  evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(9)]
+  for a_, b_ in evs: a_.record(); b_.record()      # (a first record() of an event costs ~40 us of host time: not inside a region)
   torch.cuda.synchronize()
-  if dist is not None: dist.barrier()
-  torch.cuda.synchronize()
-  elapsed = time.perf_counter() - t0
-  kernel_ms = ev0.elapsed_time(ev1) / args.steps     # average per-launch duration over the timed region, HIP events on the launch stream
-  # Cross-check outside the timed region: every launch records its OWN begin / end (dgp_time_next_launch == hipExtLaunchKernelGGL
-  # events; rocprofv3's definition of a kernel's duration).  Not done inside the timed region: such launches dispatch ~5 us slower.
-  ktimer = _capi.KernelTimer(min(max(args.steps, 200), 1000))
+  for e in evs: region(e)
+  spans_ms = np.asarray([a_.elapsed_time(b_) for a_, b_ in evs])
+  if dist is not None:
+    assert tuple(gathered.shape) == (world * B, n, d)
+    t = torch.tensor(walls, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)        # every region: the slowest rank's clock
+    walls = t.cpu().numpy()
+  elapsed = float(np.median(walls))
+  q = lambda v, f: float(np.percentile(v, f))
+  regions = {'count': R, 'steps_per_region': K,
+             'ms_per_step': {'min': float(walls.min()) * 1e3 / K, 'p25': q(walls, 25) * 1e3 / K, 'median': elapsed * 1e3 / K, 'p75': q(walls, 75) * 1e3 / K,
+                             'max': float(walls.max()) * 1e3 / K, 'first_region': float(walls[0]) * 1e3 / K},
+             'note': 'each region = synchronise [+ barrier] -> K launches [-> all-gather] -> synchronise, wall clock, max over ranks; value = K / median region'}
+  if os.environ.get('DGP_BENCH_DUMP_REGIONS') == '1':      # (profiles/tools/region_gaps.py: which regions were slow, next to a rocprofv3 trace of the same run)
+    regions['wall_us'] = [float(w) * 1e6 for w in walls]; regions['span_us'] = [float(x) * 1e3 for x in spans_ms]
+  region_span_ms = float(np.median(spans_ms)) / K   # HIP events around a region's launches on the launch stream: includes the start-up of the first launch and the gaps
+  # The dominant kernel's own duration: every launch records its OWN begin / end (dgp_time_next_launch == hipExtLaunchKernelGGL events, rocprofv3's
+  # definition of a kernel's duration).  A separate pass: such launches dispatch ~5 us slower, so they are kept out of the timed regions.
+  ktimer = _capi.KernelTimer(1000)
   for k in range(len(ktimer.pairs)):
     ktimer.arm(); step(k)
   torch.cuda.synchronize()
   kdur = np.asarray(ktimer.durations_ms())
+  kernel_ms = float(kdur.mean())
+  # ... and the steady-state launch PERIOD (kernel + the gap to the next dependent launch): events around 3 x 2000 back-to-back launches, median
+  period_ms = time_launches(step, 2000, warm_s=0.05) * 1e-3
+  # fixed cost of an N > 1 region that is not the path's: the all-gather + the wait for it, measured on their own
+  region_fixed_us = None
   if dist is not None:
-    assert tuple(gathered.shape) == (world * B, n, d)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    ts = []
+    for _ in range(20):
+      torch.cuda.synchronize(); t0 = time.perf_counter()
+      parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)
+      torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    region_fixed_us = float(np.median(ts)) * 1e6
 
   # Beside the headline (one launch per GN step, the reference's step()): the same 10 GN iterations from th_init as ONE
   # launch of the fused loop (the reference's forward(); dgp_gn_solve, tol 0 so that all 10 run) -- no launch gaps, th
@@ -563,11 +612,20 @@ def main():
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
         'rccl_ranks': world if dist is not None else 0,
         'trajectory_steps_per_s': world * args.steps * B / elapsed,
+        'regions': regions,
         'kernel_events': {'launches': int(kdur.size), 'mean_ms': float(kdur.mean()), 'median_ms': float(np.median(kdur)),
-                          'note': 'per-launch begin/end events (dgp_time_next_launch), a separate pass after the timed region'},
+                          'note': 'per-launch begin/end events (dgp_time_next_launch), a separate pass after the timed regions'},
         'roofline': roofline_block(bytes_per_launch, kernel_ms * 1e3, kname, traffic_key='gn_step',
-                                   note='HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'),
+                                   note='kernel_avg_ms = mean duration of the dominant kernel over 1000 launches, each recording its own begin / end HIP events on the '
+                                        'launch stream (what rocprofv3 --kernel-trace calls the kernel\'s duration: profiles/r04_kernel_trace.txt); HBM is the bound SURVEY '
+                                        '8(d) prescribes, the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'),
     }
+    out['roofline']['launch_period_ms'] = period_ms                    # kernel + gap to the next dependent launch, 3 x 2000 back-to-back launches
+    out['roofline']['region_span_ms_per_launch'] = region_span_ms      # events around one K-launch region / K (median region): start-up and gaps included
+    if region_fixed_us is not None:
+      out['region_fixed_us'] = region_fixed_us
+      out['region_fixed_note'] = ('one all-gather of the final trajectories + the wait for it, timed on its own (median of 20): the part of an N > 1 region '
+                                  'that is not GN steps; at --steps 20 it is a visible share of the region, at the default 5000 steps it is noise')
     if ks:
       flops = (2 * ks['fma_f64'] + ks['mul_f64'] + ks['add_f64']) * 64 * waves
       tf = flops / (kernel_ms * 1e-3) / 1e12

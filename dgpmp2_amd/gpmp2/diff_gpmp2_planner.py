@@ -97,6 +97,8 @@ class DiffGPMP2Planner(nn.Module):
       self.sdf_predict = lp['dgpmp2']['sdf_predict']
       self.use_dtheta = lp['dgpmp2']['dtheta_predict'] if 'dtheta_predict' in lp['dgpmp2'] else False
       self.dynamics_mode = lp['dgpmp2']['dynamics_mode']
+      # like the reference's constructor (:60-76), tell the learn modules -- through the SAME dict -- what they must emit, before they are built
+      self.res = self.prepare_learn_params(lp, planner_params, env_params, robot_model)
       if self.dynamics_mode == 'fix_dynamics':
         self.qc_inv_traj = mk((self.num_gp_factors, self.dof, self.dof), gp_params['Q_c_inv'])
       if not self.learn_eps:
@@ -105,7 +107,14 @@ class DiffGPMP2Planner(nn.Module):
       self.fixed_conv = lp['dgpmp2']['fixed_conv'] if 'fixed_conv' in lp['dgpmp2'] else False
       if learn_module_fcn is None:
         raise NotImplementedError('learn_params given but no learn modules: the CNN/FCN covariance predictors are stock torch.nn '
-                                  'and outside this build; pass them as learn_module_conv= / learn_module_fcn=')
+                                  'and outside this build; pass them (instances, or the reference\'s classes / any factory with their '
+                                  'constructor signature) as learn_module_conv= / learn_module_fcn=')
+      # an nn.Module instance is used as it is; anything else callable is a factory with the signature of the reference's classes
+      # (diff_gpmp2_planner.py:86-87) and is called now, with learn_params['out_dim'] etc. already in place
+      if learn_module_conv is not None and not isinstance(learn_module_conv, nn.Module):
+        learn_module_conv = learn_module_conv(lp, env_params, robot_model, use_cuda=self.use_cuda)
+      if not isinstance(learn_module_fcn, nn.Module):
+        learn_module_fcn = learn_module_fcn(lp, env_params, obs_params, robot_model, use_cuda=self.use_cuda)
       self.learn_module_conv = learn_module_conv
       self.learn_module_fcn = learn_module_fcn
     self.plan_layer = PlanLayer(gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params,
@@ -113,6 +122,29 @@ class DiffGPMP2Planner(nn.Module):
     # plain-attribute aliases for step(): a submodule / None-module attribute is resolved by nn.Module.__getattr__ (~1 us per access)
     self.__dict__['_pl'] = self.plan_layer
     self.__dict__['_learned'] = self.learn_module_fcn is not None
+
+  @staticmethod
+  def prepare_learn_params(learn_params, planner_params, env_params, robot_model):
+    """What the reference's constructor writes into `learn_params` before it builds LearnModuleConv / LearnModuleFCN from that dict
+    (diff_gpmp2_planner.py:60-78): 'num_traj_states' (doubled with dtheta_predict), 'state_dim' and 'out_dim' -- the length of the
+    vector get_covariances() slices, per dynamics_mode, + one more block of obstacle factors with learn_eps.  Returns the image
+    resolution the reference keeps as `self.res` (:58).  Called by the constructor; public so that a caller who builds the learn
+    modules first can prepare the dict the same way."""
+    lp = learn_params
+    n = int(planner_params['total_time_step']) + 1
+    dof, state_dim, nl = int(planner_params['dof']), int(planner_params['state_dim']), robot_model.nlinks
+    n_gp, n_obs = n - 1, n * nl
+    lp['num_traj_states'] = n
+    lp['state_dim'] = planner_params['state_dim']
+    if lp['dgpmp2']['dtheta_predict'] if 'dtheta_predict' in lp['dgpmp2'] else False:
+      lp['num_traj_states'] = 2 * n
+    per_mode = {'fix_dynamics': 0, 'diag_identity': n_gp, 'diag': n_gp * dof, 'qc_full': n_gp * dof, 'q_full': n_gp * state_dim}
+    mode = lp['dgpmp2']['dynamics_mode']
+    if mode in per_mode:                   # (an unknown mode leaves 'out_dim' alone, as the reference's if / elif chain does)
+      lp['out_dim'] = per_mode[mode] + n_obs
+    if lp['dgpmp2']['learn_eps'] if 'learn_eps' in lp['dgpmp2'] else False:
+      lp['out_dim'] = lp['out_dim'] + n_obs
+    return (_f(env_params['x_lims'][1]) - _f(env_params['x_lims'][0])) / (lp['data']['im_size'] * 1.0)
 
   # -- helpers ------------------------------------------------------------------------------------------
   def _static_view(self, t, B, like):
@@ -217,6 +249,12 @@ class DiffGPMP2Planner(nn.Module):
     pl.last_info = info
     pl._last = (st, go, None, None, None)
     host = buf.cpu()                                # synchronises
+    # the copy above has synchronised, so the SPD flags of this launch can be looked at for the price of one more small copy: the
+    # reference raises from torch.cholesky at the first non-SPD system (plan_layer.py:226)
+    bad = int(info.count_nonzero())
+    if bad:
+      raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories during forward() '
+                         '(the reference raises from torch.cholesky here); per-trajectory flags: plan_layer.last_info' % (bad, B))
     eh_c, eeh_c = host[:B * m].view(B, m).numpy(), host[B * m:2 * B * m].view(B, m).numpy()
     ef_c = host[2 * B * m:2 * B * m + B].numpy()
     jb = host[2 * B * m + B:].view(torch.int32)[:B].tolist()

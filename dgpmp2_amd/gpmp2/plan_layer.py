@@ -14,6 +14,11 @@ Differences a caller can observe (all deliberate):
     error_batch(thb, sdfb)-style helpers does the layer remember the means/covariances of the last forward() (SURVEY Q9);
   * a non-SPD system raises RuntimeError (as torch.cholesky does in the reference) only when `check_spd` is True,
     because the check forces a device synchronisation; the per-trajectory flags are always available in `last_info`.
+    When no input requires grad (planning loops) `last_info` is ONE buffer per (batch, device, stream), overwritten by the next
+    forward() on that stream -- clone() it to keep an iteration's flags; a differentiable step or check_spd gets its own tensor;
+  * the autograd node of forward() holds plain references to its inputs (addresses + a version-counter check instead of
+    SavedVariables, ~1.5 us per tensor): they are released with the node, not at the end of backward(), and
+    torch.autograd.graph.saved_tensors_hooks (save_on_cpu, checkpointing) do not see them -- only `dtheta` is a SavedVariable.
 """
 import ctypes
 import weakref
@@ -109,7 +114,7 @@ class _GNStep(torch.autograd.Function):
   """dtheta, err, err_ext = GN step; backward through dgp_gn_step_backward (adjoint block-tridiagonal solve)."""
 
   @staticmethod
-  def launch(layer, static, th, start, goal, sdf, qc, ow, eps):
+  def launch(layer, static, th, start, goal, sdf, qc, ow, eps, own_info=False):
     """The forward launch itself (no autograd bookkeeping): -> dth, err, eex, and what the backward needs (contiguous inputs,
     the marshalled SDF / covariance arguments with the tensors they keep alive)."""
     B = th.shape[0]
@@ -127,7 +132,10 @@ class _GNStep(torch.autograd.Function):
     err = torch.empty_like(proto)           # (empty_like of a cached (B,1,1) tensor: 1.3 us; new_empty / torch.empty with a shape: 2.1 us)
     eex = torch.empty_like(proto)
     stream = _raw_stream(dev)
+    # SPD flags: a differentiable step (own_info) or a checking layer gets its own tensor -- `last_info` kept from iteration k stays that
+    # iteration's; the planning loop without an autograd graph reuses one buffer per (batch, device, stream), see _info_buffer
     info = layer._info_buffer(B, dev, stream, thc)
+    if own_info or layer.check_spd: info = torch.empty_like(info)
     _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
             cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
     layer.__dict__['last_info'] = info      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
@@ -142,7 +150,7 @@ class _GNStep(torch.autograd.Function):
     tensor ARGUMENTS of the Function (the bookkeeping of Function.apply is paid per tensor argument: ~1 us each, and a TBPTT link
     differentiates one of the seven); err -- never differentiable, plan_layer.py:275 -- leaves through `box` instead of as an output."""
     th, start, goal, sdf, qc, ow, eps = ts
-    dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps)
+    dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, static, th, start, goal, sdf, qc, ow, eps, True)
     box.append(err)
     ctx.layer = layer
     ctx.slots = slots
@@ -393,13 +401,17 @@ class PlanLayer(nn.Module):
   def _sdf_args(self, sdfb, dtype, B, dev):
     """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35) -> (address, H, W, batch stride in elements, keep-alive tensor); an
     expand()ed / single grid is passed as shared (stride 0).  None: no grid (dgp_eval_errors without obstacle outputs only).
-    The result for the LAST tensor seen is cached (same object, same version counter, same storage address, same dtype / batch):
-    a GN loop passes the same grid tensor every iteration, and slicing + checking it costs 5 us -- half a kernel."""
+    A GN loop passes the same grid tensor every iteration, and slicing + checking it costs 5 us -- half a kernel -- so the result for
+    the LAST tensor seen is cached, but ONLY in the zero-copy case: the kernel then reads sdfb's own storage, whatever was written to
+    it and however (in place, through .data, through an aliasing numpy / DLPack buffer), so the entry cannot go stale; it is keyed on
+    the tensor object, its storage address, shape, strides, dtype and the batch.  A grid that needs a converted copy (other dtype than
+    thb, non-contiguous) is converted on EVERY call, on the current stream, like any other torch op."""
     if sdfb is None:
       return _NO_SDF
     c = self._sdf_cache
-    if c is not None and c[0]() is sdfb and c[1] == sdfb._version and c[2] == sdfb.data_ptr() and c[3] is dtype and c[4] == B and c[5] == dev:
-      return c[6]
+    if (c is not None and c[0]() is sdfb and c[1] == sdfb.data_ptr() and c[2] == sdfb.shape and c[3] == sdfb.stride() and c[4] is sdfb.dtype
+        and c[5] == B and c[6] == dev and c[7] is dtype):
+      return c[8]
     _require_cuda(sdfb, 'sdfb')
     if sdfb.get_device() != dev: _same_device(dev, sdfb=sdfb)
     if sdfb.dim() != 4: raise ValueError('sdfb must be (B,1,H,W)')
@@ -411,19 +423,19 @@ class PlanLayer(nn.Module):
     t = sdfb[0:1, 0:1] if shared else sdfb[:, 0:1]
     t = t.detach()
     if t.dtype != dtype or not t.is_contiguous():
-      t = t.to(dtype).contiguous()
-    own = t.data_ptr() != sdfb.data_ptr()       # a converted copy: the cache entry owns it; a view lives as long as sdfb does
-    res = (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), t if own else None)
+      t = t.to(dtype).contiguous()              # an owned copy: never cached (it would not see later writes to sdfb)
+      return (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), t)
+    res = (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), None)      # a view into sdfb: lives as long as sdfb does
     me = weakref.ref(self)
 
-    def _drop(_, me=me):                        # the tensor died: let go of the converted copy
+    def _drop(_, me=me):                        # the tensor died: its address may be reused by another tensor object
       s = me()
       if s is not None: s.__dict__['_sdf_cache'] = None
     try:
-      self.__dict__['_sdf_cache'] = (weakref.ref(sdfb, _drop), sdfb._version, sdfb.data_ptr(), dtype, B, dev, res)
+      self.__dict__['_sdf_cache'] = (weakref.ref(sdfb, _drop), sdfb.data_ptr(), sdfb.shape, sdfb.stride(), sdfb.dtype, B, dev, dtype, res)
     except TypeError:
       self.__dict__['_sdf_cache'] = None
-    return res if own else res[:4] + (t,)       # (the caller's copy of the result keeps a view alive for the duration of the call)
+    return res[:4] + (t,)                       # (the caller's copy of the result keeps the view alive for the duration of the call)
 
   @staticmethod
   def static_flags(qc, ow, eps):

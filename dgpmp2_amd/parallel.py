@@ -34,9 +34,18 @@ def shard_batch(tensors, rank=None, world_size=None):
   return out
 
 
-def all_gather_trajectories(local, batch, group=None):
+def gather_buffer(local, batch, group=None):
+  """The (world * largest shard, ...) buffer all_gather_trajectories fills, for callers that gather repeatedly (a GN loop that
+  collects trajectories every outer iteration, bench.py's timed regions) and pass it back as `out=`: no allocation per call."""
+  world = dist.get_world_size(group)
+  mx = max(shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world))
+  return local.new_empty((world * mx,) + tuple(local.shape[1:]))
+
+
+def all_gather_trajectories(local, batch, group=None, out=None):
   """All-gather per-rank result slices (B_r, ...) into the full (batch, ...) tensor on every rank.  Ragged shards
-  (batch not divisible by the world size) are padded to the largest shard for the collective and trimmed afterwards."""
+  (batch not divisible by the world size) are padded to the largest shard for the collective and trimmed afterwards.
+  `out`: a buffer from gather_buffer() to gather into (the returned tensor is `out` itself when the shards are even)."""
   world = dist.get_world_size(group)
   sizes = [shard_range(batch, r, world)[1] - shard_range(batch, r, world)[0] for r in range(world)]
   mx = max(sizes)
@@ -44,7 +53,11 @@ def all_gather_trajectories(local, batch, group=None):
   if local.shape[0] < mx:
     pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], 0)
   pad = pad.contiguous()
-  out = local.new_empty((world * mx,) + tuple(local.shape[1:]))
+  shape = (world * mx,) + tuple(local.shape[1:])
+  if out is None:
+    out = local.new_empty(shape)
+  elif tuple(out.shape) != shape or out.dtype != local.dtype or out.device != local.device or not out.is_contiguous():
+    raise ValueError('out must be a contiguous %s %s tensor on %s (gather_buffer() makes one)' % (shape, local.dtype, local.device))
   dist.all_gather_into_tensor(out, pad, group=group)
   if all(s == mx for s in sizes):
     return out

@@ -440,6 +440,43 @@ def g6_helpers():
   imr = (rs.rand(24, 40) > 0.3).astype(np.float64)
   out.update(sdf_im5=im5.astype(np.float32), sdf_im5_pad1=sdf_2d(im5, res=10.0 / im5.shape[0]), sdf_imr=imr,
              sdf_imr_pad0=sdf_2d(imr, padlen=0, res=0.25), sdf_imr_pad2=sdf_2d(imr, padlen=2, res=1.0))
+  # the learned-covariance plumbing: get_covariances for every runnable mode x learn_eps, get_obs_covariance
+  # (diff_gpmp2_planner.py:247-297), on random predictor outputs
+  n, Bc = 16, 3
+  planner = make_planner(Bc, n)
+  gen = torch.Generator().manual_seed(64)
+  sizes = {'fix_dynamics': 0, 'diag_identity': n - 1, 'qc_full': (n - 1) * 2, 'q_full': (n - 1) * 4}
+  for mode, n_gp in sizes.items():
+    for le in (False, True):
+      key = 'cov_%s_%d' % (mode, int(le))
+      o = torch.randn(Bc, 1, n_gp + n + (n if le else 0), generator=gen)
+      res = planner.get_covariances(o, mode, le)
+      res = res if isinstance(res, tuple) else (res,)
+      out[key + '_in'] = o; out[key + '_count'] = len(res)
+      for i, t in enumerate(res): out['%s_out%d' % (key, i)] = t
+  o = torch.randn(n, generator=gen)
+  out.update(obscov_in=o, obscov_out=planner.get_obs_covariance(o))
+  # what the constructor leaves in learn_params before it builds the learn modules (diff_gpmp2_planner.py:58-78), every combination of
+  # dynamics_mode x learn_eps x dtheta_predict; the modules themselves replaced by stubs (learn_module_fcn.py:41 needs Python 2)
+  import copy
+  import diff_gpmp2.gpmp2.diff_gpmp2_planner as pmod
+  import torch.nn as nn
+  saved = (pmod.LearnModuleConv, pmod.LearnModuleFCN)
+  pmod.LearnModuleConv = lambda lp_, *a, **k: nn.Identity()
+  pmod.LearnModuleFCN = lambda lp_, *a, **k: nn.Identity()
+  try:
+    rows = []
+    for mode in ('fix_dynamics', 'diag_identity', 'qc_full', 'q_full'):
+      for le in (False, True):
+        for dp in (False, True):
+          lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
+          lp['dgpmp2'].update(dynamics_mode=mode, learn_eps=le, dtheta_predict=dp)
+          gp_, obs_, pl_, opt_ = params_2d(n)
+          pln = DiffGPMP2Planner(gp_, obs_, pl_, opt_, ENV, PointRobot2D(torch.tensor(0.4), 2, n), learn_params=lp, batch_size=2)
+          rows.append([lp['num_traj_states'], lp['state_dim'], lp['out_dim']])
+    out.update(lp_prepared=np.asarray(rows), lp_res=float(pln.res))
+  finally:
+    pmod.LearnModuleConv, pmod.LearnModuleFCN = saved
   save('g6_helpers', **out)
 
 
@@ -496,9 +533,9 @@ def g6_dataset():
 # G7: autograd through the errors the reference's TRAINING LOSS differentiates besides dtheta:
 #   unweighted_errors_batch (diff_gpmp2_planner.py:229-237 -> plan_layer.py:374-388) and error_ext_batch (:310-345), evaluated at
 #   th + dtheta (learning/train_planner.py:313,327), with start / goal / eps remembered WITH their graphs by forward() (:88-94).
-#   g7_errors: plan_layer-level, every leaf learnable (incl. eps);  g7_tbptt: one batch of train() (train_planner.py:258-410, restated
-#   in tests/tbptt_loop.py) through planner.step() with learn modules -- stubs injected in place of LearnModuleConv / LearnModuleFCN
-#   (the latter cannot be constructed under Python 3, learn_module_fcn.py:41), in memory only.
+#   g7_errors: plan_layer-level, every leaf learnable (incl. eps);  g7_tbptt: one batch of train() (train_planner.py:258-424, the
+#   reference's own loop text exec'd from /root/reference) through planner.step() with learn modules -- the stubs of tests/tbptt_driver.py
+#   injected in place of LearnModuleConv / LearnModuleFCN (the latter cannot be constructed under Python 3, learn_module_fcn.py:41), in memory only.
 # ------------------------------------------------------------------------------------------------
 def g7_errors():
   B, n, Gsz = 4, 16, 48
@@ -551,20 +588,45 @@ TBPTT_LEARN_PARAMS = {
 }
 
 
+def _reference_training_text():
+  """(one_step_loss source, the per-batch body of train()) read from the reference's learning/train_planner.py at generation time.
+  The file as a whole is Python 2 (print statements elsewhere) and cannot be imported, but these two spans parse under Python 3
+  (`xrange` is supplied by the namespace they are exec'd in).  Nothing of the text is written anywhere."""
+  import textwrap
+  lines = open(os.path.join(REF, 'diff_gpmp2/learning/train_planner.py')).read().split('\n')
+  i0 = next(i for i, l in enumerate(lines) if l.startswith('def one_step_loss'))
+  i1 = next(i for i, l in enumerate(lines) if i > i0 and l.startswith('def '))
+  j0 = next(i for i, l in enumerate(lines) if 'in enumerate(train_loader' in l)
+  j1 = next(i for i, l in enumerate(lines) if i > j0 and "print('Updating parameters')" in l) + 1      # ... through the optimizer.step() behind it
+  return '\n'.join(lines[i0:i1]), textwrap.dedent('\n'.join(lines[j0:j1 + 1]))
+
+
+class _NullOptimizer(object):
+  """The fixture pins the gradients the loop deposits, not a parameter update: zero_grad() / step() do nothing."""
+  def zero_grad(self): pass
+  def step(self): pass
+
+
 def g7_tbptt():
-  import copy
+  """One batch of the reference's train() -- its own loop text, exec'd -- on the reference's planner with stub learn modules
+  (tests/tbptt_driver.py: the real LearnModuleFCN cannot be constructed under Python 3, learn_module_fcn.py:41): feed-forward model
+  in two dynamics modes and a recurrent model (diff_gpmp2_planner.py:192, train_planner.py:282-284,303-309,315,369-371)."""
+  import copy, contextlib, io, time
+  import torch.nn as nn
   import diff_gpmp2.gpmp2.diff_gpmp2_planner as pmod
   sys.path.insert(0, os.path.join(ROOT, 'tests'))
-  import tbptt_loop as TL
+  import tbptt_driver as TD
+  loss_src, loop_src = _reference_training_text()
   B, n, Gsz = 3, 16, 48
   out = {}
   saved = (pmod.LearnModuleConv, pmod.LearnModuleFCN)
-  pmod.LearnModuleConv = lambda lp, *a, **k: TL.ConvStub()
-  pmod.LearnModuleFCN = lambda lp, *a, **k: TL.FcnStub(lp['out_dim'])
   try:
-    for mode in ('fix_dynamics', 'qc_full'):
+    for tag, mode, mtype in (('fix_dynamics', 'fix_dynamics', 'feed_forward'), ('qc_full', 'qc_full', 'feed_forward'), ('recurrent', 'fix_dynamics', 'recurrent')):
       lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
       lp['dgpmp2']['dynamics_mode'] = mode
+      lp['model']['type'] = mtype
+      pmod.LearnModuleConv = lambda lp_, *a, **k: TD.ConvStub()
+      pmod.LearnModuleFCN = (lambda lp_, *a, **k: TD.RecurrentFcnStub(lp_['out_dim'])) if mtype == 'recurrent' else (lambda lp_, *a, **k: TD.FcnStub(lp_['out_dim']))
       gp, obs, plp, opt = params_2d(n)
       planner = DiffGPMP2Planner(gp, obs, plp, opt, ENV, PointRobot2D(torch.tensor(0.4), B, n), learn_params=lp, batch_size=B)
       start, goal = rand_start_goal(B, seed=17)
@@ -573,18 +635,36 @@ def g7_tbptt():
       g = torch.Generator().manual_seed(73)
       th_opt = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.3
       sample = {'im': (sdf > 0).double(), 'sdf': sdf.clone(), 'start': start, 'goal': goal, 'th_opt': th_opt}
-      import contextlib, io
+      # the free names of the loop text (train_planner.py:203-254 sets them up from the same dicts)
+      dg = lp['dgpmp2']
+      ns = {'torch': torch, 'nn': nn, 'time': time, 'xrange': range, 'print': lambda *a, **k: None,
+            'planner': planner, 'train_loader': [sample], 'device': torch.device('cpu'), 'dof': plp['dof'], 'planner_params': plp, 'learn_params': lp,
+            'straight_line_trajb': lambda s, e, tt, ts, dof, dev: straight_line_trajb(s, e, tt, ts, dof),
+            'fixed_conv': dg['fixed_conv'], 'optimizer': _NullOptimizer(), 'model_type': mtype, 'batch_size': B, 'T': dg['T'], 'tk': dg['tk'], 'tk2': dg['tk2'],
+            'retain_graph': True, 'criterion': None, 'epoch': 0, 'clip_grad': False}      # (retain_graph: train_planner.py:228-229, True with use_inter_loss)
+      exec(compile(loss_src, 'train_planner.one_step_loss', 'exec'), ns)
+      terms, ref_loss = [], ns['one_step_loss']
+
+      def recording_loss(*a, **k):      # what the loop only accumulates as rounded prints: the loss terms of every step, in full precision
+        r = ref_loss(*a, **k)
+        terms.append([float(x) for x in r])
+        return r
+      ns['one_step_loss'] = recording_loss
       with contextlib.redirect_stdout(io.StringIO()):
-        r = TL.tbptt_batch(planner, sample, lp, plp, lambda s, e, tt, ts, dof, dev: straight_line_trajb(s, e, tt, ts, dof), torch.device('cpu'))
-      if mode == 'fix_dynamics':
+        exec(compile(loop_src, 'train_planner.train[batch body]', 'exec'), ns)
+      if tag == 'fix_dynamics':
         out.update(G=Gsz, circles=np.asarray(circ), start=start, goal=goal, th_opt=th_opt)
-      pre = mode + '_'
-      out[pre + 'w_grad'] = r['param_grads']['learn_module_fcn.w']
-      out[pre + 'sdf_grad'] = r['sdf_grad']; out[pre + 'th_final'] = r['th_final']; out[pre + 'err'] = r['err']; out[pre + 'err_ext'] = r['err_ext']
-      out[pre + 'th_curr_grad_last'] = r['th_curr_grad_last']
-      out[pre + 'th_init_grad_is_none'] = r['th_init_grad'] is None
-      out[pre + 'param_names'] = np.asarray(sorted(r['param_grads'].keys()))
-      for k, v in r['log'].items(): out[pre + 'log_' + k] = np.asarray(v)
+      pre = tag + '_'
+      grads = {name: p.grad for name, p in planner.named_parameters()}
+      for name, gr in grads.items():
+        out[pre + 'grad_' + name.replace('.', '_')] = gr
+      out[pre + 'param_names'] = np.asarray(sorted(grads.keys()))
+      out[pre + 'sdf_grad'] = ns['sdf_b'].grad; out[pre + 'th_final'] = ns['th_new_b']; out[pre + 'err'] = ns['errb']; out[pre + 'err_ext'] = ns['err_extb']
+      out[pre + 'th_curr_grad_last'] = ns['th_curr_b'].grad
+      out[pre + 'th_init_grad_is_none'] = ns['th_init_b'].grad is None
+      out[pre + 'terms'] = np.asarray(terms)          # (T, 8): total, pos, vel, cov, gp, sg, obs, ext of every step (one_step_loss's return order)
+      out[pre + 'batch_total_loss'] = ns['batch_total_loss']      # the loop's own running figure (divided by tk at every flush, never cleared)
+      out[pre + 'final_loss'] = ns['final_loss'].detach()
   finally:
     pmod.LearnModuleConv, pmod.LearnModuleFCN = saved
   save('g7_tbptt', **out)

@@ -78,24 +78,50 @@ def test_sdf_cache_hits_and_misses(layer):
   entry = layer._sdf_cache
   assert entry is not None and entry[0]() is sdfb
   layer(th, st, go, None, sdfb, None, None, None)
-  assert layer._sdf_cache is entry                                               # same tensor, same version: hit
+  assert layer._sdf_cache is entry                                               # same tensor object, storage, shape, strides: hit
   i0 = layer.last_info
-  sdf.add_(1.0)                                                                  # in-place change of the storage: version bump -> miss
+  # zero-copy entries cannot go stale: the kernel reads sdfb's own storage, so an in-place write (through the tensor or through .data,
+  # which does not bump the version counter -- ADVICE r3) needs no re-marshalling, and the address handed over is still the tensor's
+  sdf.add_(1.0); sdf.data.mul_(2.0)
   layer(th, st, go, None, sdfb, None, None, None)
+  assert layer._sdf_cache is entry and layer._pc.calls[-1][1][5] == sdf.data_ptr()
+  assert layer.last_info is i0                                                   # flag buffer reused per (batch, device, stream) without grad
+  # a resize / restride of the same tensor object is a miss
+  sdfb2 = sdf.expand(3, 1, 8, 10)
+  layer(th, st, go, None, sdfb2, None, None, None)
   assert layer._sdf_cache is not entry
-  assert layer.last_info is i0                                                   # flag buffer reused per (batch, device, stream)
-  # a float64 grid with float32 trajectories: converted copy owned by the cache entry, dropped when the tensor dies
+  # a float64 grid with float32 trajectories needs a converted copy: made on EVERY call and never cached (it would not see later writes)
   sdf64 = torch.randn(3, 1, 8, 10, dtype=torch.float64)
+  before = layer._sdf_cache
   layer(th, st, go, None, sdf64, None, None, None)
   a = layer._pc.calls[-1][1]
   assert a[5] != sdf64.data_ptr() and a[6:9] == (8, 10, 80)                      # per-sample grids: stride H*W elements
-  assert layer._sdf_cache[6][4] is not None and layer._sdf_cache[6][4].dtype == torch.float32
-  del sdf64
+  assert layer._sdf_cache is before
+  sdf64.data.zero_()                                                             # invisible to the version counter ...
+  sd = layer._sdf_args(sdf64, torch.float32, 3, -1)
+  assert float(sd[4].abs().max()) == 0.0                                         # ... but the next call converts again and sees it
+  # the cached entry dies with its tensor
+  layer(th, st, go, None, sdfb, None, None, None)
+  assert layer._sdf_cache is not None
+  del sdfb, sdfb2, entry, before
   gc.collect()
   assert layer._sdf_cache is None
   # fewer grids than trajectories would be read out of bounds
   with pytest.raises(ValueError):
     layer(th, st, go, None, torch.randn(2, 1, 8, 10), None, None, None)
+
+
+def test_info_buffer_is_fresh_under_grad(layer):
+  th, st, go, sdf = _inputs()
+  sdfb = sdf.expand(3, 1, 8, 10)
+  th.requires_grad_(True)
+  layer(th, st, go, None, sdfb, None, None, None); i0 = layer.last_info
+  layer(th, st, go, None, sdfb, None, None, None); i1 = layer.last_info
+  assert i0 is not i1 and i0.data_ptr() != i1.data_ptr()                         # a training step keeps its own flags
+  th2 = th.detach()
+  layer(th2, st, go, None, sdfb, None, None, None); j0 = layer.last_info
+  layer(th2, st, go, None, sdfb, None, None, None); j1 = layer.last_info
+  assert j0 is j1                                                                # no autograd node: one buffer per (batch, device, stream)
 
 
 def test_per_state_covariances_and_backward_arguments(layer):

@@ -246,18 +246,19 @@ def test_autograd_shared_sdf_expand_and_static_covs(golden):
   assert rel_err(sdf1.grad.cpu().numpy(), sdfB.grad.sum(0, keepdim=True).cpu().numpy()) < 1e-10
 
 
-def _learn_planner(n, B, lp, out_dim=None):
-  """dgpmp2_amd planner in learned mode with the stub learn modules of tests/tbptt_loop.py (the ones make_golden.py injected into the
-  reference planner); out_dim as the reference's constructor computes it (diff_gpmp2_planner.py:62-76)."""
-  import tbptt_loop as TL
+def _learn_planner(n, B, lp):
+  """dgpmp2_amd planner in learned mode with the stub learn modules of tests/tbptt_driver.py (the ones make_golden.py injected into the
+  reference planner), handed over as FACTORIES with the reference classes' constructor signature: like the reference's constructor
+  (diff_gpmp2_planner.py:60-87) the planner first writes num_traj_states / state_dim / out_dim into learn_params, then builds the modules."""
+  import tbptt_driver as TD
   from dgpmp2_amd.robot_models import PointRobot2D
   from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
   gp, ob, pp, op, ev = ref_params(n)
-  mode = lp['dgpmp2']['dynamics_mode']
-  n_gp = {'fix_dynamics': 0, 'diag_identity': n - 1, 'qc_full': (n - 1) * 2, 'q_full': (n - 1) * 4}[mode]
-  out_dim = n_gp + n + (n if lp['dgpmp2'].get('learn_eps') else 0)
+  recurrent = lp['model']['type'] == 'recurrent'
+  fcn = (lambda lp_, env, obs, robot, use_cuda=False: (TD.RecurrentFcnStub if recurrent else TD.FcnStub)(lp_['out_dim']).to(DEV))
+  conv = lambda lp_, env, robot, use_cuda=False: TD.ConvStub()
   planner = DiffGPMP2Planner(gp, ob, pp, op, ev, PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n), learn_params=lp,
-                             batch_size=B, use_cuda=True, learn_module_conv=TL.ConvStub(), learn_module_fcn=TL.FcnStub(out_dim).to(DEV))
+                             batch_size=B, use_cuda=True, learn_module_conv=conv, learn_module_fcn=fcn)
   return planner, pp
 
 
@@ -270,35 +271,103 @@ TBPTT_LEARN_PARAMS = {      # == tests/golden/make_golden.py::TBPTT_LEARN_PARAMS
 }
 
 
-@pytest.mark.parametrize('mode', ['fix_dynamics', 'qc_full'])
-def test_tbptt_outer_loop_runs(golden, mode):
-  """One batch of the reference's train() -- learning/train_planner.py:258-410 + one_step_loss :75-120, restated statement by
-  statement in tests/tbptt_loop.py -- driven through dgpmp2_amd's planner: detach -> step() -> th + dtheta ->
-  unweighted_errors_batch(th_new, sdf) -> one_step_loss (expert loss on dtheta + ext_loss_weight * (gp + sg + obs_lambda * obs)) ->
-  final_loss.backward() + the chained buffer backward.  The SAME function ran on the reference's planner to make the fixture
-  (tests/golden/make_golden.py::g7_tbptt): losses, the final trajectory and the gradients deposited in the learn module's parameters,
-  in sdf_b and in the last th_curr_b must agree."""
+@pytest.mark.parametrize('tag,mode,mtype', [('fix_dynamics', 'fix_dynamics', 'feed_forward'), ('qc_full', 'qc_full', 'feed_forward'),
+                                            ('recurrent', 'fix_dynamics', 'recurrent')])
+def test_tbptt_outer_loop_runs(golden, tag, mode, mtype):
+  """The solver drops into the reference's outer learning loop.  Fixture g7_tbptt = one batch of the reference's train() -- ITS OWN loop
+  text (learning/train_planner.py:258-424 and one_step_loss, exec'd from /root/reference by tests/golden/make_golden.py) on the
+  reference's planner.  Here: this build's statement of the same truncated-BPTT procedure (tests/tbptt_driver.py: fresh leaf per GN step,
+  loss on the update + the unweighted factor errors at th + dtheta, flush every tk steps through at most tk2 links) through dgpmp2_amd's
+  planner -- feed-forward predictor in two dynamics modes, and a recurrent one (hiddenb through step(), diff_gpmp2_planner.py:192,208-210).
+  Loss terms of every step, the final trajectory, and the gradients left in the predictor's parameters, in the grid and in the last
+  trajectory leaf must agree with the reference's."""
   import copy
-  import tbptt_loop as TL
+  import tbptt_driver as TD
   from dgpmp2_amd.utils.planner_utils import straight_line_trajb
   g = golden('g7_tbptt')
   B, n, G = 3, 16, int(g['G'])
   lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
   lp['dgpmp2']['dynamics_mode'] = mode
+  lp['model']['type'] = mtype
   planner, pp = _learn_planner(n, B, lp)
+  dg = lp['dgpmp2']
   sdf = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1)
-  sample = {'im': (sdf > 0).double(), 'sdf': sdf.clone(), 'start': T(g['start']), 'goal': T(g['goal']), 'th_opt': T(g['th_opt'])}
-  r = TL.tbptt_batch(planner, sample, lp, pp, straight_line_trajb, torch.device(DEV))
-  pre = mode + '_'
-  assert sorted(r['param_grads'].keys()) == list(g[pre + 'param_names'])
-  for k in ('final_loss', 'ext_loss', 'obs_loss', 'gp_loss', 'sg_loss', 'pos_loss'):
-    assert rel_err(np.asarray(r['log'][k]), g[pre + 'log_' + k]) < 1e-9, k
+  batch = {'im': (sdf > 0).double(), 'sdf': sdf.clone().requires_grad_(True), 'start': T(g['start']), 'goal': T(g['goal']), 'th_opt': T(g['th_opt'])}
+  th_init = straight_line_trajb(batch['start'][:, :, :2], batch['goal'][:, :, :2], pp['total_time_sec'], pp['total_time_step'], 2, torch.device(DEV))
+  th_init.requires_grad_(True)
+  r = TD.truncated_bptt(planner, batch, th_init, dg['T'], dg['tk'], dg['tk2'], lp['optim'], recurrent=(mtype == 'recurrent'))
+  pre = tag + '_'
+  ref_terms = g[pre + 'terms']                    # (T, 8): total, pos, vel, cov (always 0), gp, sg, obs, ext
+  mine = np.asarray([[float(x) for x in (t.total, t.pos, t.vel, 0.0, t.gp, t.sg, t.obs, t.ext)] for t in r['terms']])
+  assert mine.shape == ref_terms.shape
+  for c, name in enumerate(('total', 'pos', 'vel', 'cov', 'gp', 'sg', 'obs', 'ext')):
+    assert rel_err(mine[:, c], ref_terms[:, c]) < 1e-9 or float(np.abs(ref_terms[:, c]).max()) == 0.0, name
+  grads = {name: p.grad for name, p in planner.named_parameters()}
+  assert sorted(grads.keys()) == list(g[pre + 'param_names'])
   assert rel_err(r['th_final'].cpu().numpy(), g[pre + 'th_final']) < 1e-9
   assert rel_err(r['err'].cpu().numpy(), g[pre + 'err']) < 1e-9 and rel_err(r['err_ext'].cpu().numpy(), g[pre + 'err_ext']) < 1e-9
-  assert rel_err(r['param_grads']['learn_module_fcn.w'].cpu().numpy(), g[pre + 'w_grad']) < 1e-8
-  assert rel_err(r['sdf_grad'].cpu().numpy(), g[pre + 'sdf_grad']) < 1e-8
-  assert rel_err(r['th_curr_grad_last'].cpu().numpy(), g[pre + 'th_curr_grad_last']) < 1e-8
-  assert (r['th_init_grad'] is None) == bool(g[pre + 'th_init_grad_is_none'])
+  for name, gr in grads.items():
+    assert rel_err(gr.cpu().numpy(), g[pre + 'grad_' + name.replace('.', '_')]) < 1e-8, name
+  assert rel_err(batch['sdf'].grad.cpu().numpy(), g[pre + 'sdf_grad']) < 1e-8
+  assert rel_err(r['last_input_leaf'].grad.cpu().numpy(), g[pre + 'th_curr_grad_last']) < 1e-8
+  assert (th_init.grad is None) == bool(g[pre + 'th_init_grad_is_none'])
+
+
+def test_constructor_prepares_learn_params_like_the_reference(golden):
+  """diff_gpmp2_planner.py:58-78: the constructor writes num_traj_states / state_dim / out_dim into learn_params (per dynamics_mode,
+  dtheta_predict, learn_eps) and keeps the image resolution as self.res.  Fixture g6_helpers: what the REFERENCE's constructor left
+  in the dict for every combination."""
+  import copy
+  g = golden('g6_helpers')
+  n, B = 16, 2
+  combos = [(m, le, dp) for m in ('fix_dynamics', 'diag_identity', 'qc_full', 'q_full') for le in (False, True) for dp in (False, True)]
+  got = []
+  for mode, learn_eps, dth_pred in combos:
+    lp = copy.deepcopy(TBPTT_LEARN_PARAMS)
+    lp['dgpmp2'].update(dynamics_mode=mode, learn_eps=learn_eps, dtheta_predict=dth_pred)
+    planner, _ = _learn_planner(n, B, lp)
+    got.append([lp['num_traj_states'], lp['state_dim'], lp['out_dim']])
+    assert planner.res == float(g['lp_res'])
+    assert planner.learn_module_fcn.w.numel() == lp['out_dim']       # the factory saw the prepared dict
+  assert np.array_equal(np.asarray(got), g['lp_prepared'])
+
+
+def test_get_covariances_matches_reference_fixture(golden):
+  """get_covariances (diff_gpmp2_planner.py:247-290), every mode x learn_eps, and get_obs_covariance (:293-297) on the inputs of
+  fixture g6_helpers: bit-identical to what the reference's methods returned."""
+  g = golden('g6_helpers')
+  n, B = 16, 3
+  planner = make_planner(n, B)
+  for mode in ('fix_dynamics', 'diag_identity', 'qc_full', 'q_full'):
+    for le in (False, True):
+      key = 'cov_%s_%d' % (mode, int(le))
+      out = T(g[key + '_in'])
+      res = planner.get_covariances(out, mode, le)
+      res = res if isinstance(res, tuple) else (res,)
+      assert len(res) == int(g[key + '_count'])
+      for i, t in enumerate(res):
+        ref = g['%s_out%d' % (key, i)]
+        assert tuple(t.shape) == ref.shape and np.array_equal(t.cpu().numpy(), ref), (key, i)
+  with pytest.raises(NotImplementedError):
+    planner.get_covariances(T(g['cov_qc_full_0_in']), 'diag')
+  w = planner.get_obs_covariance(T(g['obscov_in']))
+  assert tuple(w.shape) == g['obscov_out'].shape and np.array_equal(w.cpu().numpy(), g['obscov_out'])
+
+
+def test_forward_raises_on_non_spd_like_cholesky():
+  """forward()'s fused path has synchronised anyway (history copy): a non-SPD system raises, as torch.cholesky does in the reference
+  (plan_layer.py:226).  A negative obstacle weight cannot be expressed through the static config, so drive it with reg < 0."""
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  n, B = 16, 2
+  gp, ob, pp, op, ev = ref_params(n)
+  op['reg'] = -1.0e6
+  planner = DiffGPMP2Planner(gp, ob, pp, op, ev, PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n, use_cuda=True), batch_size=B, use_cuda=True)
+  th = torch.zeros(B, n, 4, dtype=torch.float64, device=DEV)
+  sdf = torch.ones(B, 1, 16, 16, dtype=torch.float64, device=DEV)
+  with pytest.raises(RuntimeError, match='not positive definite'):
+    planner.forward(th, th[:, :1], th[:, :1], None, sdf)
+  assert int(planner.plan_layer.last_info.count_nonzero()) == B
 
 
 def test_unweighted_errors_and_error_ext_are_differentiable_like_the_reference(golden):
