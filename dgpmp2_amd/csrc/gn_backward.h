@@ -129,7 +129,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     SpdCheck<Ctx> ok = {&cx, 0};
     if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
+      gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR), false, WbParks<DOF, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
     } else {
       gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
     }

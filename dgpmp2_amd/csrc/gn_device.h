@@ -142,7 +142,9 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
   // (+ an S_k^-1 stash where SinvStashBlocks asks for one -- currently only the backward kernel does: in STEP mode it would ALIAS
   // the staging block, th being loaded before the sweep and dtheta stored after the recovery; in SOLVE mode follow the trajectory)
   constexpr int kRows = (MODE == dgp::MODE_SOLVE) ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
-  constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;
+  constexpr int kStashS = dgp::is_wb(QK) ? 0 : dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, MODE>::value>::kBytes;      // (the Woodbury kernels keep no S_k^-1)
+  constexpr int kParkB = (dgp::is_wb(QK) && dgp::WbParks<DOF, MODE>::value != 0) ? dgp::LdsPark<dgp::WbParkCells<DOF, dgp::WbParks<DOF, MODE>::value>::value>::kBytes : 0;     // gn_woodbury.h, PARK
+  constexpr int kStash = kStashS > kParkB ? kStashS : kParkB;
   constexpr int kLds = (MODE == dgp::MODE_SOLVE) ? kRows + kStash : (kRows > kStash ? kRows : kStash);
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
   __shared__ __attribute__((aligned(16))) char lds[kLds + kWb];
@@ -173,7 +175,10 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_a
   const dgp::GnGradParams& g = *gg;
   constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
-  constexpr int kStash = dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
+  // the adjoint solve's LDS: the S_k^-1 stash of the block elimination, or the parked recovery state of the Woodbury elimination (gn_woodbury.h, PARK)
+  constexpr int kStash = dgp::is_wb(QK) ? (dgp::WbParks<DOF, dgp::MODE_BACKWARD_SOLVE>::value != 0
+                                               ? dgp::LdsPark<dgp::WbParkCells<DOF, dgp::WbParks<DOF, dgp::MODE_BACKWARD_SOLVE>::value>::value>::kBytes : 0)
+                                        : dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;

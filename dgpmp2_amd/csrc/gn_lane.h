@@ -2296,6 +2296,27 @@ DGP_HD void stash_get(Ctx& cx, int slot, Sym<D>& S) {
   }
 }
 
+// Lane-private LDS slots of NQ 16-byte cells (lane stride an odd number of cells: conflict-free 128-bit accesses) in the block cx.stash()
+// points at: where the d = 6 Woodbury kernels park their recovery state across the Schur assembly and the PCR rounds (gn_woodbury.h, PARK).
+template <int NQ> struct LdsPark {
+  static constexpr int kStride = ((NQ % 2) ? NQ : NQ + 1) * 16;
+  static constexpr int kBytes = 64 * kStride;
+};
+template <int NQ, typename Ctx>
+DGP_HD void lds_park_put(Ctx& cx, const double (&v)[2 * NQ]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  char* l = cx.stash() + cx.lane() * LdsPark<NQ>::kStride;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) { V2 t; t[0] = v[2 * i]; t[1] = v[2 * i + 1]; *(V2*)(l + i * 16) = t; }
+}
+template <int NQ, typename Ctx>
+DGP_HD void lds_park_get(Ctx& cx, double (&v)[2 * NQ]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  const char* l = cx.stash() + cx.lane() * LdsPark<NQ>::kStride;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) { const V2 t = *(const V2*)(l + i * 16); v[2 * i] = t[0]; v[2 * i + 1] = t[1]; }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // One Gauss-Newton linear solve for the C rows owned by this lane (rows j*C .. j*C+C-1 of trajectory b).
 //
@@ -2927,7 +2948,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     };
     if constexpr (is_wb(QK)) {
       static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE), (QK == QK_WBR), (MODE == MODE_STEP)>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
+      gn_linear_solve_wb<DOF, LPT, IO, false, (D == 4 || MODE == MODE_SOLVE), (QK == QK_WBR), (MODE == MODE_STEP), WbParks<DOF, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, x, dx, acc, ok, it == 0 ? &wbv : nullptr, before_pcr);
     } else {
 #if defined(DGP_BISECT_LAMBDA)
       gn_linear_solve<DOF, LPT, C, IO, false, QK, SinvStashBlocks<2 * DOF, C, MODE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, x, dx, acc, ok, [&](const ErrAcc& a) {

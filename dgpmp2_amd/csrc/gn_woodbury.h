@@ -186,6 +186,20 @@ struct WbF {
   static constexpr DGP_HD bool touches(int ft, int c) { return ft == 0 ? ((c % DOF) == 0 || (c % DOF) == 1) : true; }
 };
 
+// 16-byte LDS cells per lane the PARK option of gn_linear_solve_wb needs: t (3 d) + non-zeros of the R factor rows [+ PARK == 1: the strict lower
+// triangle of L; PARK == 2 leaves L in registers -- the fused loop, whose LDS block also holds the fp64 trajectory, has no room for it:
+// four workgroups must fit the CU's 160 KB, or a 4096-trajectory batch no longer runs as ONE wave of workgroups]
+template <int DOF, int PARK> struct WbParkCells {
+  static constexpr int kNzRows = (DOF == 3) ? 3 * (2 + 3) : 3 * 2;
+  static constexpr int value = PARK == 0 ? 0 : (3 * 2 * DOF + kNzRows + (PARK == 1 ? WbF<DOF>::R * (WbF<DOF>::R - 1) / 2 : 0) + 1) / 2;
+};
+
+// which kernels park (bit MODE of DGP_WB_PARK_MODES, d = 6 only; bit 3: the backward kernel's adjoint solve)
+#ifndef DGP_WB_PARK_MODES
+#define DGP_WB_PARK_MODES 11      // STEP, SOLVE, backward (profiles/r04_kernel_variants.txt: 26.7 -> 22.7 us, 21.2 -> 19.6 us per iteration, 42.1 -> 34.5 us)
+#endif
+template <int DOF, int MODE> struct WbParks { static constexpr int value = ((DOF == 3) && (((DGP_WB_PARK_MODES) >> MODE) & 1) != 0) ? (MODE == MODE_SOLVE ? 2 : 1) : 0; };
+
 // S = I + H^T K H (R x R, SPD) in the form the elimination uses it: products B^T S^-1 B' as Y^T Z' with
 //   R = 6 (primary template): S = L Dg L^T (unit lower L);  Y = L^-1 B,  Z = Dg^-1 Y;  S^-1 c = L^-T Dg^-1 L^-1 c
 //          (forward substitutions instead of products with an explicit inverse: R (R - 1) / 2 instead of R^2 operations per column,
@@ -283,7 +297,14 @@ struct WbSolver<3> {
 // RAGGED: the trajectory does not fill the shape (n < 4 LPT): the lane picks one of four table versions from g0 and n; otherwise
 // (every row of every lane exists) the first lane of a trajectory reads version 1, all others version 0.
 // PF: scheduling fences at the phase boundaries (phase_fence in gn_lane.h: the STEP kernels only).
-template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, bool RAGGED, bool PF = false, typename Ctx, typename Hook>
+// PARK (d = 6, round 4): what only the interior recovery needs again -- t = K r (18 doubles), the scaled factor rows (15), L of S (15) -- is
+// written to lane-private LDS slots (LdsPark in gn_lane.h: cx.stash(), 26 conflict-free 128-bit cells per lane) the moment the forward
+// substitutions Y = L^-1 B are done, and read back after the PCR rounds.  The register allocator cannot do that itself (its only spill targets
+// are the accumulation registers, two VALU moves per double each way, and scratch): left alone, the Schur assembly -- Y_p, Y_s, Z_p, Z_s, D_s,
+// U_red: 207 doubles -- and the PCR rounds shuffled this state in and out of AGPRs and kept 22 doubles of it in scratch (244 B per lane, 17.6 MB
+// of HBM traffic per launch).  configs[3] step: 26.4 -> 22.6 us, no scratch (profiles/r04_kernel_variants.txt: parking in AGPRs by hand, across
+// the PCR rounds only or from the same point, gains nothing -- 26.3-26.5 us; LDS reads and writes take no VALU issue slot).
+template <int DOF, int LPT, typename IO, bool RHS_OVERRIDE, bool COLWISE, bool RAGGED, bool PF = false, int PARK = 0, typename Ctx, typename Hook>
 DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[4][2 * DOF],
                                const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const double (&rhs)[4][2 * DOF],
                                double (&dx)[4][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, const WbStaged* staged, Hook&& before_pcr) {
@@ -447,6 +468,9 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   // ---- b_r = H^T t,  B_p = H^T K Cp,  B_s = H^T K Cs;  Schur pieces as Y^T Z (WbSolver), every entry folded into the reduced
   //      separator row the moment it exists: own block (Ess, es) subtracted here, the NEXT lane's (Epp', Eps', ep') fetched across
   //      lanes entry by entry -- no E block is ever live as a whole
+  constexpr bool kPark = (PARK != 0) && (D == 6);
+  constexpr bool kParkL = (PARK == 1);
+  constexpr int kParkCells = kPark ? WbParkCells<DOF, PARK>::value : 1;
   {
     double Yp[R][D], Ys[R][D], yr[R][1];
     {
@@ -492,6 +516,28 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
         const double epn = nb.hi(sp);
         rs[a] -= ss + ((kZeroFill || has_next) ? epn : 0.0);
       }
+    }
+    if constexpr (kPark) {
+      sched_fence();
+      double flat[2 * kParkCells];
+      int q = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) flat[q++] = t[k][a];
+#pragma unroll
+      for (int f = 0; f < R; ++f) {
+#pragma unroll
+        for (int a = 0; a < D; ++a) if (F::nz(f % NF, a)) flat[q++] = hh[f][a];
+        if constexpr (kParkL) {
+#pragma unroll
+          for (int g = 0; g < f; ++g) flat[q++] = sv.L[f][g];
+        }
+      }
+#pragma unroll
+      for (; q < 2 * kParkCells; ++q) flat[q] = 0.0;
+      lds_park_put<kParkCells>(cx, flat);
+      sched_fence();
     }
     if constexpr (COLWISE) {
       // blocks, one COLUMN c at a time: z_p = (S^-1 B_p)_.c, z_s = (S^-1 B_s)_.c, then every entry of that column
@@ -557,6 +603,25 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   double xs[D];
   pcr_solve<D, LPT, true>(cx, j, Ds, Us, rs, xs, ok);
   if constexpr (kFence) sched_fence();
+  if constexpr (kPark) {
+    double flat[2 * kParkCells];
+    lds_park_get<kParkCells>(cx, flat);
+    int q = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) t[k][a] = flat[q++];
+#pragma unroll
+    for (int f = 0; f < R; ++f) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) if (F::nz(f % NF, a)) hh[f][a] = flat[q++];
+      if constexpr (kParkL) {
+#pragma unroll
+        for (int g = 0; g < f; ++g) sv.L[f][g] = flat[q++];
+      }
+    }
+    sched_fence();
+  }
 #pragma unroll
   for (int a = 0; a < D; ++a) dx[C - 1][a] = xs[a];
   // ---- interior rows: y = K q - K H M H^T K q,  K q = t - (K Cp) x_ps - (K Cs) x_s

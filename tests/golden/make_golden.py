@@ -670,5 +670,34 @@ def g7_tbptt():
   save('g7_tbptt', **out)
 
 
+# ------------------------------------------------------------------------------------------------
+# G8: autograd through DiffGPMP2Planner.forward -- the whole Gauss-Newton loop kept in the graph (diff_gpmp2_planner.py:92-174; consumer:
+#   examples/diff_gpmp2_2d_example.py:77) -- w.r.t. the initial trajectory, the grids, the start and goal means.  Samples stop after
+#   different numbers of iterations (tol_delta) and one runs into max_iters; the last dtheta of a sample IS applied (planner_utils.py:3-16).
+# ------------------------------------------------------------------------------------------------
+def g8_forward_grads():
+  import io, contextlib
+  B, n, Gsz = 4, 16, 48
+  start, goal = rand_start_goal(B, seed=41)
+  g = torch.Generator().manual_seed(42)
+  th0 = straight_line_trajb(start[:, :, :2], goal[:, :, :2], 10.0, n - 1, 2) + torch.randn(B, n, 4, generator=g) * 0.15
+  circ = ((-1.0, -1.0, 1.5), (2.0, 1.5, 1.2), (0.5, -2.5, 1.0))
+  sdf = T(circles_sdf(Gsz, circ))[None, None].repeat(B, 1, 1, 1)
+  sdf[0] = 3.0                                     # an obstacle-free sample: converges by tol_delta after two iterations
+  gbar = torch.randn(B, n, 4, generator=g)
+  gp, obs, plp, opt = params_2d(n, max_iters=9)
+  opt['tol_delta'] = 0.5
+  planner = DiffGPMP2Planner(gp, obs, plp, opt, ENV, PointRobot2D(torch.tensor(0.4), 1, n), batch_size=1)
+  leaves = [x.clone().requires_grad_(True) for x in (th0, sdf, start, goal)]
+  with contextlib.redirect_stdout(io.StringIO()):
+    thf, _, e_init, e_final, e_iter, ee_iter, k, _ = planner.forward(leaves[0], leaves[2], leaves[3], (sdf > 0).double(), leaves[1])
+  gr = torch.autograd.grad((gbar * thf).sum(), leaves)
+  maxlen = max(len(e) for e in e_iter)
+  pad = lambda L: np.asarray([list(e) + [np.nan] * (maxlen - len(e)) for e in L])
+  save('g8_forward_grads', th0=th0, G=Gsz, circles=np.asarray(circ), free_sample=0, free_value=3.0, start=start, goal=goal, gbar=gbar, max_iters=9, tol_delta=0.5,
+       th_final=thf, iters=np.asarray(k), err_init=np.asarray(e_init), err_final=np.asarray(e_final), err_iter=pad(e_iter), errext_iter=pad(ee_iter),
+       g_th0=gr[0], g_sdf=gr[1], g_start=gr[2], g_goal=gr[3])
+
+
 if __name__ == '__main__':
-  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset(); g7_errors(); g7_tbptt()
+  g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset(); g7_errors(); g7_tbptt(); g8_forward_grads()

@@ -298,7 +298,7 @@ def test_tbptt_outer_loop_runs(golden, tag, mode, mtype):
   r = TD.truncated_bptt(planner, batch, th_init, dg['T'], dg['tk'], dg['tk2'], lp['optim'], recurrent=(mtype == 'recurrent'))
   pre = tag + '_'
   ref_terms = g[pre + 'terms']                    # (T, 8): total, pos, vel, cov (always 0), gp, sg, obs, ext
-  mine = np.asarray([[float(x) for x in (t.total, t.pos, t.vel, 0.0, t.gp, t.sg, t.obs, t.ext)] for t in r['terms']])
+  mine = np.asarray([[float(x.detach()) if torch.is_tensor(x) else float(x) for x in (t.total, t.pos, t.vel, 0.0, t.gp, t.sg, t.obs, t.ext)] for t in r['terms']])
   assert mine.shape == ref_terms.shape
   for c, name in enumerate(('total', 'pos', 'vel', 'cov', 'gp', 'sg', 'obs', 'ext')):
     assert rel_err(mine[:, c], ref_terms[:, c]) < 1e-9 or float(np.abs(ref_terms[:, c]).max()) == 0.0, name
