@@ -428,10 +428,42 @@ def planner_api_backward_rate(device, reps=200):
     for _ in range(K): x = x + planner.step(x, start, goal, None, sdfb)[0]
     torch.autograd.grad(x, thr, g)
 
+  # one iteration of the reference's training loop (learning/train_planner.py:311-327, 366): step, the unweighted errors at th + dtheta, backward of
+  # both -- as the two calls of the reference API (two autograd nodes) and as planner.step_with_errors (one node; dgp_gn_step_errors[_backward])
+  cw = torch.randn(B, 1, 1, device=device)
+
+  def train_iteration_two_calls():
+    dth = planner.plan_layer(thr, start, goal, None, sdfb, qc, ow, ep)[0]
+    sg, gp_, ob = planner.unweighted_errors_batch(thr + dth, sdfb)
+    torch.autograd.grad((g * dth).sum() + (cw * gp_).sum() + (cw * ob).sum() + (cw.view(B, 1) * sg).sum(), (thr, qc, ow, ep))
+
+  def train_iteration_fused():
+    dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc, ow, ep)
+    torch.autograd.grad((g * dth).sum() + (cw * gp_).sum() + (cw * ob).sum() + (cw.view(B, 1) * sg).sum(), (thr, qc, ow, ep))
+
+  # planner.forward with the graph kept (examples/diff_gpmp2_2d_example.py:77): 10 GN iterations + the backward pass through all of them, two launches
+  sdf_leaf = sdf.clone().requires_grad_(True)
+  planner.optim_params['tol_delta'] = 0.0            # all 10 iterations, as the fused_forward block
+
+  def forward_backward():
+    thf = planner.forward(thr, start, goal, None, sdf_leaf.expand(B, 1, GRID, GRID))[0]
+    torch.autograd.grad(thf, (thr, sdf_leaf), g)
+
   a, b = wall(static_fb), wall(learned_fb)
+  t2, t1 = wall(train_iteration_two_calls), wall(train_iteration_fused)
   reps = max(20, reps // 10)
   c = wall(tbptt_fb) / 10.0
+  fb = wall(forward_backward)
   return {'us_per_call': a, 'learned_covariances_us_per_call': b, 'tbptt_window10_us_per_step': c,
+          'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1,
+                                  'note': 'learned covariances (per-state qc_inv / obscov_inv / eps that require grad): step + unweighted errors at th + dtheta + '
+                                          'backward of a loss on all four outputs w.r.t. all four inputs, wall per iteration -- PlanLayer.forward + '
+                                          'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '
+                                          'C-ABI call each way: dgp_gn_step_errors / dgp_gn_step_errors_backward, two stream-ordered launches each)'},
+          'forward_backward_fused': {'us_per_call': fb, 'us_per_gn_iteration': fb / GN_ITERS, 'gn_iterations': GN_ITERS,
+                                     'note': 'DiffGPMP2Planner.forward with requires_grad inputs + torch.autograd.grad through all 10 iterations w.r.t. the '
+                                             'initial trajectory and the grid: dgp_gn_solve_traced + dgp_gn_solve_backward, one launch each (wall, host '
+                                             'side of forward() -- the history copy and python lists -- included)'},
           'note': 'wall time of DiffGPMP2Planner.step() + torch.autograd.grad through it, B=4096: static covariances with the gradient w.r.t. the '
                   'trajectory (us_per_call), and per-state qc_inv / obscov_inv / eps tensors with gradients w.r.t. all four (learned_covariances_us_per_call); '
                   'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine.  tbptt_window10_us_per_step: ten chained steps '

@@ -17,7 +17,7 @@ DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64 = 0, 1
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
-DGP_ABI_VERSION = 3
+DGP_ABI_VERSION = 4
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
@@ -50,7 +50,8 @@ class CApi(object):
   """Thin typed wrapper over one shared library exporting <prefix>create, <prefix>gn_step, ..."""
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
-             'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
+             'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward', 'gn_step_errors',
+             'gn_step_errors_backward', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -79,6 +80,15 @@ class CApi(object):
                                       i32, vp, vp, vp, vp]
     self.eval_errors_backward = f('eval_errors_backward'); self.eval_errors_backward.restype = C.c_int
     self.eval_errors_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp]
+    self.gn_solve_traced = f('gn_solve_traced'); self.gn_solve_traced.restype = C.c_int
+    self.gn_solve_traced.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), i32, dbl, vp, vp, vp, vp, vp, vp, vp, vp]
+    self.gn_solve_backward = f('gn_solve_backward'); self.gn_solve_backward.restype = C.c_int
+    self.gn_solve_backward.argtypes = [vp, i32, vp, vp, C.POINTER(DgpSdf), i32, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp]
+    self.gn_step_errors = f('gn_step_errors'); self.gn_step_errors.restype = C.c_int
+    self.gn_step_errors.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp]
+    self.gn_step_errors_backward = f('gn_step_errors_backward'); self.gn_step_errors_backward.restype = C.c_int
+    self.gn_step_errors_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64,
+                                             i32, vp, vp, vp, vp, vp]
     self.time_next_launch = f('time_next_launch'); self.time_next_launch.restype = C.c_int; self.time_next_launch.argtypes = [vp, vp]
     self.event_create = f('event_create'); self.event_create.restype = C.c_int; self.event_create.argtypes = [C.POINTER(vp)]
     self.event_destroy = f('event_destroy'); self.event_destroy.restype = None; self.event_destroy.argtypes = [vp]
@@ -132,7 +142,12 @@ class KernelTimer(object):
 
 _api = None
 _pycall = None
-PYCALL_PATH = os.path.join(_HERE, 'lib', '_dgp_pycall.so')
+import sysconfig
+# the trampoline is a CPython extension: its file name carries the interpreter's ABI tag, so that a library built for another Python is
+# never loaded by mistake
+PYCALL_PATH = os.path.join(_HERE, 'lib', '_dgp_pycall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
+_PYCALL_ENTRIES = ('gn_step', 'gn_solve', 'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward',
+                   'gn_step_errors', 'gn_step_errors_backward')
 
 
 def get_api():
@@ -143,21 +158,61 @@ def get_api():
   return _api
 
 
+class CtypesPycall(object):
+  """Drop-in for the trampoline module, on the plain ctypes binding: the same positional signatures (addresses as ints / None, the two
+  structs flattened into their fields), 3-5 us slower per call.  Used when the trampoline has not been built or does not load
+  (no Python.h on the build host, another interpreter): the product path is then still the C-ABI, only the marshalling is slower."""
+
+  def __init__(self, api):
+    self.api = api
+
+  @staticmethod
+  def _sdf(a, i):
+    return C.byref(DgpSdf(a[i], int(a[i + 1]), int(a[i + 2]), int(a[i + 3]))) if a[i] else None
+
+  @staticmethod
+  def _covs(a, i):
+    return C.byref(DgpCovs(int(a[i]), a[i + 1], a[i + 2], a[i + 3]))
+
+  def _prefixed(self, fn, a):
+    return fn(a[0], a[1], a[2], a[3], a[4], self._sdf(a, 5), self._covs(a, 9), *a[13:])
+
+  def gn_step(self, *a): return self._prefixed(self.api.gn_step, a)
+  def gn_solve(self, *a): return self._prefixed(self.api.gn_solve, a)
+  def eval_errors(self, *a): return self._prefixed(self.api.eval_errors, a)
+  def gn_step_backward(self, *a): return self._prefixed(self.api.gn_step_backward, a)
+  def eval_errors_backward(self, *a): return self._prefixed(self.api.eval_errors_backward, a)
+  def gn_solve_traced(self, *a): return self._prefixed(self.api.gn_solve_traced, a)
+  def gn_step_errors(self, *a): return self._prefixed(self.api.gn_step_errors, a)
+  def gn_step_errors_backward(self, *a): return self._prefixed(self.api.gn_step_errors_backward, a)
+
+  def gn_solve_backward(self, *a):
+    return self.api.gn_solve_backward(a[0], a[1], a[2], a[3], self._sdf(a, 4), *a[8:])
+
+
 def get_pycall():
   """The METH_FASTCALL trampoline onto the product library's entry points (csrc/dgp_pycall.c): the same C-ABI calls as the ctypes
   binding above at a tenth of the per-call marshalling cost.  What the torch-facing layer (dgpmp2_amd.gpmp2) launches through;
-  the ctypes methods of `Solver` stay the reference binding (tests, tools).  Raises ImportError if it was not built."""
+  the ctypes methods of `Solver` stay the reference binding (tests, tools).  The product library itself must exist
+  (ImportError otherwise: there is no CPU path); a missing or unloadable trampoline falls back to CtypesPycall with a warning."""
   global _pycall
   if _pycall is None:
     api = get_api()
-    if not os.path.exists(PYCALL_PATH):
-      raise ImportError('%s is missing: build it with `python -c "import __graft_entry__ as g; g.build()"`' % PYCALL_PATH)
-    spec = importlib.util.spec_from_file_location('_dgp_pycall', PYCALL_PATH)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    addr = lambda f: C.cast(f, C.c_void_p).value
-    mod.bind(addr(api.gn_step), addr(api.gn_solve), addr(api.eval_errors), addr(api.gn_step_backward), addr(api.eval_errors_backward))
-    _pycall = mod
+    try:
+      if not os.path.exists(PYCALL_PATH):
+        raise ImportError('%s is missing' % PYCALL_PATH)
+      spec = importlib.util.spec_from_file_location('_dgp_pycall', PYCALL_PATH)
+      mod = importlib.util.module_from_spec(spec)
+      spec.loader.exec_module(mod)
+      addr = lambda f: C.cast(f, C.c_void_p).value
+      mod.bind(*[addr(getattr(api, name)) for name in _PYCALL_ENTRIES])
+      _pycall = mod
+    except (ImportError, OSError, TypeError) as e:
+      import warnings
+      warnings.warn('dgpmp2_amd: the call trampoline %s is not usable (%s: %s); using the ctypes binding of the same C-ABI entry points '
+                    '(3-5 us more host time per launch).  Build it with `python -c "import __graft_entry__ as g; g.build()"`.'
+                    % (os.path.basename(PYCALL_PATH), type(e).__name__, e))
+      _pycall = CtypesPycall(api)
   return _pycall
 
 
@@ -242,6 +297,28 @@ class Solver(object):
     self.api.check(self.api.gn_step_backward(self.handle, batch, th, start, goal, C.byref(sdf),
                                              C.byref(covs) if covs is not None else None, dtheta, g_dtheta, g_err_ext, g_th, g_start,
                                              g_goal, g_sdf, int(g_sdf_batch_stride), int(g_sdf_copies), g_qc_inv, g_obs_w, g_eps, stream))
+
+  def gn_solve_traced(self, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist=None, errext_hist=None,
+                      err_final=None, info=None, th_hist=None, stream=None):
+    self.api.check(self.api.gn_solve_traced(self.handle, batch, th_init, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,
+                                            int(max_iters), float(tol_delta), th_out, iters, err_hist, errext_hist, err_final, info, th_hist, stream))
+
+  def gn_solve_backward(self, batch, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, g_th_init=None, g_start=None, g_goal=None,
+                        g_sdf=None, g_sdf_batch_stride=0, stream=None, g_sdf_copies=1):
+    self.api.check(self.api.gn_solve_backward(self.handle, batch, start, goal, C.byref(sdf), int(max_iters), th_hist, th_out, iters, g_th_out,
+                                              g_th_init, g_start, g_goal, g_sdf, int(g_sdf_batch_stride), int(g_sdf_copies), stream))
+
+  def gn_step_errors(self, batch, th, start, goal, sdf, covs, dtheta, err=None, err_ext=None, info=None, unw_sg=None, unw_gp=None, unw_obs=None,
+                     stream=None):
+    self.api.check(self.api.gn_step_errors(self.handle, batch, th, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,
+                                           dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs, stream))
+
+  def gn_step_errors_backward(self, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th=None,
+                              g_start=None, g_goal=None, g_sdf=None, g_sdf_batch_stride=0, g_qc_inv=None, g_obs_w=None, g_eps=None, workspace=None,
+                              stream=None, g_sdf_copies=1):
+    self.api.check(self.api.gn_step_errors_backward(self.handle, batch, th, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,
+                                                    dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start, g_goal, g_sdf,
+                                                    int(g_sdf_batch_stride), int(g_sdf_copies), g_qc_inv, g_obs_w, g_eps, workspace, stream))
 
   def eval_errors_backward(self, batch, th, start, goal, sdf, covs, g_err_ext=None, g_unw_sg=None, g_unw_gp=None, g_unw_obs=None,
                            g_th=None, g_start=None, g_goal=None, g_sdf=None, g_sdf_batch_stride=0, g_eps=None, stream=None, g_sdf_copies=1):

@@ -279,6 +279,11 @@ inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const vo
   return DGP_OK;
 }
 
+// fields of GnGradParams that only the round-4 entry points set
+inline void clear_extensions(dgp::GnGradParams& g) {
+  g.accumulate = 0; g.g_th_new = nullptr; g.th_addend = nullptr; g.th_hist = nullptr; g.th_final = nullptr; g.iters = nullptr; g.chain_iters = 0; g.pad_ = 0;
+}
+
 inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                          const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
                          void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv,
@@ -290,6 +295,7 @@ inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   if (g_dtheta && !dtheta) return fail(DGP_EINVAL, "dtheta (the forward output) is needed with a g_dtheta cotangent");
   if (g_qc_inv && p.qc_mode == DGP_QC_STATIC) return fail(DGP_EINVAL, "g_qc_inv given but qc_mode is DGP_QC_STATIC");
+  clear_extensions(g);
   g.dtheta = dtheta; g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
   g.g_unw_sg = g.g_unw_gp = g.g_unw_obs = nullptr;
   g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
@@ -316,12 +322,118 @@ inline int fill_eval_backward(const DgpHandle* h, int32_t batch, const void* th,
   if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
   if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   if (g_eps && !c.eps) return fail(DGP_EINVAL, "g_eps given but covs->eps is NULL (static epsilon)");
+  clear_extensions(g);
   g.dtheta = nullptr; g.g_dtheta = nullptr; g.g_err_ext = g_err_ext;
   g.g_unw_sg = g_unw_sg; g.g_unw_gp = g_unw_gp; g.g_unw_obs = g_unw_obs;
   g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
   g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = g_eps;
   p.vec_io = (aligned16(th) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
+}
+
+// dgp_gn_solve_backward: the chain kernels (static covariances, n <= 256)
+inline int fill_solve_backward(const DgpHandle* h, int32_t batch, const void* start, const void* goal, const DgpSdf* sdf, int32_t max_iters,
+                               const double* th_hist, const void* th_out, const int32_t* iters, const void* g_th_out, void* g_th_init,
+                               void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, dgp::GnParams& p,
+                               dgp::GnGradParams& g) {
+  if (!th_hist || !th_out || !iters || !g_th_out) return fail(DGP_EINVAL, "th_hist, th_out, iters and g_th_out must be non-null");
+  int rc = fill_call(h, batch, th_out, start, goal, sdf, nullptr, p);
+  if (rc != DGP_OK) return rc;
+  if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward is not implemented for num_states > 256 (chain the per-step backward instead)");
+  if (!dgp::use_static_kernels(p)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward needs a diagonal static Q_c_inv");
+  if (max_iters < 1) return fail(DGP_EINVAL, "max_iters must be >= 1, got %d", max_iters);
+  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
+  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
+  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
+  clear_extensions(g);
+  g.dtheta = nullptr; g.g_dtheta = g_th_out; g.g_err_ext = nullptr; g.g_unw_sg = g.g_unw_gp = g.g_unw_obs = nullptr;
+  g.g_th = g_th_init; g.g_start = g_start; g.g_goal = g_goal;
+  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = nullptr;
+  g.th_hist = th_hist; g.th_final = th_out; g.iters = iters; g.chain_iters = max_iters;
+  p.max_iters = max_iters;
+  p.vec_io = (aligned16(th_out) && aligned16(g_th_out) && aligned16(g_th_init)) ? 1 : 0;
+  return DGP_OK;
+}
+
+// ---- the round-4 entry points, generic over how a kernel is launched (HIP: dgpmp2_hip.hip; the test emulator: tests/emul) ------------------
+// `launch(mode, p, g)` -> DGP_OK or an error code; mode: dgp::MODE_* / 3 = backward / 4 = chain backward.
+enum { kModeBackward = 3, kModeChain = 4 };
+
+template <typename Launch>
+int gn_solve_traced(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf, const DgpCovs* covs,
+                    int32_t max_iters, double tol_delta, void* th_out, int32_t* iters, void* err_hist, void* errext_hist, void* err_final, int32_t* info,
+                    double* th_hist, Launch&& launch) {
+  dgp::GnParams p;
+  int rc = fill_solve(h, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist, errext_hist, err_final, info, p);
+  if (rc != DGP_OK) return rc;
+  if (th_hist && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "th_hist is not implemented for num_states > 256");
+  if (th_hist && !iters) return fail(DGP_EINVAL, "th_hist needs iters (rows at or past iters[b] are not written)");
+  p.dtheta = th_hist;              // (the fused loop has no dtheta output: the field carries the history pointer, gn_lane.h)
+  return launch(dgp::MODE_SOLVE, p, (const dgp::GnGradParams*)nullptr);
+}
+
+template <typename Launch>
+int gn_solve_backward(const DgpHandle* h, int32_t batch, const void* start, const void* goal, const DgpSdf* sdf, int32_t max_iters, const double* th_hist,
+                      const void* th_out, const int32_t* iters, const void* g_th_out, void* g_th_init, void* g_start, void* g_goal, void* g_sdf,
+                      int64_t g_sdf_batch_stride, int32_t g_sdf_copies, Launch&& launch) {
+  dgp::GnParams p;
+  dgp::GnGradParams g;
+  int rc = fill_solve_backward(h, batch, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, g_th_init, g_start, g_goal, g_sdf,
+                               g_sdf_batch_stride, g_sdf_copies, p, g);
+  if (rc != DGP_OK) return rc;
+  return launch((int)kModeChain, p, &g);
+}
+
+template <typename Launch>
+int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf, const DgpCovs* covs,
+                   void* dtheta, void* err, void* err_ext, int32_t* info, void* unw_sg, void* unw_gp, void* unw_obs, Launch&& launch) {
+  dgp::GnParams p;
+  int rc = fill_step(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, p);
+  if (rc != DGP_OK) return rc;
+  const bool errs = unw_sg || unw_gp || unw_obs;
+  if (errs && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors is not implemented for num_states > 256");
+  rc = launch(dgp::MODE_STEP, p, (const dgp::GnGradParams*)nullptr);
+  if (rc != DGP_OK || !errs) return rc;
+  // the unweighted errors at th + dtheta: the error kernel with dtheta as addend, stream-ordered behind the step (only eps of the covariances enters them)
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
+  rc = fill_eval(h, batch, th, start, goal, sdf, &c, nullptr, nullptr, unw_sg, unw_gp, unw_obs, p);
+  if (rc != DGP_OK) return rc;
+  p.dtheta = dtheta;               // MODE_EVAL: the addend (gn_lane.h)
+  p.vec_io = (aligned16(th) && aligned16(dtheta)) ? 1 : 0;
+  return launch(dgp::MODE_EVAL, p, (const dgp::GnGradParams*)nullptr);
+}
+
+template <typename Launch>
+int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf, const DgpCovs* covs,
+                            const void* dtheta, const void* g_dtheta, const void* g_err_ext, const void* g_unw_sg, const void* g_unw_gp,
+                            const void* g_unw_obs, void* g_th, void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                            void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace, Launch&& launch) {
+  dgp::GnParams p;
+  dgp::GnGradParams g;
+  const bool errs = g_unw_sg || g_unw_gp || g_unw_obs;
+  if (errs) {
+    if (!workspace || !dtheta) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs dtheta and a (B,n,d) workspace when an unweighted-error cotangent is given");
+    // launch 1: backward of the unweighted errors at th + dtheta -> workspace (gradient w.r.t. th + dtheta), start / goal / eps / grid shares
+    int rc = fill_eval_backward(h, batch, th, start, goal, sdf, covs, nullptr, g_unw_sg, g_unw_gp, g_unw_obs, workspace, g_start, g_goal, g_sdf,
+                                g_sdf_batch_stride, g_sdf_copies, nullptr, p, g);
+    if (rc != DGP_OK) return rc;
+    if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors_backward is not implemented for num_states > 256");
+    g.g_eps = g_eps;                // (written by BOTH launches whatever the epsilon source: launch 2 adds to what this one stores)
+    g.th_addend = dtheta;
+    p.vec_io = (p.vec_io && aligned16(dtheta)) ? 1 : 0;
+    rc = launch((int)kModeBackward, p, &g);
+    if (rc != DGP_OK) return rc;
+  }
+  // launch 2 (the only one without error cotangents): backward of the step; with launch 1 in front, the workspace joins the dtheta cotangent and g_th,
+  // and the small gradients are added to launch 1's
+  int rc = fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
+                         g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
+  if (rc != DGP_OK) return rc;
+  if (errs) {
+    g.g_th_new = workspace; g.accumulate = 1;
+    p.vec_io = (p.vec_io && aligned16(workspace)) ? 1 : 0;
+  }
+  return launch((int)kModeBackward, p, &g);
 }
 
 }  // namespace dgp_host

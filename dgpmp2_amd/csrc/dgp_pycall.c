@@ -26,7 +26,21 @@ typedef int (*eval_errors_backward_fn)(const DgpHandle*, int32_t, const void*, c
                                        const void*, const void*, const void*, const void*, void*, void*, void*, void*, int64_t, int32_t, void*,
                                        void*);
 
+typedef int (*gn_solve_traced_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, int32_t, double, void*,
+                                  int32_t*, void*, void*, void*, int32_t*, double*, void*);
+typedef int (*gn_solve_backward_fn)(const DgpHandle*, int32_t, const void*, const void*, const DgpSdf*, int32_t, const double*, const void*, const int32_t*,
+                                    const void*, void*, void*, void*, void*, int64_t, int32_t, void*);
+typedef int (*gn_step_errors_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, void*, void*, void*,
+                                 int32_t*, void*, void*, void*, void*);
+typedef int (*gn_step_errors_backward_fn)(const DgpHandle*, int32_t, const void*, const void*, const void*, const DgpSdf*, const DgpCovs*, const void*,
+                                          const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*, int64_t, int32_t,
+                                          void*, void*, void*, void*, void*);
+
 static gn_step_fn f_gn_step;
+static gn_solve_traced_fn f_gn_solve_traced;
+static gn_solve_backward_fn f_gn_solve_backward;
+static gn_step_errors_fn f_gn_step_errors;
+static gn_step_errors_backward_fn f_gn_step_errors_backward;
 static gn_solve_fn f_gn_solve;
 static eval_errors_fn f_eval_errors;
 static gn_step_backward_fn f_gn_step_backward;
@@ -66,12 +80,16 @@ static inline int64_t as_i64(PyObject* o, int* bad) {
   const DgpSdf* sdfp = sdf.data ? &sdf : NULL
 
 static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
-  NEED(5, "bind");
+  NEED(9, "bind");
   f_gn_step = (gn_step_fn)P(0);
   f_gn_solve = (gn_solve_fn)P(1);
   f_eval_errors = (eval_errors_fn)P(2);
   f_gn_step_backward = (gn_step_backward_fn)P(3);
   f_eval_errors_backward = (eval_errors_backward_fn)P(4);
+  f_gn_solve_traced = (gn_solve_traced_fn)P(5);
+  f_gn_solve_backward = (gn_solve_backward_fn)P(6);
+  f_gn_step_errors = (gn_step_errors_fn)P(7);
+  f_gn_step_errors_backward = (gn_step_errors_backward_fn)P(8);
   if (bad) return NULL;
   Py_RETURN_NONE;
 }
@@ -142,8 +160,74 @@ static PyObject* py_eval_errors_backward(PyObject* self, PyObject* const* a, Py_
                                                 copies, g_eps, stream));
 }
 
+/* gn_solve_traced(PREFIX..., max_iters, tol_delta, th_out, iters, err_hist, errext_hist, err_final, info, th_hist, stream) */
+static PyObject* py_gn_solve_traced(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 10, "gn_solve_traced");
+  BOUND(f_gn_solve_traced);
+  BUILD_PREFIX;
+  const int32_t max_iters = (int32_t)I(13);
+  const double tol = PyFloat_AsDouble(a[14]);
+  if (tol == -1.0 && PyErr_Occurred()) return NULL;
+  void *th_out = P(15), *iters = P(16), *eh = P(17), *eeh = P(18), *ef = P(19), *info = P(20), *hist = P(21), *stream = P(22);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_solve_traced(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info,
+                                           (double*)hist, stream));
+}
+
+/* gn_solve_backward(handle, batch, start, goal, sdf_data, sdf_rows, sdf_cols, sdf_batch_stride, max_iters, th_hist, th_out, iters, g_th_out,
+ *                   g_th_init, g_start, g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, stream) */
+static PyObject* py_gn_solve_backward(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(20, "gn_solve_backward");
+  BOUND(f_gn_solve_backward);
+  const DgpHandle* h = (const DgpHandle*)P(0);
+  const int32_t batch = (int32_t)I(1);
+  const void *start = P(2), *goal = P(3);
+  DgpSdf sdf = {P(4), (int32_t)I(5), (int32_t)I(6), I(7)};
+  const int32_t max_iters = (int32_t)I(8);
+  const void *hist = P(9), *th_out = P(10), *iters = P(11), *g_out = P(12);
+  void *g_th = P(13), *g_st = P(14), *g_go = P(15), *g_sdf = P(16);
+  const int64_t g_stride = I(17);
+  const int32_t copies = (int32_t)I(18);
+  void* stream = P(19);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_solve_backward(h, batch, start, goal, sdf.data ? &sdf : NULL, max_iters, (const double*)hist, th_out, (const int32_t*)iters,
+                                             g_out, g_th, g_st, g_go, g_sdf, g_stride, copies, stream));
+}
+
+/* gn_step_errors(PREFIX..., dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs, stream) */
+static PyObject* py_gn_step_errors(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 8, "gn_step_errors");
+  BOUND(f_gn_step_errors);
+  BUILD_PREFIX;
+  void *dth = P(13), *err = P(14), *eex = P(15), *info = P(16), *usg = P(17), *ugp = P(18), *uobs = P(19), *stream = P(20);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_step_errors(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, usg, ugp, uobs, stream));
+}
+
+/* gn_step_errors_backward(PREFIX..., dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
+ *                         g_sdf_copies, g_qc_inv, g_obs_w, g_eps, workspace, stream) */
+static PyObject* py_gn_step_errors_backward(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(PREFIX + 17, "gn_step_errors_backward");
+  BOUND(f_gn_step_errors_backward);
+  BUILD_PREFIX;
+  const void *dth = P(13), *g_dth = P(14), *g_eex = P(15), *g_usg = P(16), *g_ugp = P(17), *g_uobs = P(18);
+  void *g_th = P(19), *g_st = P(20), *g_go = P(21), *g_sdf = P(22);
+  const int64_t g_stride = I(23);
+  const int32_t copies = (int32_t)I(24);
+  void *g_qc = P(25), *g_ow = P(26), *g_eps = P(27), *ws = P(28), *stream = P(29);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_gn_step_errors_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf,
+                                                   g_stride, copies, g_qc, g_ow, g_eps, ws, stream));
+}
+
 static PyMethodDef methods[] = {
-    {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL, "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward): addresses of the C-ABI entry points"},
+    {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL,
+     "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward, gn_solve_traced, gn_solve_backward, gn_step_errors, gn_step_errors_backward): "
+     "addresses of the C-ABI entry points"},
+    {"gn_solve_traced", (PyCFunction)(void (*)(void))py_gn_solve_traced, METH_FASTCALL, "dgp_gn_solve_traced"},
+    {"gn_solve_backward", (PyCFunction)(void (*)(void))py_gn_solve_backward, METH_FASTCALL, "dgp_gn_solve_backward"},
+    {"gn_step_errors", (PyCFunction)(void (*)(void))py_gn_step_errors, METH_FASTCALL, "dgp_gn_step_errors"},
+    {"gn_step_errors_backward", (PyCFunction)(void (*)(void))py_gn_step_errors_backward, METH_FASTCALL, "dgp_gn_step_errors_backward"},
     {"gn_step", (PyCFunction)(void (*)(void))py_gn_step, METH_FASTCALL, "dgp_gn_step"},
     {"gn_solve", (PyCFunction)(void (*)(void))py_gn_solve, METH_FASTCALL, "dgp_gn_solve"},
     {"eval_errors", (PyCFunction)(void (*)(void))py_eval_errors, METH_FASTCALL, "dgp_eval_errors"},

@@ -21,10 +21,10 @@ hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dg
   const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p));
   // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
   static const DgpLaunchFn table[2][2][dgp_dev::NUM_GROUPS] = {
-      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3},
-       {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2, dgp_launch_2_f64_g3}},
-      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2, dgp_launch_3_f32_g3},
-       {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2, dgp_launch_3_f64_g3}}};
+      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3, dgp_launch_2_f32_g4},
+       {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2, dgp_launch_2_f64_g3, dgp_launch_2_f64_g4}},
+      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2, dgp_launch_3_f32_g3, dgp_launch_3_f32_g4},
+       {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2, dgp_launch_3_f64_g3, dgp_launch_3_f64_g4}}};
   const int f64 = h->cfg.io_dtype == DGP_F64 ? 1 : 0;
   return table[h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
 }
@@ -117,6 +117,53 @@ int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th, 
   hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
   if (e != hipSuccess) return fail(DGP_EHIP, "dgp_eval_errors_backward launch failed: %s", hipGetErrorString(e));
   return DGP_OK;
+}
+
+// The round-4 entry points: their host logic (validation, the two launches behind one call) is shared with the test emulator, dgp_host.h
+namespace {
+struct HipLaunch {
+  const DgpHandle* h; hipStream_t s; const char* what;
+  int operator()(int mode, const dgp::GnParams& p, const dgp::GnGradParams* g) const {
+    hipError_t e = launch(h, mode, p, g, s);
+    if (e != hipSuccess) return fail(DGP_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return DGP_OK;
+  }
+};
+}  // namespace
+
+int dgp_gn_solve_traced(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf,
+                        const DgpCovs* covs, int32_t max_iters, double tol_delta, void* th_out, int32_t* iters, void* err_hist,
+                        void* errext_hist, void* err_final, int32_t* info, double* th_hist, void* stream) {
+  int rc = dgp_host::gn_solve_traced(h, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist, errext_hist, err_final, info,
+                                     th_hist, HipLaunch{h, (hipStream_t)stream, "dgp_gn_solve_traced"});
+  return rc == DGP_OK ? rc : drop_events(rc);
+}
+
+int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch, const void* start, const void* goal, const DgpSdf* sdf, int32_t max_iters,
+                          const double* th_hist, const void* th_out, const int32_t* iters, const void* g_th_out, void* g_th_init, void* g_start,
+                          void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* stream) {
+  int rc = dgp_host::gn_solve_backward(h, batch, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, g_th_init, g_start, g_goal, g_sdf,
+                                       g_sdf_batch_stride, g_sdf_copies, HipLaunch{h, (hipStream_t)stream, "dgp_gn_solve_backward"});
+  return rc == DGP_OK ? rc : drop_events(rc);
+}
+
+int dgp_gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                       const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void* unw_sg, void* unw_gp, void* unw_obs,
+                       void* stream) {
+  int rc = dgp_host::gn_step_errors(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs,
+                                    HipLaunch{h, (hipStream_t)stream, "dgp_gn_step_errors"});
+  return rc == DGP_OK ? rc : drop_events(rc);
+}
+
+int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                                const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, const void* g_unw_sg,
+                                const void* g_unw_gp, const void* g_unw_obs, void* g_th, void* g_start, void* g_goal, void* g_sdf,
+                                int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace,
+                                void* stream) {
+  int rc = dgp_host::gn_step_errors_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start,
+                                             g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, workspace,
+                                             HipLaunch{h, (hipStream_t)stream, "dgp_gn_step_errors_backward"});
+  return rc == DGP_OK ? rc : drop_events(rc);
 }
 
 // Event helpers for dgp_time_next_launch: created / read through the HIP runtime THIS library is linked against (an event made by

@@ -28,6 +28,15 @@ struct GnGradParams {
   void *g_th, *g_start, *g_goal, *g_sdf, *g_qc, *g_obs_w, *g_eps;
   int64_t g_sdf_bstride;
   int32_t g_sdf_copies;              // > 1: per-XCD partial grids of a shared SDF gradient (see include/dgpmp2_hip.h)
+  // round 4 -- dgp_gn_step_errors_backward: the step's backward launched behind the errors' backward at th + dtheta
+  int32_t accumulate;                // 1: g_start / g_goal / g_eps already hold the first launch's share -- add to them instead of overwriting
+  const void* g_th_new;              // (B,n,d) or null: gradient w.r.t. th + dtheta left by the first launch; added to the dtheta cotangent AND to g_th
+  const void* th_addend;             // (B,n,d) or null: evaluate at th + th_addend (the errors' backward of dgp_gn_step_errors_backward: th_addend = dtheta)
+  // round 4 -- dgp_gn_solve_backward (chain kernels): the fused loop's trajectory history and iteration counts
+  const double* th_hist;             // (max_iters,B,n,d) fp64: th_k of every iteration the forward loop ran (dgp_gn_solve's th_hist)
+  const void* th_final;              // (B,n,d): th_out of the forward loop
+  const int32_t* iters;              // (B): iterations each trajectory ran
+  int32_t chain_iters, pad_;         // rows of th_hist (max_iters of the forward call)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -80,7 +89,14 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
     }
 }
 
-template <int DOF, int LPT, int C, typename IO, int QK, typename Ctx>
+// CHAIN = false: the backward of ONE Gauss-Newton step (dgp_gn_step_backward, dgp_eval_errors_backward).
+// CHAIN = true : the backward of the fused loop (dgp_gn_solve_backward): th_{k+1} = th_k + dtheta(th_k), k = 0 .. iters[b]-1, reversed inside the
+//   kernel -- the running cotangent g (gradient w.r.t. th_{k+1}) stays in registers, every pass re-assembles Lambda(th_k) from the forward loop's
+//   history (fp64 whatever the I/O type, so that dtheta_k = th_{k+1} - th_k is exact to rounding), solves the adjoint system, applies the per-factor
+//   chain rule, g += J_k^T g; the start / goal gradients accumulate in registers, the grid gradient is scattered pass by pass.  Static covariances
+//   only (what DiffGPMP2Planner.forward's fused path runs); a trajectory that stopped early sits out the passes it did not run (zero cotangent on
+//   its final trajectory: the adjoint of a zero right-hand side is exactly zero).
+template <int DOF, int LPT, int C, typename IO, int QK, bool CHAIN = false, typename Ctx>
 DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, Ctx& cx) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;
@@ -101,7 +117,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   // d = 4: a fully populated wavefront block whose length fills the shape moves its row tensors (th, the dtheta cotangent, dtheta in;
   // g_th out) as full cache lines through the LDS staging block, as the forward step does (load / store_rows_through_lds; the output
   // write-through) instead of 16 bytes per lane at a 64-byte stride.  Wave-uniform.
-  constexpr bool kBlockRows = WaveStore<IO, C, D>::kUsable && LPT != 32 && DOF == 2;
+  constexpr bool kBlockRows = WaveStore<IO, C, D>::kUsable && LPT != 32 && DOF == 2 && !CHAIN;
   bool block_rows = false;
   if constexpr (kBlockRows) block_rows = vec && n == LPT * C && ((int64_t)cx.wave() + 1) * TPW <= (int64_t)p.B;
   const int64_t wave_first_elem = (int64_t)cx.wave() * TPW * n * D;
@@ -112,7 +128,17 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       load_lane_rows<DOF, C, IO>(p, src, b, g0, traj_ok, vec, dst);
     }
   };
-  load_rows(p.th, x);
+  if constexpr (!CHAIN) {
+    load_rows(p.th, x);
+    if (gp.th_addend) {             // wave-uniform: the point is th + dtheta, summed in the I/O type as torch forms th_curr_b + dthetab
+      double dq[C][D];
+      load_rows(gp.th_addend, dq);
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)x[k][a] + (IO)dq[k][a]);
+    }
+  }
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
@@ -121,19 +147,89 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
     for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
   if (gp.g_dtheta) load_rows(gp.g_dtheta, gbar);
-  LaneQ<D, C, QK> lq;              // generic covariances: Q^-1 of the lane's C + 1 GP factors, shared by the adjoint solve and the chain rule
-  load_lane_Q<DOF, C, IO>(p, b, g0, traj_ok, lq);
-  // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
-  if (gp.g_dtheta) {
-    ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
-    SpdCheck<Ctx> ok = {&cx, 0};
-    if constexpr (is_wb(QK)) {
-      static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-      gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR), false, WbParks<DOF, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, gbar, lam, acc, ok, &wbv, [](const ErrAcc&) {});
-    } else {
-      gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, gbar, lam, acc, ok);
+  // dgp_gn_step_errors_backward: the gradient w.r.t. th + dtheta that the errors' backward left behind joins the dtheta cotangent
+  // (th + dtheta depends on dtheta with a unit Jacobian) and, further down, the trajectory gradient (and on th likewise)
+  double gnew[(!CHAIN) ? C : 1][D];
+  if constexpr (!CHAIN) {
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) gnew[k][a] = 0.0;
+    if (gp.g_th_new) {              // wave-uniform
+      load_rows(gp.g_th_new, gnew);
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) gbar[k][a] += gnew[k][a];
     }
   }
+  const bool have_gbar = gp.g_dtheta != nullptr || (!CHAIN && gp.g_th_new != nullptr);
+  LaneQ<D, C, QK> lq;              // generic covariances: Q^-1 of the lane's C + 1 GP factors, shared by the adjoint solve and the chain rule
+  load_lane_Q<DOF, C, IO>(p, b, g0, traj_ok, lq);
+  // ---- CHAIN: running cotangent (starts as the cotangent of th_final, loaded into gbar above), accumulated mean gradients, pass count
+  double gacc_s[CHAIN ? D : 1], gacc_g[CHAIN ? D : 1];
+  int my_iters = 0, passes = 1;
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int a = 0; a < D; ++a) { gacc_s[a] = 0.0; gacc_g[a] = 0.0; }
+    my_iters = traj_ok ? gp.iters[b] : 0;
+    int mx = my_iters;                                     // passes = the most iterations any trajectory of this wavefront ran
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const int o = cx.fetch_i(mx, lane ^ m); mx = o > mx ? o : mx; }
+    passes = mx;
+  }
+  bool first_pass = true;
+#pragma unroll 1
+  for (int it = passes - 1; it >= 0; --it) {
+  bool pass_on = true;             // CHAIN: did this trajectory run iteration `it`
+  double xnext[CHAIN ? C : 1][D];
+  if constexpr (CHAIN) {
+    pass_on = it < my_iters;
+    // th_it (the history; a trajectory that sits this pass out reads its FINAL trajectory instead: valid data, and its cotangent is zeroed below)
+    // and th_{it+1} (the next history row, or th_final behind the last iteration)
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const bool valid = traj_ok && g0 + k < n;
+      const int64_t row = valid ? b * n + g0 + k : 0;
+      const double* h0 = gp.th_hist + ((int64_t)it * p.B * n + row) * D;
+      const double* h1 = gp.th_hist + ((int64_t)(it + 1) * p.B * n + row) * D;
+      double fin[D];
+      ld_row<IO, D>(gp.th_final, row, vec, fin);
+      const bool last = it + 1 >= my_iters;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double v0 = pass_on ? h0[a] : fin[a];
+        const double v1 = (pass_on && !last) ? h1[a] : fin[a];
+        x[k][a] = valid ? v0 : 0.0;
+        xnext[k][a] = valid ? v1 : 0.0;
+      }
+    }
+  }
+  // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
+  if (have_gbar) {
+    ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+    SpdCheck<Ctx> ok = {&cx, 0};
+    auto solve = [&](const double (&rhs)[C][D]) {
+      if constexpr (is_wb(QK)) {
+        static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
+        gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR), false, WbParks<DOF, MODE_BACKWARD_SOLVE>::value>(
+            p, cx, b, j, traj_ok, x, mu_s, mu_g, rhs, lam, acc, ok, first_pass ? &wbv : nullptr, [](const ErrAcc&) {});
+      } else {
+        gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, rhs, lam, acc, ok);
+      }
+    };
+    if constexpr (CHAIN) {
+      double rhs[C][D];            // a trajectory that did not run iteration `it` contributes nothing: zero right-hand side, lambda == 0 exactly
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) rhs[k][a] = pass_on ? gbar[k][a] : 0.0;
+      solve(rhs);
+    } else {
+      solve(gbar);
+    }
+  }
+  first_pass = false;
   const double ebar = (traj_ok && gp.g_err_ext) ? ld<IO>(gp.g_err_ext, b) / p.M : 0.0;      // d L / d (M err_ext)
   // cotangents of the unweighted errors (dgp_eval_errors_backward): start_goal_error = 1/2 |mu_s - x_0|^2 + 1/2 |mu_g - x_{n-1}|^2
   // (plan_layer.py:384-388), gp_error = mean over the n-1 factors of 1/2 |e|^2 (:374-377), obs_error = mean over the n states of
@@ -160,7 +256,14 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   for (int k = 0; k < C; ++k)
 #pragma unroll
     for (int a = 0; a < D; ++a) dthr[k][a] = 0.0;
-  if (gp.g_dtheta) load_rows(gp.dtheta, dthr);
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) dthr[k][a] = xnext[k][a] - x[k][a];      // dtheta_it = th_{it+1} - th_it (zero for a trajectory that sits the pass out)
+  } else {
+    if (have_gbar) load_rows(gp.dtheta, dthr);
+  }
 #pragma unroll
   for (int a = 0; a < D; ++a) dth_next[a] = nb.hi(dthr[0][a]);
   LaneTaps<C, IO> taps;
@@ -201,7 +304,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         const double ea = (is_start ? mu_s[a] : mu_g[a]) - xk[a];
         const double t = w * (lk[a] + ebar * ea) + gsg * ea;
         gx[a] -= t;
-        if (gmu) st<IO>(gmu, b * D + a, t);
+        if constexpr (CHAIN) {
+          if (is_start) gacc_s[a] += t; else gacc_g[a] += t;
+        } else {
+          if (gmu) st<IO>(gmu, b * D + a, gp.accumulate ? t + ld<IO>(gmu, b * D + a) : t);
+        }
       }
     }
     // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
@@ -289,7 +396,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
     // ---- obstacle factor: e = c, H = [hx, hy, 0..], K = omega
     if (!has_grid) {
-      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, 0.0);
+      if (gp.g_eps && !gp.accumulate) st<IO>(gp.g_eps, b * n + g, 0.0);
       if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, 0.0);
     } else {
       const double w = taps.ow[k];
@@ -321,7 +428,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
           tap_i[k][3] = (int32_t)tp.i22; tap_v[k][3] = (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd);
         }
       }
-      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
+      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, gp.accumulate ? g_eps + ld<IO>(gp.g_eps, b * n + g) : g_eps);
       if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, g_w);
     }
     // ---- velocity limits: e = |v| - vmax, H = -sign(v) (piecewise constant), K = w_v
@@ -356,7 +463,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       gx[DOF] += a2 * cs + ae * (-sn);                             // d/dvx: h2 -> cos, e -> -sin
       gx[DOF + 1] += a2 * (-sn) + ae * cs;                         // d/dvy: h2 -> -sin, e -> cos
     }
-    if (gp.g_th) {
+    if constexpr (CHAIN) {
+      // g_{th_it} = g_{th_{it+1}} + J_it^T g_{th_{it+1}}  (th_{it+1} = th_it + dtheta(th_it)); nothing to add for a pass the trajectory sat out
+#pragma unroll
+      for (int a = 0; a < D; ++a) gbar[k][a] += pass_on ? gx[a] : 0.0;
+    } else if (gp.g_th) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) gx[a] += gnew[k][a];                 // (zero unless dgp_gn_step_errors_backward passed the errors' share)
       if (block_rows) {
         if constexpr (kBlockRows) {
 #pragma unroll
@@ -376,6 +489,23 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
   }
   if (gp.g_sdf) sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);      // wave-uniform
+  }  // passes (one unless CHAIN)
+  if constexpr (CHAIN) {
+    // gradient w.r.t. the INITIAL trajectory, and the start / goal means' gradients summed over the passes
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      const int g = g0 + k;
+      if (traj_ok && g < n && gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gbar[k]);
+    }
+    if (traj_ok && g0 == 0 && gp.g_start) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) st<IO>(gp.g_start, b * D + a, gacc_s[a]);
+    }
+    if (traj_ok && g0 <= n - 1 && n - 1 < g0 + C && gp.g_goal) {
+#pragma unroll
+      for (int a = 0; a < D; ++a) st<IO>(gp.g_goal, b * D + a, gacc_g[a]);
+    }
+  }
 }
 
 }  // namespace dgp

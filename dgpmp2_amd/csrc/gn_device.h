@@ -155,11 +155,11 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
-template <int DOF, int LPT, int C, typename IO, int QK>
+template <int DOF, int LPT, int C, typename IO, int QK, bool CHAIN = false>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_arg, const dgp::GnGradParams g_arg) {
   // d = 4 static-covariance kernels: both argument structs read through the laundered pointer, as the fused loop does (static backward 15.0 -> 14.6 us;
   // the per-state kernel gets slower that way, 19.4 -> 19.7 us, and d = 6 was not measured: both keep the by-value reads)
-  constexpr bool kLaunder = DOF == 2 && (dgp::is_wb(QK) || QK == dgp::QK_STATIC);
+  constexpr bool kLaunder = DOF == 2 && (dgp::is_wb(QK) || QK == dgp::QK_STATIC) && !CHAIN;
   constexpr int kGOff = (int)sizeof(dgp::GnParams);                          // GnGradParams follows GnParams (both 8-byte aligned)
   static_assert(sizeof(dgp::GnParams) % 8 == 0 && alignof(dgp::GnGradParams) <= 8, "argument layout");
   const dgp::GnParams* pp = &p_arg;
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_a
   cx.lds_ = lds;
   cx.stash_ = lds;
   cx.wb_ = lds + kAll;
-  dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK>(p, g, cx);
+  dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK, CHAIN>(p, g, cx);
 }
 
 // Long trajectories (n > 256, gn_long.h): one trajectory per wavefront, rows per lane a runtime value, dynamic LDS.
@@ -212,14 +212,15 @@ __global__ void __launch_bounds__(64) gn_long_backward_kernel(const dgp::GnParam
 #define DGP_FOR_EACH_SHAPE(X) X(16, 1) X(32, 1) X(64, 1) X(16, 2) X(32, 2) X(64, 2) X(16, 4) X(32, 4) X(64, 4)
 
 // mode: dgp::MODE_* or MODE_BACKWARD
-enum { MODE_BACKWARD = 3 };
+enum { MODE_BACKWARD = 3, MODE_CHAIN = 4 };      // MODE_CHAIN: dgp_gn_solve_backward (the chain kernels, static covariances)
 
 // The kernels are spread over translation units (gn_inst.hip, one per (dof, io dtype, group)) so that they build in
 // parallel.  Group of a launch: static-covariance STEP / SOLVE; the general-covariance STEP / SOLVE plus EVAL; the static and
 // general backward kernels; everything for per-state Q_c^-1 tensors (QK_KRON: STEP, SOLVE, backward).
-enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, GROUP_KRON = 3, NUM_GROUPS = 4 };
+enum { GROUP_STATIC = 0, GROUP_GENERIC = 1, GROUP_BACKWARD = 2, GROUP_KRON = 3, GROUP_CHAIN = 4, NUM_GROUPS = 5 };
 inline int launch_group(int mode, const dgp::GnParams& p) {
   if (mode == dgp::MODE_EVAL) return GROUP_GENERIC;
+  if (mode == MODE_CHAIN) return GROUP_CHAIN;
   const int qk = dgp::kernel_variant(p);
   if (qk == dgp::QK_KRON) return GROUP_KRON;
   if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
@@ -268,6 +269,16 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));                \
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));         \
       else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                       \
+    } else if constexpr (GROUP == GROUP_CHAIN) {                                                                           \
+      if (!qstat) return hipErrorInvalidValue;                                                                             \
+      if constexpr (CC == 4) {                                                                                             \
+        if (dgp::wb_applies(p, L, CC)) {                                                                                   \
+          if (p.n == L * CC) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB, true>));                       \
+          else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WBR, true>));                                    \
+          return hipGetLastError();                                                                                        \
+        }                                                                                                                  \
+      }                                                                                                                    \
+      DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_STATIC, true>));                                          \
     } else if constexpr (GROUP == GROUP_KRON) {                                                                            \
       if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_KRON>));                   \
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));            \
@@ -300,7 +311,8 @@ typedef hipError_t (*DgpLaunchFn)(DgpShape, int, const dgp::GnParams&, const dgp
   hipError_t dgp_launch_##d##_##t##_g0(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
   hipError_t dgp_launch_##d##_##t##_g1(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
   hipError_t dgp_launch_##d##_##t##_g2(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
-  hipError_t dgp_launch_##d##_##t##_g3(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
+  hipError_t dgp_launch_##d##_##t##_g3(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
+  hipError_t dgp_launch_##d##_##t##_g4(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
 DGP_DECL_INST(2, f32) DGP_DECL_INST(2, f64) DGP_DECL_INST(3, f32) DGP_DECL_INST(3, f64)
 #undef DGP_DECL_INST
 // gn_long_inst.hip: the long-trajectory kernels of every (dof, io dtype); mode: dgp::MODE_* or dgp_dev::MODE_BACKWARD

@@ -2907,6 +2907,14 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
 
   if (MODE == MODE_EVAL) {
     ErrAcc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (p.dtheta) {               // wave-uniform.  dgp_gn_step_errors: the errors at th + dtheta (learning/train_planner.py:313,327), the sum formed in the
+      double dq[C][D];            // I/O type exactly as torch forms th_curr_b + dthetab before it hands the result to unweighted_errors_batch
+      load_lane_rows<DOF, C, IO>(p, p.dtheta, b, j * C, traj_ok, vec, dq);
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)x[k][a] + (IO)dq[k][a]);
+    }
     gn_eval_only<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, x, mu_s, mu_g, acc);
     const double e = group_sum_to_first<LPT>(cx, acc.e), ee = group_sum_to_first<LPT>(cx, acc.eext);
     const double usg = group_sum_to_first<LPT>(cx, acc.usg), ugp = group_sum_to_first<LPT>(cx, acc.ugp);
@@ -2938,6 +2946,22 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
     double dx[C][D];
     if constexpr (MODE == MODE_SOLVE && (DGP_SOLVE_OPAQUE_Q == 1 || DGP_SOLVE_OPAQUE_Q == D)) lane_q_opaque<D, C>(lq);
     if constexpr (kPark) lds_get_rows<C, D>(cx, x);       // the state comes back from LDS
+    if constexpr (MODE == MODE_SOLVE) {
+      // dgp_gn_solve's optional trajectory history (what dgp_gn_solve_backward re-assembles the passes from): th_it in fp64 whatever the I/O type,
+      // row (it, b, g).  The pointer travels in GnParams::dtheta, which the fused loop does not otherwise use.  Wave-uniform test.
+      if (p.dtheta) {
+        double* hist = (double*)p.dtheta;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const int g = j * C + k;
+          if (active && g < n) {
+            double* row = hist + (((int64_t)it * p.B + b) * n + g) * D;
+#pragma unroll
+            for (int a = 0; a < D; ++a) row[a] = x[k][a];
+          }
+        }
+      }
+    }
     double e = 0.0, ee = 0.0;
     auto before_pcr = [&](const ErrAcc& a) {
       e = group_sum_to_first<LPT>(cx, a.e); ee = group_sum_to_first<LPT>(cx, a.eext);

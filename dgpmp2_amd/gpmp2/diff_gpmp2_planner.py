@@ -7,8 +7,9 @@ examples/diff_gpmp2_*) run unchanged on top of the HIP solver.
   forward() -> the reference loops over samples and iterates each to convergence in Python
                (diff_gpmp2_planner.py:104-156); here the whole batch runs in ONE launch of the fused multi-iteration
                kernel (dgp_gn_solve), every trajectory with its own convergence test, when no autograd graph is needed;
-               with requires_grad inputs it falls back to chained differentiable step() calls (the reference keeps the
-               graph across iterations, examples/diff_gpmp2_2d_example.py:77), still batched.
+               with requires_grad inputs (the reference keeps the graph across iterations, examples/diff_gpmp2_2d_example.py:77)
+               the same launch also records the trajectory history and the backward pass is ONE more launch (dgp_gn_solve_backward);
+               learn modules, a plan_time limit, a non-diagonal Q_c_inv or more than 256 states chain differentiable step() calls.
 
 The learned-covariance modules (LearnModuleConv / LearnModuleFCN, stock torch.nn in the reference) are out of this
 build's scope: pass your own modules as `learn_module_conv` / `learn_module_fcn`; get_covariances() (the plumbing between
@@ -19,7 +20,7 @@ import time
 import torch
 import torch.nn as nn
 
-from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC
+from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC, _GNSolve
 from ..utils.planner_utils import check_convergence
 
 
@@ -191,20 +192,25 @@ class DiffGPMP2Planner(nn.Module):
     return qc, obscov, eps, hidden
 
   # -- reference API --------------------------------------------------------------------------------------
-  def step(self, th_currb, startb, goalb, imb, sdfb, conv_out=None, dtheta_currb=None, hiddenb=None):
-    """One iteration of non-linear optimisation on a batch of environments (diff_gpmp2_planner.py:176-211).
-    -> (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr)"""
-    B = th_currb.shape[0]
-    hidden = None
-    pl = self.__dict__['_pl']
+  def _step_covariances(self, th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb):
+    """The covariance inputs of one step (diff_gpmp2_planner.py:183-205): predicted by the learn modules, or the static ones."""
     if self.__dict__['_learned']:
       im_in = None
       if not self.fixed_conv:
         im_in = torch.cat((imb, sdfb), dim=1) if self.sdf_predict else imb
       th_in = torch.cat((th_currb, dtheta_currb), dim=-1) if self.use_dtheta else th_currb
-      qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._predict(th_in, conv_out, hiddenb, im_in)
+      return self._predict(th_in, conv_out, hiddenb, im_in)
+    return self._static_covs(th_currb.shape[0], th_currb) + (None,)
+
+  def step(self, th_currb, startb, goalb, imb, sdfb, conv_out=None, dtheta_currb=None, hiddenb=None):
+    """One iteration of non-linear optimisation on a batch of environments (diff_gpmp2_planner.py:176-211).
+    -> (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr)"""
+    pl = self.__dict__['_pl']
+    if self.__dict__['_learned']:
+      qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb)
     else:
-      qc_inv_curr, obscov_inv_curr, eps_curr = self._static_covs(B, th_currb)
+      hidden = None
+      qc_inv_curr, obscov_inv_curr, eps_curr = self._static_covs(th_currb.shape[0], th_currb)
     # (nn.Module.__call__ costs ~2 us of hook bookkeeping per call; without hooks it does nothing but call forward())
     if pl._forward_hooks or pl._forward_pre_hooks or pl._backward_hooks or pl._backward_pre_hooks or _global_module_hooks():
       dthetab, err_oldb, err_ext_oldb = pl(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
@@ -212,6 +218,18 @@ class DiffGPMP2Planner(nn.Module):
       dthetab, err_oldb, err_ext_oldb = pl.forward(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
     hidden_newb = hidden if hiddenb is not None else None
     return dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr
+
+  def step_with_errors(self, th_currb, startb, goalb, imb, sdfb, conv_out=None, dtheta_currb=None, hiddenb=None):
+    """step() and, in the same call, unweighted_errors_batch(th_currb + dthetab, sdfb) -- what every iteration of the reference's training
+    loop does back to back (learning/train_planner.py:311,313,327).  -> (step()'s 7-tuple, (err_sg (B,1), err_gp (B,1,1), err_obs (B,1,1)));
+    one C-ABI call forward, one backward (PlanLayer.forward_with_errors).  No counterpart in the reference: an addition for its outer loop,
+        out, (err_sg, err_gp, err_obs) = planner.step_with_errors(th, start, goal, im, sdf, conv_out, dtheta)
+    replacing  out = planner.step(...); err_sg, err_gp, err_obs = planner.unweighted_errors_batch(th + out[0], sdf)."""
+    qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb)
+    dthetab, err_oldb, err_ext_oldb, e_sg, e_gp, e_obs = self.__dict__['_pl'].forward_with_errors(th_currb, startb, goalb, imb, sdfb, qc_inv_curr,
+                                                                                                 obscov_inv_curr, eps_curr)
+    hidden_newb = hidden if hiddenb is not None else None
+    return (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr), (e_sg, e_gp, e_obs)
 
   def forward(self, th_initb, startb, goalb, imb, sdfb, hiddenb=None):
     """Gauss-Newton to convergence for every sample (diff_gpmp2_planner.py:92-174).
@@ -223,29 +241,49 @@ class DiffGPMP2Planner(nn.Module):
     tol_delta = float(self.optim_params['tol_delta'])
     plan_time = float(self.optim_params['plan_time']) if 'plan_time' in self.optim_params else float('inf')
     needs_graph = torch.is_grad_enabled() and any(t.requires_grad for t in (th_initb, startb, goalb, sdfb))
-    if self.learn_module_fcn is None and not needs_graph and plan_time == float('inf'):
-      return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t)
+    if self.learn_module_fcn is None and plan_time == float('inf'):
+      if not needs_graph:
+        return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t)
+      if self._chain_backward_available():
+        return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t, with_graph=True)
     return self._forward_stepwise(th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t)
 
-  def _forward_fused(self, th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t):
+  def _chain_backward_available(self):
+    """dgp_gn_solve_backward covers static covariances with a diagonal Q_c_inv and trajectories of up to 256 states; anything else
+    differentiates through chained step() calls (_forward_stepwise)."""
+    q = self.plan_layer._qc_rows
+    diag = all(q[i][j] == 0.0 for i in range(len(q)) for j in range(len(q)) if i != j)
+    return diag and self.num_traj_states <= 256
+
+  def _forward_fused(self, th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t, with_graph=False):
+    """The whole batch in ONE launch of the fused loop.  with_graph: th_currb carries the autograd graph of the loop (w.r.t. th_initb, startb,
+    goalb, sdfb) as ONE node whose backward is one more launch (_GNSolve: dgp_gn_solve_traced / dgp_gn_solve_backward)."""
     pl = self.plan_layer
     pl._check_inputs(th_initb, startb, goalb)
     B = th_initb.shape[0]
     dt, dev = th_initb.dtype, th_initb.device
     solver = pl._solver(dt)
     idx = th_initb.get_device()
-    sd = pl._sdf_args(sdfb, dt, B, idx)
-    th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
-    th_out = torch.empty_like(th0)
-    # the per-sample outputs share ONE device buffer -- err history | err_ext history | final error | iteration counts -- so that one fill (NaN: entries
-    # past a sample's last iteration stay untouched) and ONE device-to-host copy serve all four (each separate copy costs a synchronisation of its own)
     m = max_iters
-    buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dt, device=dev)
-    eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
-    iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts in the last B elements' storage
-    info = torch.empty(B, dtype=torch.int32, device=dev)
-    _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
-            max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
+    if with_graph:
+      ts = (th_initb, startb, goalb, sdfb)
+      slots = tuple([i for i in range(4) if ts[i] is not None and ts[i].requires_grad])
+      box = []
+      th_out = _GNSolve.apply(pl, max_iters, tol_delta, slots, ts, box, *[ts[i] for i in slots])
+      buf, info = box[0]
+      st, go = startb, goalb
+    else:
+      sd = pl._sdf_args(sdfb, dt, B, idx)
+      th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
+      th_out = torch.empty_like(th0)
+      # the per-sample outputs share ONE device buffer -- err history | err_ext history | final error | iteration counts -- so that one fill (NaN: entries
+      # past a sample's last iteration stay untouched) and ONE device-to-host copy serve all four (each separate copy costs a synchronisation of its own)
+      buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dt, device=dev)
+      eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
+      iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts in the last B elements' storage
+      info = torch.empty(B, dtype=torch.int32, device=dev)
+      _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
+              max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
     pl.last_info = info
     pl._last = (st, go, None, None, None)
     host = buf.cpu()                                # synchronises

@@ -253,6 +253,171 @@ def _finish_sdf_grad(g, sdf, shared):
   return g if g.dtype is sdf.dtype else g.to(sdf.dtype)
 
 
+class _GNStepErrors(torch.autograd.Function):
+  """One iteration of the reference's training loop as ONE autograd node (learning/train_planner.py:311-327): dtheta, err, err_ext of the
+  step AND the three unweighted errors at th + dtheta -- forward = dgp_gn_step_errors, backward = dgp_gn_step_errors_backward (each two
+  stream-ordered launches behind one C-ABI call; no th + dtheta tensor, no second Function.apply, no second trip through the autograd engine)."""
+
+  @staticmethod
+  def launch(layer, static, th, start, goal, sdf, qc, ow, eps, own_info=False):
+    B = th.shape[0]
+    dtype = th.dtype
+    solver = layer._solvers.get(dtype) or layer._solver(dtype)
+    dev = th.get_device()
+    if start.get_device() != dev or goal.get_device() != dev:
+      _same_device(dev, startb=start, goalb=goal)
+    sd = layer._sdf_args(sdf, dtype, B, dev)
+    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static)
+    thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
+    dth = torch.empty_like(thc)
+    proto = layer._err_protos.get((B, dtype, dev))
+    if proto is None: proto = layer._err_proto(B, dtype, dev, thc)
+    err, eex, usg, ugp, uobs = (torch.empty_like(proto) for _ in range(5))
+    stream = _raw_stream(dev)
+    info = layer._info_buffer(B, dev, stream, thc)
+    if own_info or layer.check_spd: info = torch.empty_like(info)
+    _launch(dev, layer._pc.gn_step_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), usg.data_ptr(), ugp.data_ptr(),
+            uobs.data_ptr(), stream)
+    layer.__dict__['last_info'] = info
+    if layer.check_spd and bool(info.any()):
+      raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
+                         '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
+    return dth, err, eex, usg, ugp, uobs, (thc, stc, goc), (sd, cv)
+
+  @staticmethod
+  def forward(ctx, layer, static, slots, ts, box, *diff):
+    th, start, goal, sdf, qc, ow, eps = ts
+    dth, err, eex, usg, ugp, uobs, (thc, stc, goc), args = _GNStepErrors.launch(layer, static, th, start, goal, sdf, qc, ow, eps, True)
+    box.append(err)
+    ctx.layer, ctx.slots, ctx.args = layer, slots, args
+    ctx.inputs = (thc, stc, goc, sdf, qc, ow, eps, start, goal)
+    ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, -1 if qc is None else qc._version,
+                    -1 if ow is None else ow._version, -1 if eps is None else eps._version)
+    ctx.save_for_backward(dth)
+    ctx.set_materialize_grads(False)
+    return dth, eex, usg, ugp, uobs
+
+  @staticmethod
+  def backward(ctx, g_dth, g_eex, g_usg, g_ugp, g_uobs):
+    if torch.is_grad_enabled():
+      return _GNStepErrors._backward_once(ctx, g_dth, g_eex, g_usg, g_ugp, g_uobs)
+    return _GNStepErrors._backward_impl(ctx, g_dth, g_eex, g_usg, g_ugp, g_uobs)
+
+  @staticmethod
+  def _backward_impl(ctx, g_dth, g_eex, g_usg, g_ugp, g_uobs):
+    layer = ctx.layer
+    dth, = ctx.saved_tensors
+    th, stc, goc, sdf, qc, ow, eps, start, goal = ctx.inputs
+    _check_versions(ctx.inputs, ctx.versions)
+    sd, cv = ctx.args
+    B, n, d = th.shape
+    dtype = th.dtype
+    solver = layer._solvers[dtype]
+    dev = th.get_device()
+    slots = ctx.slots
+    nig = ctx.needs_input_grad                    # (layer, static, slots, ts, box, *diff)
+    need = [False] * 9
+    for q, i in enumerate(slots): need[2 + i] = nig[5 + q]
+    fix = lambda g: g if (g is None or (g.dtype is dtype and g.is_contiguous())) else g.contiguous().to(dtype)
+    g_dth, g_eex, g_usg, g_ugp, g_uobs = fix(g_dth), fix(g_eex), fix(g_usg), fix(g_ugp), fix(g_uobs)
+    g_th = torch.empty_like(th) if need[2] else None
+    g_st = _grad_like(start, stc) if need[3] else None
+    g_go = _grad_like(goal, goc) if need[4] else None
+    shared = sd[3] == 0
+    g_sdf, copies, g_stride = None, 1, 0
+    if need[5]:
+      H, W = sd[1], sd[2]
+      copies = _SDF_GRAD_COPIES if shared else 1
+      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
+      g_stride = 0 if shared else H * W
+    g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
+    g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
+    g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
+    ws = torch.empty_like(th) if (g_usg is not None or g_ugp is not None or g_uobs is not None) else None      # dL/d(th + dtheta) between the two launches
+    _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
+            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
+            _ptr(g_go), _ptr(g_sdf), g_stride, copies, _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _ptr(ws), _raw_stream(dev))
+    if g_sdf is not None:
+      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
+    return (None, None, None, None, None) + tuple(grads[i] for i in slots)
+
+
+_GNStepErrors._backward_once = staticmethod(once_differentiable(_GNStepErrors._backward_impl))
+
+
+class _GNSolve(torch.autograd.Function):
+  """The whole Gauss-Newton loop of DiffGPMP2Planner.forward as ONE autograd node: forward = dgp_gn_solve_traced (the fused loop, keeping the
+  fp64 history of the trajectory), backward = dgp_gn_solve_backward (one launch that walks the iterations backwards per trajectory).  The
+  reference keeps the graph across its python loop (diff_gpmp2_planner.py:122-156); K iterations there are K x (dense solve + 2 error
+  evaluations) nodes, here two launches whatever K is."""
+
+  @staticmethod
+  def forward(ctx, layer, max_iters, tol_delta, slots, ts, box, *diff):
+    """ts = (th_init, start, goal, sdf); box receives (iters, err_hist, errext_hist, err_final, info) -- none of them differentiable
+    (forward() returns the errors as python floats, :138-141,162-164)."""
+    th, start, goal, sdf = ts
+    B, n, d = th.shape
+    dtype = th.dtype
+    solver = layer._solvers.get(dtype) or layer._solver(dtype)
+    dev = th.get_device()
+    sd = layer._sdf_args(sdf, dtype, B, dev)
+    thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
+    th_out = torch.empty_like(thc)
+    m = max_iters
+    buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dtype, device=th.device)
+    eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
+    iters = buf[2 * B * m + B:].view(torch.int32)[:B]
+    info = torch.empty(B, dtype=torch.int32, device=th.device)
+    hist = torch.empty((m, B, n, d), dtype=torch.float64, device=th.device)      # th_k, fp64 whatever the I/O type (rows past iters[b] stay unwritten and unread)
+    _launch(dev, layer._pc.gn_solve_traced, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
+            max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), hist.data_ptr(),
+            _raw_stream(dev))
+    box.append((buf, info))
+    ctx.layer, ctx.slots, ctx.max_iters = layer, slots, max_iters
+    ctx.args = sd
+    ctx.inputs = (stc, goc, sdf, start, goal, thc)
+    ctx.versions = (stc._version, goc._version, -1 if sdf is None else sdf._version)
+    ctx.hist, ctx.iters = hist, iters               # (work buffers of this node, never handed out: plain references)
+    ctx.save_for_backward(th_out)
+    return th_out
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, g_out):
+    layer = ctx.layer
+    th_out, = ctx.saved_tensors
+    stc, goc, sdf, start, goal, thc = ctx.inputs
+    _check_versions(ctx.inputs[:3], ctx.versions)
+    sd = ctx.args
+    B, n, d = th_out.shape
+    dtype = th_out.dtype
+    solver = layer._solvers[dtype]
+    dev = th_out.get_device()
+    nig = ctx.needs_input_grad                    # (layer, max_iters, tol_delta, slots, ts, box, *diff)
+    need = [False] * 4
+    for q, i in enumerate(ctx.slots): need[i] = nig[6 + q]
+    if g_out.dtype is not dtype or not g_out.is_contiguous(): g_out = g_out.contiguous().to(dtype)
+    g_th = torch.empty_like(th_out) if need[0] else None
+    g_st = _grad_like(start, stc) if need[1] else None
+    g_go = _grad_like(goal, goc) if need[2] else None
+    shared = sd[3] == 0
+    g_sdf, copies, g_stride = None, 1, 0
+    if need[3]:
+      H, W = sd[1], sd[2]
+      copies = _SDF_GRAD_COPIES if shared else 1
+      g_sdf = th_out.new_zeros((copies if shared else B, 1, H, W))
+      g_stride = 0 if shared else H * W
+    _launch(dev, layer._pc.gn_solve_backward, solver.h, B, stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3], ctx.max_iters,
+            ctx.hist.data_ptr(), th_out.data_ptr(), ctx.iters.data_ptr(), g_out.data_ptr(), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf), g_stride,
+            copies, _raw_stream(dev))
+    if g_sdf is not None:
+      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf)
+    return (None, None, None, None, None, None) + tuple(grads[i] for i in ctx.slots)
+
+
 _NO_COVS_KEEP = _NO_COVS + ((),)
 
 
@@ -505,6 +670,30 @@ class PlanLayer(nn.Module):
         return dth, box[0], eex
     # planning / validation loops: no autograd node, one launch
     return _GNStep.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:3]
+
+  def forward_with_errors(self, thb, startb, goalb, imb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb):
+    """forward() and, in the same call, what the reference's training loop evaluates right behind it (learning/train_planner.py:313,327):
+    the unweighted errors of unweighted_errors_batch at thb + dthetab.  -> (dthetab, err, err_ext, err_sg (B,1), err_gp (B,1,1), err_obs (B,1,1));
+    everything but err carries the graph (ONE autograd node, ONE backward call).  Equivalent to
+        dth, err, eex = layer(thb, ...); sg, gp, ob = layer.unweighted_errors(thb + dth, sdfb)"""
+    self._check_inputs(thb, startb, goalb)
+    static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+    if static == _ALL_STATIC:
+      self.__dict__['_last'] = (startb, goalb, None, None, None)
+    else:
+      det = lambda t, st: None if (t is None or st) else t.detach()
+      self.__dict__['_last'] = (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
+                                None if (eps_trajb is None or static[2]) else eps_trajb)
+    B = thb.shape[0]
+    if torch.is_grad_enabled():
+      ts = (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+      slots = tuple([i for i in range(7) if ts[i] is not None and ts[i].requires_grad])
+      if slots:
+        box = []
+        dth, eex, usg, ugp, uobs = _GNStepErrors.apply(self, static, slots, ts, box, *[ts[i] for i in slots])
+        return dth, box[0], eex, usg.reshape(B, 1), ugp, uobs
+    dth, err, eex, usg, ugp, uobs = _GNStepErrors.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:6]
+    return dth, err, eex, usg.reshape(B, 1), ugp, uobs
 
   def _eval_launch(self, thb, sdfb, startb, goalb, qc, ow, eps):
     """One dgp_eval_errors launch -> ([err, err_ext, start_goal_error, gp_error, obs_error] (None where a grid is needed and sdfb is

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DGP_ABI_VERSION 3
+#define DGP_ABI_VERSION 4
 
 /* status codes */
 #define DGP_OK              0
@@ -191,6 +191,56 @@ int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch,
                              void* g_th, void* g_start, void* g_goal,
                              void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                              void* g_eps, void* stream);
+
+/* ---- round 4: what the reference's callers do around the step, as single calls ------------------------------------------------ */
+
+/* dgp_gn_solve with the trajectory history the backward pass needs: th_hist (max_iters, B, n, d) in fp64 WHATEVER the handle's io_dtype
+ * (dtheta_k = th_{k+1} - th_k is formed from it), row (k, b) = th_k of trajectory b for k < iters[b]; rows at or past iters[b] are not
+ * written.  iters must be given with th_hist.  th_hist == NULL: exactly dgp_gn_solve.  num_states <= 256. */
+int dgp_gn_solve_traced(const DgpHandle* h, int32_t batch,
+                        const void* th_init, const void* start, const void* goal,
+                        const DgpSdf* sdf, const DgpCovs* covs,
+                        int32_t max_iters, double tol_delta,
+                        void* th_out, int32_t* iters, void* err_hist, void* errext_hist, void* err_final,
+                        int32_t* info, double* th_hist, void* stream);
+
+/* Backward of the whole Gauss-Newton loop == torch autograd through DiffGPMP2Planner.forward, which keeps the graph across its
+ * iterations (diff_gpmp2_planner.py:122-156; consumer examples/diff_gpmp2_2d_example.py:77): given dgp_gn_solve_traced's th_hist,
+ * th_out, iters and the cotangent g_th_out (B,n,d) of the final trajectory, ONE launch walks th_{k+1} = th_k + dtheta(th_k) backwards
+ * per trajectory (adjoint solve + per-factor chain rule per iteration, the running cotangent in registers) and writes dL/d th_init
+ * (B,n,d), dL/d start, dL/d goal (B,1,d) and ACCUMULATES dL/d sdf (layout / partial copies as in dgp_gn_step_backward; the caller
+ * zeroes it).  Static covariances with a diagonal Q_c_inv (what forward() runs without learn modules), num_states <= 256;
+ * DGP_EUNSUPPORTED otherwise -- chain dgp_gn_step_backward then.  The per-iteration errors have no cotangent: forward() returns them
+ * as python floats (:138-141). */
+int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch,
+                          const void* start, const void* goal, const DgpSdf* sdf,
+                          int32_t max_iters, const double* th_hist, const void* th_out, const int32_t* iters,
+                          const void* g_th_out,
+                          void* g_th_init, void* g_start, void* g_goal,
+                          void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* stream);
+
+/* One iteration of the reference's training loop (learning/train_planner.py:311-327): dgp_gn_step, then the unweighted errors of
+ * DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (the sum formed in io_dtype, as torch forms th_curr_b + dthetab) -- two
+ * stream-ordered launches behind one call, no th + dtheta tensor in between.  unw_* (B), any may be NULL (all NULL: dgp_gn_step). */
+int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
+                       const void* th, const void* start, const void* goal,
+                       const DgpSdf* sdf, const DgpCovs* covs,
+                       void* dtheta, void* err, void* err_ext, int32_t* info,
+                       void* unw_sg, void* unw_gp, void* unw_obs, void* stream);
+
+/* Backward of dgp_gn_step_errors: cotangents of dtheta, err_ext and of the three unweighted errors at th + dtheta in, every gradient
+ * of dgp_gn_step_backward out (same conventions; g_sdf accumulated).  Two stream-ordered launches: the errors' backward at th + dtheta
+ * leaves dL/d(th + dtheta) in `workspace` ((B,n,d) elements of io_dtype, caller-provided: nothing is allocated inside a call) and its
+ * share of g_start / g_goal / g_eps / g_sdf; the step's backward adds the workspace to the dtheta cotangent and to g_th and its own
+ * share to the small gradients.  No unweighted-error cotangent: exactly dgp_gn_step_backward (workspace may be NULL). */
+int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch,
+                                const void* th, const void* start, const void* goal,
+                                const DgpSdf* sdf, const DgpCovs* covs,
+                                const void* dtheta, const void* g_dtheta, const void* g_err_ext,
+                                const void* g_unw_sg, const void* g_unw_gp, const void* g_unw_obs,
+                                void* g_th, void* g_start, void* g_goal,
+                                void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
+                                void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace, void* stream);
 
 /* Measurement aid (no counterpart in the reference): the NEXT kernel launched by the calling thread through any entry point
  * above records its own begin and end on the two HIP events (hipEvent_t, created with timing enabled, cast to void*), the way

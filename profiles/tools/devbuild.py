@@ -3,7 +3,7 @@
 dgpmp2_amd/lib/libdgpmp2_dev.so; the launch entry points of the units left out are stubs that fail with hipErrorInvalidValue.
 Use it with DGP_LIB_PATH=dgpmp2_amd/lib/libdgpmp2_dev.so (dgpmp2_amd/_capi.py).  Never the product build.
 
-  python profiles/tools/devbuild.py 2_f32_g0 2_f32_g1 [-D...] [-o name.so]     units: <dof>_<f32|f64>_g<0 static|1 general|2 backward|3 per-state Kronecker>
+  python profiles/tools/devbuild.py 2_f32_g0 2_f32_g1 [-D...] [-o name.so]     units: <dof>_<f32|f64>_g<0 static|1 general|2 backward|3 per-state Kronecker|4 chain backward>
 Prints the ISA statistics (registers, scratch, instruction counts) of the kernels whose name contains --show (default ',16,4,').
 """
 import argparse
@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
 import isa_stats
 
 CSRC = os.path.join(ROOT, 'dgpmp2_amd', 'csrc')
-ALL = ['%d_%s_g%d' % (d, t, g) for d in (2, 3) for t in ('f32', 'f64') for g in (0, 1, 2, 3)]
+ALL = ['%d_%s_g%d' % (d, t, g) for d in (2, 3) for t in ('f32', 'f64') for g in (0, 1, 2, 3, 4)]
 
 
 def main():

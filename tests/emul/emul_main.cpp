@@ -120,6 +120,7 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
           } else {
             if (mode == dgp::MODE_STEP) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_WBR>(p, cx);
             else if (mode == dgp::MODE_SOLVE) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_WBR>(p, cx);
+            else if (mode == 4) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_WBR, true>(p, *g, cx);
             else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_WBR>(p, *g, cx);
           }
           return;
@@ -135,6 +136,8 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
         else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>(p, cx);
       } else if (mode == dgp::MODE_EVAL) {
         dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>(p, cx);
+      } else if (mode == 4) {
+        dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC, true>(p, *g, cx);      // (dgp_gn_solve_backward: static covariances only, host-checked)
       } else {
         if (qk == dgp::QK_STATIC) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC>(p, *g, cx);
         else if (qk == dgp::QK_KRON) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_KRON>(p, *g, cx);
@@ -274,6 +277,40 @@ int emul_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th,
   if (rc != DGP_OK) return rc;
   run(h, p, &g, 3);
   return DGP_OK;
+}
+
+namespace {
+struct EmulLaunch {
+  const DgpHandle* h;
+  int operator()(int mode, const dgp::GnParams& p, const dgp::GnGradParams* g) const { run(h, p, g, mode); return DGP_OK; }
+};
+}  // namespace
+
+int emul_gn_solve_traced(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf,
+                         const DgpCovs* covs, int32_t max_iters, double tol_delta, void* th_out, int32_t* iters, void* err_hist,
+                         void* errext_hist, void* err_final, int32_t* info, double* th_hist, void*) {
+  return dgp_host::gn_solve_traced(h, batch, th_init, start, goal, sdf, covs, max_iters, tol_delta, th_out, iters, err_hist, errext_hist, err_final, info, th_hist,
+                                   EmulLaunch{h});
+}
+
+int emul_gn_solve_backward(const DgpHandle* h, int32_t batch, const void* start, const void* goal, const DgpSdf* sdf, int32_t max_iters,
+                           const double* th_hist, const void* th_out, const int32_t* iters, const void* g_th_out, void* g_th_init, void* g_start,
+                           void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void*) {
+  return dgp_host::gn_solve_backward(h, batch, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, g_th_init, g_start, g_goal, g_sdf,
+                                     g_sdf_batch_stride, g_sdf_copies, EmulLaunch{h});
+}
+
+int emul_gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                        const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, void* unw_sg, void* unw_gp, void* unw_obs, void*) {
+  return dgp_host::gn_step_errors(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs, EmulLaunch{h});
+}
+
+int emul_gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
+                                 const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, const void* g_unw_sg,
+                                 const void* g_unw_gp, const void* g_unw_obs, void* g_th, void* g_start, void* g_goal, void* g_sdf,
+                                 int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace, void*) {
+  return dgp_host::gn_step_errors_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, g_th, g_start,
+                                           g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, workspace, EmulLaunch{h});
 }
 
 int emul_event_create(void** out) { if (out) *out = nullptr; return DGP_OK; }      // nothing to time on the host

@@ -190,3 +190,65 @@ class Backend(object):
     solver.eval_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride, gep_p,
                                 self.stream(), g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), eps=self.to_np(gep))
+
+  # -- round 4: the fused-loop backward and the training iteration as single calls ---------------------------
+  def solve_traced(self, p, th, start, goal, sdf, max_iters, tol_delta, io='f64'):
+    """dgp_gn_solve_traced (static covariances) -> th_out, iters, th_hist (max_iters,B,n,d; NaN where untouched), info"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, None, None, None, False)
+    tho, tho_p = self.empty(th.shape, io)
+    its, its_p = self.empty((B,), dtype=np.int32)
+    hist, hist_p = self.empty((max_iters,) + tuple(th.shape), dtype=np.float64)
+    info, info_p = self.empty((B,), dtype=np.int32)
+    solver.gn_solve_traced(B, th_p, st_p, go_p, sdf_arg, None, max_iters, tol_delta, tho_p, its_p, None, None, None, info_p, hist_p, self.stream())
+    return self.to_np(tho), self.to_np(its), self.to_np(hist), self.to_np(info)
+
+  def solve_backward(self, p, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, io='f64', sdf_copies=1, want_sdf=True):
+    """dgp_gn_solve_backward -> dict of gradients: th (w.r.t. th_init), start, goal, sdf"""
+    th_out = np.asarray(th_out)
+    solver, B, tho_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th_out, start, goal, sdf, None, None, None, False)
+    _, hist_p = self.to_dev(th_hist, dtype=np.float64)
+    _, its_p = self.to_dev(iters, dtype=np.int32)
+    _, g_p = self.to_dev(g_th_out, io)
+    gth, gth_p = self.empty(th_out.shape, io)
+    gst, gst_p = self.empty(np.asarray(start).shape, io)
+    ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
+    sdf = np.asarray(sdf)
+    gsdf, gsdf_p = (None, None)
+    if want_sdf:
+      gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    solver.gn_solve_backward(B, st_p, go_p, sdf_arg, max_iters, hist_p, tho_p, its_p, g_p, gth_p, gst_p, ggo_p, gsdf_p, stride, self.stream(),
+                             g_sdf_copies=sdf_copies)
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf))
+
+  def step_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+    """dgp_gn_step_errors -> dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs (the last three at th + dtheta)"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    dth, dth_p = self.empty(th.shape, io)
+    outs = [self.empty((B,), io) for _ in range(5)]
+    info, info_p = self.empty((B,), dtype=np.int32)
+    solver.gn_step_errors(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, outs[0][1], outs[1][1], info_p, outs[2][1], outs[3][1], outs[4][1], self.stream())
+    return (self.to_np(dth), self.to_np(outs[0][0]), self.to_np(outs[1][0]), self.to_np(info)) + tuple(self.to_np(o[0]) for o in outs[2:])
+
+  def step_errors_backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, qc=None, ow=None, eps=None,
+                           q_full=False, io='f64', sdf_copies=1):
+    """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    n = th.shape[1]
+    _, dth_p = self.to_dev(dtheta, io)
+    _, gd_p = self.to_dev(g_dtheta, io)
+    cot = [self.to_dev(None if c is None else np.reshape(c, (B,)), io)[1] for c in (g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs)]
+    gth, gth_p = self.empty(th.shape, io)
+    gst, gst_p = self.empty(np.asarray(start).shape, io)
+    ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
+    sdf = np.asarray(sdf)
+    gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+    gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
+    gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
+    gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
+    ws, ws_p = self.empty(th.shape, io)
+    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    solver.gn_step_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride,
+                                   gqc_p, gow_p, gep_p, ws_p, self.stream(), g_sdf_copies=sdf_copies)
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc), ow=self.to_np(gow),
+                eps=self.to_np(gep))

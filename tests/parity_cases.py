@@ -617,6 +617,123 @@ def case_eval_errors_backward(be, golden, io):
 ALL_CASES.append(case_eval_errors_backward)
 
 
+def case_solve_backward(be, golden, io):
+  """dgp_gn_solve_traced + dgp_gn_solve_backward vs the reference's torch autograd through DiffGPMP2Planner.forward, which keeps the graph
+  across its Gauss-Newton iterations (fixture g8_forward_grads; diff_gpmp2_planner.py:92-174, consumer examples/diff_gpmp2_2d_example.py:77):
+  four trajectories that stop after 2, 8, 9 (= max_iters) and 9 iterations, one of them on an obstacle-free grid; gradients w.r.t. the initial
+  trajectory, the grids, the start and goal means.  The loop does not converge on three of them (the hinge switches states on and off), so
+  nine chained solves amplify rounding: 6e-9 in fp64 against the reference's own fp64 run.  f32 I/O: the traced loop must equal the plain one
+  bit for bit and the history must reproduce the chained steps; the gradients are then only checked against the f64 ones at 2e-3 (the
+  iteration counts are the reference's: tol_delta sits far from every |dtheta|)."""
+  g = golden('g8_forward_grads')
+  B, n = g['th0'].shape[:2]
+  G = int(g['G'])
+  p = P2d(n)
+  K, tol_delta = int(g['max_iters']), float(g['tol_delta'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  sdf[int(g['free_sample'])] = float(g['free_value'])
+  th0, st, go, sdf, gbar = rnd(g['th0'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io), rnd(g['gbar'], io)
+  tho, its, hist, info = be.solve_traced(p, th0, st, go, sdf, K, tol_delta, io=io)
+  assert np.all(info == 0) and np.array_equal(its, g['iters'])
+  ref = be.solve(p, th0, st, go, sdf, K, tol_delta, io=io)
+  assert np.array_equal(tho, ref[0]) and np.array_equal(its, ref[1])                     # the history store does not touch the loop
+  assert rel_err(tho, g['th_final']) < (1e-8 if io == 'f64' else 2e-3)
+  for b in range(B):                                  # rows the loop ran are written, the others are not
+    k = int(its[b])
+    assert np.all(np.isfinite(hist[:k, b])) and np.all(np.isnan(hist[k:, b]))
+    assert np.array_equal(hist[0, b], th0[b])
+  r = be.solve_backward(p, st, go, sdf, K, hist, tho, its, gbar, io=io)
+  if io == 'f64':
+    for k, key in (('th', 'g_th0'), ('start', 'g_start'), ('goal', 'g_goal'), ('sdf', 'g_sdf')):
+      assert rel_err(r[k], g[key]) < 5e-8, (k, rel_err(r[k], g[key]))
+    # the same gradient as chained single-step backward calls (dgp_gn_step_backward, K launches) through the history
+    gcur = gbar.copy()
+    acc = dict(start=np.zeros_like(st), goal=np.zeros_like(go), sdf=np.zeros_like(sdf))
+    for k in range(K - 1, -1, -1):
+      on = its > k
+      thk = np.where(on[:, None, None], np.nan_to_num(hist[k]), tho)
+      nxt = np.where((its > k + 1)[:, None, None], np.nan_to_num(hist[min(k + 1, K - 1)]), tho)
+      one = be.backward(p, thk, st, go, sdf, nxt - thk, gcur * on[:, None, None], None, io=io)
+      gcur = gcur + one['th'] * on[:, None, None]
+      for key in acc: acc[key] += one[key] * on.reshape((B,) + (1,) * (one[key].ndim - 1))
+    assert rel_err(r['th'], gcur) < 1e-10 and rel_err(r['start'], acc['start']) < 1e-10 and rel_err(r['goal'], acc['goal']) < 1e-10
+    assert rel_err(r['sdf'], acc['sdf']) < 1e-10
+    # one grid shared by the batch, partial copies: the per-sample gradients summed
+    sdf1 = sdf[1:2]
+    t1 = be.solve_traced(p, th0, st, go, sdf1, K, tol_delta, io=io)
+    ra = be.solve_backward(p, st, go, sdf1, K, t1[2], t1[0], t1[1], gbar, io=io)
+    t2 = be.solve_traced(p, th0, st, go, np.repeat(sdf1, B, 0), K, tol_delta, io=io)
+    rb = be.solve_backward(p, st, go, np.repeat(sdf1, B, 0), K, t2[2], t2[0], t2[1], gbar, io=io)
+    rc = be.solve_backward(p, st, go, sdf1, K, t1[2], t1[0], t1[1], gbar, io=io, sdf_copies=8)
+    assert np.array_equal(ra['th'], rb['th']) and rel_err(ra['sdf'], rb['sdf'].sum(0, keepdims=True)) < 1e-11
+    assert rel_err(rc['sdf'].sum(0, keepdims=True), ra['sdf']) < 1e-11
+  else:
+    for k, key in (('th', 'g_th0'), ('start', 'g_start'), ('goal', 'g_goal')):
+      assert rel_err(r[k], g[key]) < 2e-3, (k, rel_err(r[k], g[key]))
+
+
+ALL_CASES.append(case_solve_backward)
+
+
+def case_step_errors(be, golden, io):
+  """dgp_gn_step_errors / dgp_gn_step_errors_backward: one iteration of the reference's training loop (learning/train_planner.py:311-327 --
+  step(), th + dtheta, unweighted_errors_batch) as single calls, against the reference's autograd through exactly that composition (fixture
+  g7_errors, part (b), per-state covariances; its loss also holds error_ext_batch at th + dtheta, whose share is added here through the
+  existing single-purpose entry points), and bit for bit against the two-call sequence it replaces."""
+  g = golden('g7_errors')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  th, st, go, sdf = rnd(g['th'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io)
+  qc, ow, eps = rnd(g['qc'], io), rnd(g['ow'].reshape(B, n), io), rnd(g['eps'].reshape(B, n), io)
+  cs, cg, co, ce = rnd(g['c_sg'], io).reshape(B), rnd(g['c_gp'], io).reshape(B), rnd(g['c_obs'], io).reshape(B), rnd(g['c_ee'], io).reshape(B)
+  dth, err, eex, info, usg, ugp, uobs = be.step_errors(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
+  # == the two calls it replaces (the sum th + dtheta formed in the I/O type, as torch does)
+  d2, e2, x2, i2 = be.step(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
+  npdt = np.float64 if io == 'f64' else np.float32
+  th_new = (th.astype(npdt) + d2.astype(npdt)).astype(np.float64)
+  _, _, s2, g2, o2 = be.eval_errors(p, th_new, st, go, sdf, eps=eps, io=io)
+  assert np.array_equal(dth, d2) and np.array_equal(err, e2) and np.array_equal(eex, x2)
+  assert np.array_equal(usg, s2) and np.array_equal(ugp, g2) and np.array_equal(uobs, o2)
+  tolv = 1e-11 if io == 'f64' else 3e-5
+  assert rel_err(dth, g['b_dth']) < TOL[io]
+  for got, key in ((usg, 'b_sg'), (ugp, 'b_gp'), (uobs, 'b_obs')):
+    assert rel_err(got, g[key].reshape(-1)) < tolv, (key, rel_err(got, g[key].reshape(-1)))
+  # backward: cotangents of the three unweighted errors through the fused call + the error_ext share through the single-purpose calls
+  r = be.step_errors_backward(p, th, st, go, sdf, dth, None, None, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io)
+  ee = be.eval_backward(p, th_new, st, go, sdf, g_err_ext=ce, eps=eps, io=io)
+  r2 = be.backward(p, th, st, go, sdf, dth, ee['th'], None, qc=qc, ow=ow, eps=eps, io=io)
+  tot = dict(th=r['th'] + r2['th'] + ee['th'], start=r['start'] + r2['start'] + ee['start'], goal=r['goal'] + r2['goal'] + ee['goal'],
+             sdf=r['sdf'] + r2['sdf'] + ee['sdf'], qc=r['qc'] + r2['qc'], ow=r['ow'] + r2['ow'], eps=r['eps'] + r2['eps'] + ee['eps'])
+  tolg = 1e-9 if io == 'f64' else 2e-3
+  for k in ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps'):
+    ref = g['b_g_' + k].reshape(tot[k].shape)
+    assert rel_err(tot[k], ref) < tolg, (k, rel_err(tot[k], ref))
+  # ... and the fused backward == its two halves run one after the other by hand (errors' backward at th + dtheta, then the step's with that
+  # gradient joined to the dtheta cotangent), with a dtheta cotangent and an err_ext cotangent as well
+  gd = rnd(np.random.RandomState(3).randn(B, n, 4), io)
+  fused = be.step_errors_backward(p, th, st, go, sdf, dth, gd, ce, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io)
+  h1 = be.eval_backward(p, th_new, st, go, sdf, None, cs, cg, co, eps=eps, io=io)
+  h2 = be.backward(p, th, st, go, sdf, dth, (gd.astype(npdt) + h1['th'].astype(npdt)).astype(np.float64), ce, qc=qc, ow=ow, eps=eps, io=io)
+  ft = 1e-12 if io == 'f64' else 2e-5
+  assert rel_err(fused['th'], h2['th'] + h1['th']) < ft and rel_err(fused['start'], h2['start'] + h1['start']) < ft
+  assert rel_err(fused['eps'], h2['eps'] + h1['eps']) < ft and rel_err(fused['sdf'], h2['sdf'] + h1['sdf']) < ft
+  assert rel_err(fused['qc'], h2['qc']) < ft and rel_err(fused['ow'], h2['ow']) < ft
+  # static covariances and a shared grid with partial copies; no error cotangent at all == dgp_gn_step_backward
+  s1 = be.step_errors(p, th, st, go, sdf[:1], io=io)
+  f1 = be.step_errors_backward(p, th, st, go, sdf[:1], s1[0], gd, None, cs, cg, co, io=io, sdf_copies=8)
+  f2 = be.step_errors_backward(p, th, st, go, np.repeat(sdf[:1], B, 0), s1[0], gd, None, cs, cg, co, io=io)
+  assert rel_err(f1['th'], f2['th']) < ft and rel_err(f1['sdf'].sum(0, keepdims=True), f2['sdf'].sum(0, keepdims=True)) < (1e-11 if io == 'f64' else 1e-4)
+  f3 = be.step_errors_backward(p, th, st, go, sdf, dth, gd, ce, None, None, None, qc=qc, ow=ow, eps=eps, io=io)
+  f4 = be.backward(p, th, st, go, sdf, dth, gd, ce, qc=qc, ow=ow, eps=eps, io=io)
+  for k in ('th', 'start', 'goal', 'qc', 'ow', 'eps'): assert np.array_equal(f3[k], f4[k]), k
+  assert rel_err(f3['sdf'], f4['sdf']) < ft           # (atomic accumulation: the order of the additions is not fixed)
+
+
+ALL_CASES.append(case_step_errors)
+
+
 def case_long_trajectories(be, golden, io, configs=None):
   """n > 256 (gn_long.h: one trajectory per wavefront, ceil(n / 64) rows per lane in a loop, interior state parked in LDS): the reference
   accepts any total_time_step (plan_layer.py:30).  Every entry point -- step, the fused loop, the error evaluation, both backward kernels --

@@ -101,9 +101,9 @@ def _leaf(t):
   return t.detach().requires_grad_(True)
 
 
-def truncated_bptt(planner, batch, th_init, num_links, every, lookback, weights, recurrent=False, loss_fn=imitation_and_factor_loss):
+def truncated_bptt(planner, batch, th_init, num_links, every, lookback, weights, recurrent=False, loss_fn=imitation_and_factor_loss, fused=False):
   """Run `num_links` GN steps from `th_init` on `batch` = dict(im, sdf, start, goal, th_opt) (sdf a leaf that requires grad), flushing
-  gradients every `every` links through at most `lookback` links (see the module docstring).  -> dict with the per-link loss terms, the
+  gradients every `every` links through at most `lookback` links (see the module docstring); fused: planner.step_with_errors per link.  -> dict with the per-link loss terms, the
   final trajectory, and the input leaf of the last link (its .grad is what the last flush left there)."""
   im, sdf, start, goal, th_opt = batch['im'], batch['sdf'], batch['start'], batch['goal'], batch['th_opt']
   chain = collections.deque([_Link(None, th_init, None, planner.learn_module_fcn.init_hidden(th_init.shape[0]) if recurrent else None)],
@@ -116,15 +116,16 @@ def truncated_bptt(planner, batch, th_init, num_links, every, lookback, weights,
   per_link = []
   for k in range(1, num_links + 1):
     x = _leaf(chain[-1].y)
-    if recurrent:
-      hin = tuple(_leaf(s) for s in chain[-1].hout)
-      update, hout, _, _, _, _, _ = planner.step(x, start, goal, im, sdf, features, update, hin)
+    hin = tuple(_leaf(s) for s in chain[-1].hout) if recurrent else None
+    if fused:          # dgpmp2_amd's addition: the step and the errors at x + update as one call (one autograd node)
+      out, errors = planner.step_with_errors(x, start, goal, im, sdf, features, update, hin)
     else:
-      hin = hout = None
-      update = planner.step(x, start, goal, im, sdf, features, update)[0]
+      out = planner.step(x, start, goal, im, sdf, features, update, hin) if recurrent else planner.step(x, start, goal, im, sdf, features, update)
+    update, hout = out[0], (out[1] if recurrent else None)
     y = x + update
     chain.append(_Link(x, y, hin, hout))            # (the deque drops the oldest link: nothing older than `lookback` is reachable)
-    terms = loss_fn(update, th_opt - x, *planner.unweighted_errors_batch(y, sdf), weights)
+    if not fused: errors = planner.unweighted_errors_batch(y, sdf)
+    terms = loss_fn(update, th_opt - x, *errors, weights)
     per_link.append(terms)
     running = running + terms.total
     if k % every == 0:

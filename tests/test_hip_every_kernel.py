@@ -129,3 +129,51 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
         # systems here.  The fp64 run pins the mathematics at 1e-6; this one only has to catch code-generation faults (O(1) errors).
         if not eb < (1e-6 if io == 'f64' else 2e-3): bad.append((tag, key, eb))
   assert not bad, '%d backward results differ from the autograd oracle:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_chain_backward_kernel(be, dof, io, monkeypatch):
+  """Every instantiation of the fused loop's backward (dgp_gn_solve_backward: 2 robots x 2 I/O types x 9 shapes x block elimination / Woodbury exact
+  fit / Woodbury ragged) and of the traced fused loop in front of it: the history must reproduce the plain loop bit for bit, and the gradients
+  must equal the chain of single-step backward launches (dgp_gn_step_backward, each instantiation of which the test above holds against the
+  independent autograd oracle) walked by hand through that history.  Three iterations, the second trajectory stopping after the first
+  (tol_delta between the two trajectories' first updates), the third batch element in a second, partially filled wavefront."""
+  rs = np.random.RandomState(300 * dof + (io == 'f32'))
+  bad = []
+  K = 3
+  for lpt, c in SHAPES:
+    monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+    for n in (lpt * c, max(4, lpt * c - 2)):
+      B = 64 // lpt + 1
+      p, th, start, goal, sdf, _, _, _, _ = _inputs(rs, dof, n, B, 'static', io)
+      tag = 'dof %d %s shape (%d,%d) n %d' % (dof, io, lpt, c, n)
+      d0 = be.step(p, th, start, goal, sdf, io=io)[0]
+      nrm = np.sqrt((d0.reshape(B, -1) ** 2).sum(1))
+      order = np.argsort(nrm)
+      tol = 0.5 * (nrm[order[0]] + nrm[order[1]]) if B > 1 else 0.0      # the trajectory with the smallest first update stops after ONE iteration
+      tho, its, hist, info = be.solve_traced(p, th, start, goal, sdf, K, tol, io=io)
+      ref = be.solve(p, th, start, goal, sdf, K, tol, io=io)
+      if not (np.array_equal(tho, ref[0]) and np.array_equal(its, ref[1]) and not info.any()): bad.append((tag, 'traced loop differs from the plain loop')); continue
+      if B > 1 and not (its.min() == 1 and its.max() > 1): bad.append((tag, 'iteration counts', its.tolist())); continue
+      gbar = PC.rnd(rs.randn(B, n, 2 * dof), io)
+      copies = 16 if (lpt + c) % 3 == 0 else 1
+      r = be.solve_backward(p, start, goal, sdf, K, hist, tho, its, gbar, io=io, sdf_copies=copies)
+      gcur = gbar.copy()
+      acc = dict(start=np.zeros_like(start), goal=np.zeros_like(goal), sdf=np.zeros_like(sdf))
+      for k in range(K - 1, -1, -1):
+        on = its > k
+        thk = np.where(on[:, None, None], np.nan_to_num(hist[k]), tho)
+        nxt = np.where((its > k + 1)[:, None, None], np.nan_to_num(hist[min(k + 1, K - 1)]), tho)
+        one = be.backward(p, thk, start, goal, sdf, nxt - thk, gcur * on[:, None, None], None, io='f64' if io == 'f64' else io)
+        gcur = gcur + one['th'] * on[:, None, None]
+        acc['start'] += one['start'] * on[:, None, None]; acc['goal'] += one['goal'] * on[:, None, None]; acc['sdf'] += one['sdf']
+      for key, a_, b_ in (('th', r['th'], gcur), ('start', r['start'], acc['start']), ('goal', r['goal'], acc['goal']),
+                          ('sdf', r['sdf'].sum(0, keepdims=True) if copies > 1 else r['sdf'], acc['sdf'])):
+        if key == 'sdf' and io == 'f32': continue
+        if not np.all(np.isfinite(a_)): bad.append((tag, key, 'non-finite')); continue
+        eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(gcur).max() if key == 'sdf' else 0.0, 1e-300)
+        # f32 I/O: the hand-walked chain rounds th_k, dtheta_k and the running cotangent to fp32 between the launches, the chain kernel keeps them in fp64
+        # (the grid gradient is summed by atomics in an order that differs between the one launch and the K: 1e-7 of cancellation noise)
+        if not eb < ((1e-7 if key == 'sdf' else 1e-9) if io == 'f64' else 5e-3): bad.append((tag, key, eb))
+  assert not bad, '%d chain-backward results differ from the chained single-step backward:\n' % len(bad) + '\n'.join(map(str, bad))

@@ -29,7 +29,8 @@ class FakePycall(object):
     return f
 
   def __getattr__(self, name):
-    n = {'gn_step': 18, 'gn_solve': 22, 'eval_errors': 19, 'gn_step_backward': 26, 'eval_errors_backward': 25}[name]
+    n = {'gn_step': 18, 'gn_solve': 22, 'eval_errors': 19, 'gn_step_backward': 26, 'eval_errors_backward': 25, 'gn_solve_traced': 23,
+         'gn_solve_backward': 20, 'gn_step_errors': 21, 'gn_step_errors_backward': 30}[name]
     return self._rec(name, n)
 
 

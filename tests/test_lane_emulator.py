@@ -36,6 +36,10 @@ def test_emul_unaligned_f32(be, golden): PC.case_unaligned_buffers(be, golden, '
 def test_emul_solve_with_covariances(be, golden): PC.case_solve_with_covariances(be, golden, 'f64')
 def test_emul_eval_errors_backward(be, golden): PC.case_eval_errors_backward(be, golden, 'f64')
 def test_emul_eval_errors_backward_f32(be, golden): PC.case_eval_errors_backward(be, golden, 'f32')
+def test_emul_solve_backward(be, golden): PC.case_solve_backward(be, golden, 'f64')
+def test_emul_solve_backward_f32(be, golden): PC.case_solve_backward(be, golden, 'f32')
+def test_emul_step_errors(be, golden): PC.case_step_errors(be, golden, 'f64')
+def test_emul_step_errors_f32(be, golden): PC.case_step_errors(be, golden, 'f32')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)

@@ -271,16 +271,18 @@ TBPTT_LEARN_PARAMS = {      # == tests/golden/make_golden.py::TBPTT_LEARN_PARAMS
 }
 
 
+@pytest.mark.parametrize('fused', [False, True], ids=['step+errors', 'step_with_errors'])
 @pytest.mark.parametrize('tag,mode,mtype', [('fix_dynamics', 'fix_dynamics', 'feed_forward'), ('qc_full', 'qc_full', 'feed_forward'),
                                             ('recurrent', 'fix_dynamics', 'recurrent')])
-def test_tbptt_outer_loop_runs(golden, tag, mode, mtype):
+def test_tbptt_outer_loop_runs(golden, tag, mode, mtype, fused):
   """The solver drops into the reference's outer learning loop.  Fixture g7_tbptt = one batch of the reference's train() -- ITS OWN loop
   text (learning/train_planner.py:258-424 and one_step_loss, exec'd from /root/reference by tests/golden/make_golden.py) on the
   reference's planner.  Here: this build's statement of the same truncated-BPTT procedure (tests/tbptt_driver.py: fresh leaf per GN step,
   loss on the update + the unweighted factor errors at th + dtheta, flush every tk steps through at most tk2 links) through dgpmp2_amd's
   planner -- feed-forward predictor in two dynamics modes, and a recurrent one (hiddenb through step(), diff_gpmp2_planner.py:192,208-210).
   Loss terms of every step, the final trajectory, and the gradients left in the predictor's parameters, in the grid and in the last
-  trajectory leaf must agree with the reference's."""
+  trajectory leaf must agree with the reference's.  fused: every link through planner.step_with_errors (one autograd node per link)
+  instead of step() + unweighted_errors_batch()."""
   import copy
   import tbptt_driver as TD
   from dgpmp2_amd.utils.planner_utils import straight_line_trajb
@@ -295,7 +297,7 @@ def test_tbptt_outer_loop_runs(golden, tag, mode, mtype):
   batch = {'im': (sdf > 0).double(), 'sdf': sdf.clone().requires_grad_(True), 'start': T(g['start']), 'goal': T(g['goal']), 'th_opt': T(g['th_opt'])}
   th_init = straight_line_trajb(batch['start'][:, :, :2], batch['goal'][:, :, :2], pp['total_time_sec'], pp['total_time_step'], 2, torch.device(DEV))
   th_init.requires_grad_(True)
-  r = TD.truncated_bptt(planner, batch, th_init, dg['T'], dg['tk'], dg['tk2'], lp['optim'], recurrent=(mtype == 'recurrent'))
+  r = TD.truncated_bptt(planner, batch, th_init, dg['T'], dg['tk'], dg['tk2'], lp['optim'], recurrent=(mtype == 'recurrent'), fused=fused)
   pre = tag + '_'
   ref_terms = g[pre + 'terms']                    # (T, 8): total, pos, vel, cov (always 0), gp, sg, obs, ext
   mine = np.asarray([[float(x.detach()) if torch.is_tensor(x) else float(x) for x in (t.total, t.pos, t.vel, 0.0, t.gp, t.sg, t.obs, t.ext)] for t in r['terms']])
@@ -368,6 +370,103 @@ def test_forward_raises_on_non_spd_like_cholesky():
   with pytest.raises(RuntimeError, match='not positive definite'):
     planner.forward(th, th[:, :1], th[:, :1], None, sdf)
   assert int(planner.plan_layer.last_info.count_nonzero()) == B
+
+
+def test_forward_with_grad_is_two_launches_and_matches_reference(golden):
+  """planner.forward on inputs that require grad (the reference keeps the graph across its Gauss-Newton loop, diff_gpmp2_planner.py:122-156;
+  consumer examples/diff_gpmp2_2d_example.py:77): ONE fused launch forward (dgp_gn_solve_traced), ONE launch backward (dgp_gn_solve_backward),
+  against the reference's autograd through its own forward() (fixture g8_forward_grads: trajectories that stop after 2, 8, 9, 9 iterations)."""
+  import dgpmp2_amd.gpmp2.plan_layer as PL
+  g = golden('g8_forward_grads')
+  B, n, G = 4, 16, int(g['G'])
+  planner = make_planner(n, B, max_iters=int(g['max_iters']), tol_delta=float(g['tol_delta']))
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1)
+  sdf[int(g['free_sample'])] = float(g['free_value'])
+  L = {'th': T(g['th0']).requires_grad_(True), 'sdf': sdf.requires_grad_(True), 'start': T(g['start']).requires_grad_(True), 'goal': T(g['goal']).requires_grad_(True)}
+  pc = planner.plan_layer._pc
+  calls = []
+
+  class Spy(object):
+    def __getattr__(self, name):
+      f = getattr(pc, name)
+      def w(*a):
+        calls.append(name)
+        return f(*a)
+      return w
+  planner.plan_layer.__dict__['_pc'] = Spy()
+  thf, hid, e_init, e_final, e_iter, ee_iter, jb, tb = planner.forward(L['th'], L['start'], L['goal'], (sdf.detach() > 0).double(), L['sdf'])
+  assert type(thf.grad_fn).__name__.startswith('_GNSolve') and calls == ['gn_solve_traced']
+  assert jb == list(g['iters']) and hid is None
+  assert rel_err(thf.detach().cpu().numpy(), g['th_final']) < 1e-8
+  assert rel_err(np.asarray(e_init), g['err_init']) < 1e-10 and rel_err(np.asarray(e_final), g['err_final']) < 1e-7
+  for b in range(B):
+    assert rel_err(np.asarray(e_iter[b]), g['err_iter'][b, :jb[b]]) < 1e-8 and rel_err(np.asarray(ee_iter[b]), g['errext_iter'][b, :jb[b]]) < 1e-8
+  gr = torch.autograd.grad((T(g['gbar']) * thf).sum(), [L['th'], L['sdf'], L['start'], L['goal']])
+  assert calls == ['gn_solve_traced', 'gn_solve_backward']
+  for got, key in zip(gr, ('g_th0', 'g_sdf', 'g_start', 'g_goal')):
+    assert rel_err(got.cpu().numpy(), g[key]) < 5e-8, (key, rel_err(got.cpu().numpy(), g[key]))
+  # a subset of the inputs (the example differentiates w.r.t. the grid only), a shared grid as an expand()ed view, float32 tensors
+  planner.plan_layer.__dict__['_pc'] = pc
+  sdf1 = T(O.circles_sdf(G, g['circles']))[None, None].requires_grad_(True)
+  thf1 = planner.forward(T(g['th0']), T(g['start']), T(g['goal']), None, sdf1.expand(B, 1, G, G))[0]
+  g1, = torch.autograd.grad((T(g['gbar']) * thf1).sum(), [sdf1])
+  sdfB = sdf1.detach().repeat(B, 1, 1, 1).requires_grad_(True)
+  thf2 = planner.forward(T(g['th0']), T(g['start']), T(g['goal']), None, sdfB)[0]
+  g2, = torch.autograd.grad((T(g['gbar']) * thf2).sum(), [sdfB])
+  assert torch.equal(thf1, thf2) and rel_err(g1.cpu().numpy(), g2.sum(0, keepdim=True).cpu().numpy()) < 1e-10
+  f32 = torch.float32
+  th32 = T(g['th0'], f32).requires_grad_(True)
+  thf3 = planner.forward(th32, T(g['start'], f32), T(g['goal'], f32), None, sdf.detach().to(f32))[0]
+  g3, = torch.autograd.grad((T(g['gbar'], f32) * thf3).sum(), [th32])
+  assert thf3.dtype == f32 and g3.dtype == f32 and rel_err(g3.cpu().numpy().astype(np.float64), g['g_th0']) < 5e-3
+  with pytest.raises(RuntimeError):               # a raw kernel behind the node: a double backward must raise, not return zeros
+    thf4 = planner.forward(T(g['th0']).requires_grad_(True), T(g['start']), T(g['goal']), None, sdf.detach())[0]
+    gg, = torch.autograd.grad(thf4.sum(), [thf4.grad_fn.next_functions[0][0].variable], create_graph=True)
+    gg.sum().backward()
+
+
+def test_step_with_errors_matches_reference_and_the_two_calls_it_replaces(golden):
+  """planner.step_with_errors == step() followed by unweighted_errors_batch(th + dtheta) (learning/train_planner.py:311,313,327) in ONE autograd
+  node: values and every gradient against the reference's autograd through exactly that composition (fixture g7_errors (b); the fixture's loss
+  also holds error_ext_batch(th + dtheta), evaluated here through the existing method), and against the two-call sequence."""
+  g = golden('g7_errors')
+  B, n, G = 4, 16, int(g['G'])
+  planner = make_planner(n, B)
+  names = ('th', 'sdf', 'start', 'goal', 'qc', 'ow', 'eps')
+  c_sg, c_gp, c_obs, c_ee = T(g['c_sg']), T(g['c_gp']), T(g['c_obs']), T(g['c_ee'])
+
+  def leaves():
+    L = {k: T(g[k]).requires_grad_(True) for k in ('th', 'start', 'goal', 'qc', 'ow', 'eps')}
+    L['sdf'] = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1).requires_grad_(True)
+    return L
+  L = leaves()
+  pl = planner.plan_layer
+  dth, err, eex, e_sg, e_gp, e_obs = pl.forward_with_errors(L['th'], L['start'], L['goal'], None, L['sdf'], L['qc'], L['ow'], L['eps'])
+  assert e_sg.shape == (B, 1) and e_gp.shape == (B, 1, 1) and e_obs.shape == (B, 1, 1) and not err.requires_grad
+  assert dth.grad_fn is e_sg.grad_fn.next_functions[0][0] or type(dth.grad_fn).__name__.startswith('_GNStepErrors')
+  for got, key in ((dth, 'b_dth'), (e_sg, 'b_sg'), (e_gp, 'b_gp'), (e_obs, 'b_obs')):
+    assert rel_err(got.detach().cpu().numpy(), g[key]) < 1e-9, key
+  e_ee = planner.error_ext_batch(L['th'] + dth, L['sdf'])
+  loss = (c_sg * e_sg).sum() + (c_gp * e_gp).sum() + (c_obs * e_obs).sum() + (c_ee * e_ee).sum()
+  gr = torch.autograd.grad(loss, [L[k] for k in names])
+  for k, gk in zip(names, gr):
+    assert rel_err(gk.cpu().numpy(), g['b_g_' + k]) < 1e-9, (k, rel_err(gk.cpu().numpy(), g['b_g_' + k]))
+  # == the two calls, value for value and gradient for gradient (static covariances through the planner-level method)
+  L2 = leaves()
+  gb = T(np.random.RandomState(5).randn(B, n, 4))
+  out, (s1, g1, o1) = planner.step_with_errors(L2['th'], L2['start'], L2['goal'], None, L2['sdf'])
+  l1 = (gb * out[0]).sum() + out[3].sum() + (c_sg * s1).sum() + (c_gp * g1).sum() + (c_obs * o1).sum()
+  ga = torch.autograd.grad(l1, [L2[k] for k in ('th', 'sdf', 'start', 'goal')])
+  L3 = leaves()
+  out3 = planner.step(L3['th'], L3['start'], L3['goal'], None, L3['sdf'])
+  s3, g3, o3 = planner.unweighted_errors_batch(L3['th'] + out3[0], L3['sdf'])
+  l3 = (gb * out3[0]).sum() + out3[3].sum() + (c_sg * s3).sum() + (c_gp * g3).sum() + (c_obs * o3).sum()
+  gc = torch.autograd.grad(l3, [L3[k] for k in ('th', 'sdf', 'start', 'goal')])
+  assert torch.equal(out[0], out3[0]) and torch.equal(s1, s3) and torch.equal(g1, g3) and torch.equal(o1, o3) and torch.equal(out[2], out3[2])
+  for a, c in zip(ga, gc): assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1e-11
+  with torch.no_grad():
+    out4, (s4, g4, o4) = planner.step_with_errors(L2['th'], L2['start'], L2['goal'], None, L2['sdf'])
+  assert out4[0].grad_fn is None and torch.equal(out4[0], out[0]) and torch.equal(s4, s1)
 
 
 def test_unweighted_errors_and_error_ext_are_differentiable_like_the_reference(golden):
