@@ -431,15 +431,17 @@ def planner_api_backward_rate(device, reps=200):
   # one iteration of the reference's training loop (learning/train_planner.py:311-327, 366): step, the unweighted errors at th + dtheta, backward of
   # both -- as the two calls of the reference API (two autograd nodes) and as planner.step_with_errors (one node; dgp_gn_step_errors[_backward])
   cw = torch.randn(B, 1, 1, device=device)
+  cws = cw.view(B, 1).contiguous()
+  leaves = (thr, qc, ow, ep)
 
   def train_iteration_two_calls():
     dth = planner.plan_layer(thr, start, goal, None, sdfb, qc, ow, ep)[0]
     sg, gp_, ob = planner.unweighted_errors_batch(thr + dth, sdfb)
-    torch.autograd.grad((g * dth).sum() + (cw * gp_).sum() + (cw * ob).sum() + (cw.view(B, 1) * sg).sum(), (thr, qc, ow, ep))
+    torch.autograd.grad((dth, sg, gp_, ob), leaves, (g, cws, cw, cw))      # (cotangents handed over directly: no loss arithmetic in the measurement)
 
   def train_iteration_fused():
     dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc, ow, ep)
-    torch.autograd.grad((g * dth).sum() + (cw * gp_).sum() + (cw * ob).sum() + (cw.view(B, 1) * sg).sum(), (thr, qc, ow, ep))
+    torch.autograd.grad((dth, sg, gp_, ob), leaves, (g, cws, cw, cw))
 
   # planner.forward with the graph kept (examples/diff_gpmp2_2d_example.py:77): 10 GN iterations + the backward pass through all of them, two launches
   sdf_leaf = sdf.clone().requires_grad_(True)
@@ -448,6 +450,19 @@ def planner_api_backward_rate(device, reps=200):
   def forward_backward():
     thf = planner.forward(thr, start, goal, None, sdf_leaf.expand(B, 1, GRID, GRID))[0]
     torch.autograd.grad(thf, (thr, sdf_leaf), g)
+
+  # ... and the two launches behind it on their own (C-ABI, HIP events): the traced fused loop and the chain backward
+  from dgpmp2_amd import _capi
+  sv = planner.plan_layer._solver(torch.float32)
+  hist = torch.empty((GN_ITERS, B, n, 4), dtype=torch.float64, device=device)
+  tho = torch.empty_like(th0); its = torch.zeros(B, dtype=torch.int32, device=device); inf = torch.zeros(B, dtype=torch.int32, device=device)
+  gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
+  sarg = sv.sdf_arg(sdf.data_ptr(), GRID, GRID, 0)
+  raw = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  k_fwd = time_launches(lambda k: sv.gn_solve_traced(B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sarg, None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(),
+                                                     None, None, None, inf.data_ptr(), hist.data_ptr(), raw), 100, warm_s=0.1)
+  k_bwd = time_launches(lambda k: sv.gn_solve_backward(B, start.data_ptr(), goal.data_ptr(), sarg, GN_ITERS, hist.data_ptr(), tho.data_ptr(), its.data_ptr(),
+                                                       g.data_ptr(), gth.data_ptr(), gst.data_ptr(), ggo.data_ptr(), None, 0, raw), 100, warm_s=0.1)
 
   a, b = wall(static_fb), wall(learned_fb)
   t2, t1 = wall(train_iteration_two_calls), wall(train_iteration_fused)
@@ -461,9 +476,11 @@ def planner_api_backward_rate(device, reps=200):
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '
                                           'C-ABI call each way: dgp_gn_step_errors / dgp_gn_step_errors_backward, two stream-ordered launches each)'},
           'forward_backward_fused': {'us_per_call': fb, 'us_per_gn_iteration': fb / GN_ITERS, 'gn_iterations': GN_ITERS,
+                                     'kernel_us': {'dgp_gn_solve_traced': k_fwd, 'dgp_gn_solve_backward': k_bwd, 'per_gn_iteration': (k_fwd + k_bwd) / GN_ITERS},
                                      'note': 'DiffGPMP2Planner.forward with requires_grad inputs + torch.autograd.grad through all 10 iterations w.r.t. the '
-                                             'initial trajectory and the grid: dgp_gn_solve_traced + dgp_gn_solve_backward, one launch each (wall, host '
-                                             'side of forward() -- the history copy and python lists -- included)'},
+                                             'initial trajectory and the grid: dgp_gn_solve_traced + dgp_gn_solve_backward, one launch each (us_per_call: wall, with '
+                                             'the host side of forward() -- one device-to-host copy of the per-sample errors, which waits for the forward launch, and the '
+                                             'reference API\'s python lists; kernel_us: the two launches by HIP events, no grid gradient)'},
           'note': 'wall time of DiffGPMP2Planner.step() + torch.autograd.grad through it, B=4096: static covariances with the gradient w.r.t. the '
                   'trajectory (us_per_call), and per-state qc_inv / obscov_inv / eps tensors with gradients w.r.t. all four (learned_covariances_us_per_call); '
                   'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine.  tbptt_window10_us_per_step: ten chained steps '

@@ -50,7 +50,7 @@ inline int fail(int code, const char* fmt, ...) {
 // Shapes the kernels are instantiated for (see DGP_FOR_EACH_SHAPE in dgpmp2_hip.hip): LPT in {16,32,64} x C in {1,2,4}.
 constexpr int kMaxStates = 256;
 // Longer trajectories run the loop kernels of gn_long.h (one trajectory per wavefront, ceil(n / 64) rows per lane), whose limit is the
-// wavefront's LDS block of (rows per lane - 1) parked (S_k^-1, z_k) slots: 16 rows per lane for d = 4 (105 KB), 10 for d = 6 (123 KB).
+// wavefront's LDS block of (rows per lane - 1) parked (S_k^-1, z_k) slots: 16 rows per lane for d = 4 (105 KB), 10 for d = 6 (127 KB = dgp::long_lds_bytes<6>(640)).
 constexpr int kMaxStatesLong4 = 1024, kMaxStatesLong6 = 640;
 inline int max_states(int dof) { return dof == 3 ? kMaxStatesLong6 : kMaxStatesLong4; }
 inline bool is_long(int n) { return n > kMaxStates; }

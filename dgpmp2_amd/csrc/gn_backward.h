@@ -89,6 +89,12 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
     }
 }
 
+// LDS parking level of the adjoint solve's Woodbury elimination (gn_woodbury.h, PARK): the chain kernels also hold the running cotangent in LDS and
+// leave L of S in registers, as the fused forward loop does -- four workgroups must fit the CU's 160 KB
+template <int DOF, bool CHAIN> struct BwdParks {
+  static constexpr int value = WbParks<DOF, MODE_BACKWARD_SOLVE>::value == 0 ? 0 : (CHAIN ? 2 : WbParks<DOF, MODE_BACKWARD_SOLVE>::value);
+};
+
 // CHAIN = false: the backward of ONE Gauss-Newton step (dgp_gn_step_backward, dgp_eval_errors_backward).
 // CHAIN = true : the backward of the fused loop (dgp_gn_solve_backward): th_{k+1} = th_k + dtheta(th_k), k = 0 .. iters[b]-1, reversed inside the
 //   kernel -- the running cotangent g (gradient w.r.t. th_{k+1}) stays in registers, every pass re-assembles Lambda(th_k) from the forward loop's
@@ -148,14 +154,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
   if (gp.g_dtheta) load_rows(gp.g_dtheta, gbar);
   // dgp_gn_step_errors_backward: the gradient w.r.t. th + dtheta that the errors' backward left behind joins the dtheta cotangent
-  // (th + dtheta depends on dtheta with a unit Jacobian) and, further down, the trajectory gradient (and on th likewise)
-  double gnew[(!CHAIN) ? C : 1][D];
+  // (th + dtheta depends on dtheta with a unit Jacobian) and, further down, the trajectory gradient (and on th likewise).  Both uses re-read it
+  // from memory behind a wave-uniform branch: the plain step backward pays a scalar test, not sixteen registers
   if constexpr (!CHAIN) {
-#pragma unroll
-    for (int k = 0; k < C; ++k)
-#pragma unroll
-      for (int a = 0; a < D; ++a) gnew[k][a] = 0.0;
-    if (gp.g_th_new) {              // wave-uniform
+    if (gp.g_th_new) {
+      double gnew[C][D];
       load_rows(gp.g_th_new, gnew);
 #pragma unroll
       for (int k = 0; k < C; ++k)
@@ -178,31 +181,28 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     for (int m = 32; m >= 1; m >>= 1) { const int o = cx.fetch_i(mx, lane ^ m); mx = o > mx ? o : mx; }
     passes = mx;
   }
+  // CHAIN: the running cotangent lives in lane-private LDS slots (cx.chain_lds()) between its two uses in a pass -- right-hand side of the adjoint
+  // solve at the top, g += J^T g row by row at the bottom -- instead of in 2 C d registers across the solve and the chain rule
+  if constexpr (CHAIN) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) lds_put_row_at<C, D>(cx.chain_lds(), lane, k, gbar[k]);
+  }
   bool first_pass = true;
 #pragma unroll 1
   for (int it = passes - 1; it >= 0; --it) {
   bool pass_on = true;             // CHAIN: did this trajectory run iteration `it`
-  double xnext[CHAIN ? C : 1][D];
   if constexpr (CHAIN) {
     pass_on = it < my_iters;
-    // th_it (the history; a trajectory that sits this pass out reads its FINAL trajectory instead: valid data, and its cotangent is zeroed below)
-    // and th_{it+1} (the next history row, or th_final behind the last iteration)
+    // th_it from the history; a trajectory that sits this pass out reads its FINAL trajectory instead (valid data; its cotangent is zeroed below)
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const bool valid = traj_ok && g0 + k < n;
       const int64_t row = valid ? b * n + g0 + k : 0;
       const double* h0 = gp.th_hist + ((int64_t)it * p.B * n + row) * D;
-      const double* h1 = gp.th_hist + ((int64_t)(it + 1) * p.B * n + row) * D;
       double fin[D];
       ld_row<IO, D>(gp.th_final, row, vec, fin);
-      const bool last = it + 1 >= my_iters;
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        const double v0 = pass_on ? h0[a] : fin[a];
-        const double v1 = (pass_on && !last) ? h1[a] : fin[a];
-        x[k][a] = valid ? v0 : 0.0;
-        xnext[k][a] = valid ? v1 : 0.0;
-      }
+      for (int a = 0; a < D; ++a) x[k][a] = valid ? (pass_on ? h0[a] : fin[a]) : 0.0;
     }
   }
   // ---- lambda = Lambda^-1 gbar (skipped, wave-uniformly, when there is no dtheta cotangent)
@@ -212,7 +212,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     auto solve = [&](const double (&rhs)[C][D]) {
       if constexpr (is_wb(QK)) {
         static_assert(C == 4, "the Woodbury kernels are built for four states per lane");
-        gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR), false, WbParks<DOF, MODE_BACKWARD_SOLVE>::value>(
+        gn_linear_solve_wb<DOF, LPT, IO, true, DGP_BWD_COLWISE(D), (QK == QK_WBR), false, BwdParks<DOF, CHAIN>::value>(
             p, cx, b, j, traj_ok, x, mu_s, mu_g, rhs, lam, acc, ok, first_pass ? &wbv : nullptr, [](const ErrAcc&) {});
       } else {
         gn_linear_solve<DOF, LPT, C, IO, true, QK, SinvStashBlocks<D, C, MODE_BACKWARD_SOLVE>::value>(p, cx, b, j, traj_ok, x, mu_s, mu_g, lq, rhs, lam, acc, ok);
@@ -221,9 +221,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     if constexpr (CHAIN) {
       double rhs[C][D];            // a trajectory that did not run iteration `it` contributes nothing: zero right-hand side, lambda == 0 exactly
 #pragma unroll
-      for (int k = 0; k < C; ++k)
+      for (int k = 0; k < C; ++k) {
+        lds_get_row_at<C, D>(cx.chain_lds(), lane, k, rhs[k]);
 #pragma unroll
-        for (int a = 0; a < D; ++a) rhs[k][a] = pass_on ? gbar[k][a] : 0.0;
+        for (int a = 0; a < D; ++a) rhs[k][a] = pass_on ? rhs[k][a] : 0.0;
+      }
       solve(rhs);
     } else {
       solve(gbar);
@@ -257,10 +259,19 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
     for (int a = 0; a < D; ++a) dthr[k][a] = 0.0;
   if constexpr (CHAIN) {
+    // dtheta_it = th_{it+1} - th_it, th_{it+1} = the next history row or, behind the last iteration, th_final (zero for a trajectory that sits the
+    // pass out) -- loaded HERE, behind the solve, like the single-step kernel's dtheta rows
+    const bool last = it + 1 >= my_iters;
 #pragma unroll
-    for (int k = 0; k < C; ++k)
+    for (int k = 0; k < C; ++k) {
+      const bool valid = traj_ok && g0 + k < n;
+      const int64_t row = valid ? b * n + g0 + k : 0;
+      const double* h1 = gp.th_hist + ((int64_t)(it + 1) * p.B * n + row) * D;
+      double fin[D];
+      ld_row<IO, D>(gp.th_final, row, vec, fin);
 #pragma unroll
-      for (int a = 0; a < D; ++a) dthr[k][a] = xnext[k][a] - x[k][a];      // dtheta_it = th_{it+1} - th_it (zero for a trajectory that sits the pass out)
+      for (int a = 0; a < D; ++a) dthr[k][a] = valid ? ((pass_on && !last) ? h1[a] : fin[a]) - x[k][a] : 0.0;
+    }
   } else {
     if (have_gbar) load_rows(gp.dtheta, dthr);
   }
@@ -307,7 +318,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         if constexpr (CHAIN) {
           if (is_start) gacc_s[a] += t; else gacc_g[a] += t;
         } else {
-          if (gmu) st<IO>(gmu, b * D + a, gp.accumulate ? t + ld<IO>(gmu, b * D + a) : t);
+          if (gmu) {
+            if (gp.accumulate) st<IO>(gmu, b * D + a, t + ld<IO>(gmu, b * D + a));
+            else st<IO>(gmu, b * D + a, t);
+          }
         }
       }
     }
@@ -428,7 +442,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
           tap_i[k][3] = (int32_t)tp.i22; tap_v[k][3] = (IO)(al * (tp.wjb * ir) + be * (-tp.wjd * ir) - ga * wd);
         }
       }
-      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, gp.accumulate ? g_eps + ld<IO>(gp.g_eps, b * n + g) : g_eps);
+      if (gp.g_eps) {
+        if (gp.accumulate) st<IO>(gp.g_eps, b * n + g, g_eps + ld<IO>(gp.g_eps, b * n + g));
+        else st<IO>(gp.g_eps, b * n + g, g_eps);
+      }
       if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, g_w);
     }
     // ---- velocity limits: e = |v| - vmax, H = -sign(v) (piecewise constant), K = w_v
@@ -465,11 +482,18 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
     if constexpr (CHAIN) {
       // g_{th_it} = g_{th_{it+1}} + J_it^T g_{th_{it+1}}  (th_{it+1} = th_it + dtheta(th_it)); nothing to add for a pass the trajectory sat out
+      double gk[D];
+      lds_get_row_at<C, D>(cx.chain_lds(), lane, k, gk);
 #pragma unroll
-      for (int a = 0; a < D; ++a) gbar[k][a] += pass_on ? gx[a] : 0.0;
+      for (int a = 0; a < D; ++a) gk[a] += pass_on ? gx[a] : 0.0;
+      lds_put_row_at<C, D>(cx.chain_lds(), lane, k, gk);
     } else if (gp.g_th) {
+      if (gp.g_th_new) {             // (dgp_gn_step_errors_backward: the errors' share of the trajectory gradient)
+        double t[D];
+        ld_row<IO, D>(gp.g_th_new, b * n + g, vec, t);
 #pragma unroll
-      for (int a = 0; a < D; ++a) gx[a] += gnew[k][a];                 // (zero unless dgp_gn_step_errors_backward passed the errors' share)
+        for (int a = 0; a < D; ++a) gx[a] += t[a];
+      }
       if (block_rows) {
         if constexpr (kBlockRows) {
 #pragma unroll
@@ -495,7 +519,9 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
     for (int k = 0; k < C; ++k) {
       const int g = g0 + k;
-      if (traj_ok && g < n && gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gbar[k]);
+      double gk[D];
+      lds_get_row_at<C, D>(cx.chain_lds(), lane, k, gk);
+      if (traj_ok && g < n && gp.g_th) st_row<IO, D>(gp.g_th, b * n + g, vec, gk);
     }
     if (traj_ok && g0 == 0 && gp.g_start) {
 #pragma unroll

@@ -17,6 +17,8 @@ struct DevCtx {
   char* stash_;    // dgp::SinvStash block (d = 6 kernels), or null
   char* wb_;       // LDS copy of the Woodbury constant table (QK_WB kernels), dgp::kWbLdsBytes
   char* long_;     // gn_long.h: the wavefront's dynamic LDS block (per-row S_k^-1, z_k slots), or null
+  char* chain_;    // the chain backward kernels: lane-private slots of the running cotangent (dgp::WaveStore<double, C, d> layout), or null
+  __device__ __forceinline__ char* chain_lds() const { return chain_; }
   __device__ __forceinline__ char* long_lds() const { return long_; }
   // writes of this wavefront to global memory become visible to its own later loads (gn_long.h: MODE_SOLVE keeps the state in th_out)
   __device__ __forceinline__ void mem_sync() const { __threadfence(); __syncthreads(); }
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
   cx.lds_ = lds;
   cx.stash_ = (MODE == dgp::MODE_SOLVE) ? lds + kRows : lds;
   cx.wb_ = lds + kLds;
+  cx.chain_ = nullptr;
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
@@ -159,7 +162,7 @@ template <int DOF, int LPT, int C, typename IO, int QK, bool CHAIN = false>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_arg, const dgp::GnGradParams g_arg) {
   // d = 4 static-covariance kernels: both argument structs read through the laundered pointer, as the fused loop does (static backward 15.0 -> 14.6 us;
   // the per-state kernel gets slower that way, 19.4 -> 19.7 us, and d = 6 was not measured: both keep the by-value reads)
-  constexpr bool kLaunder = DOF == 2 && (dgp::is_wb(QK) || QK == dgp::QK_STATIC) && !CHAIN;
+  constexpr bool kLaunder = (DOF == 2 || CHAIN) && (dgp::is_wb(QK) || QK == dgp::QK_STATIC);
   constexpr int kGOff = (int)sizeof(dgp::GnParams);                          // GnGradParams follows GnParams (both 8-byte aligned)
   static_assert(sizeof(dgp::GnParams) % 8 == 0 && alignof(dgp::GnGradParams) <= 8, "argument layout");
   const dgp::GnParams* pp = &p_arg;
@@ -176,17 +179,19 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_a
   constexpr int kPairBytes = 64 * 2 * (int)sizeof(dgp::TapEntry<IO>);        // sdf_scatter_pairs staging: two tap entries per lane
   constexpr int kRowBytes = dgp::WaveStore<IO, C, 2 * DOF>::kLdsBytes;
   // the adjoint solve's LDS: the S_k^-1 stash of the block elimination, or the parked recovery state of the Woodbury elimination (gn_woodbury.h, PARK)
-  constexpr int kStash = dgp::is_wb(QK) ? (dgp::WbParks<DOF, dgp::MODE_BACKWARD_SOLVE>::value != 0
-                                               ? dgp::LdsPark<dgp::WbParkCells<DOF, dgp::WbParks<DOF, dgp::MODE_BACKWARD_SOLVE>::value>::value>::kBytes : 0)
+  constexpr int kStash = dgp::is_wb(QK) ? (dgp::BwdParks<DOF, CHAIN>::value != 0
+                                               ? dgp::LdsPark<dgp::WbParkCells<DOF, dgp::BwdParks<DOF, CHAIN>::value>::value>::kBytes : 0)
                                         : dgp::SinvStash<2 * DOF, dgp::SinvStashBlocks<2 * DOF, C, dgp::MODE_BACKWARD_SOLVE>::value>::kBytes;
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
-  __shared__ __attribute__((aligned(16))) char lds[kAll + kWb];
+  constexpr int kChain = CHAIN ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : 0;
+  __shared__ __attribute__((aligned(16))) char lds[kAll + kWb + kChain];
   DevCtx cx;
   cx.lds_ = lds;
   cx.stash_ = lds;
   cx.wb_ = lds + kAll;
+  cx.chain_ = lds + kAll + kWb;
   dgp::gn_backward_lane_program<DOF, LPT, C, IO, QK, CHAIN>(p, g, cx);
 }
 
@@ -195,7 +200,7 @@ template <int DOF, typename IO, int MODE>
 __global__ void __launch_bounds__(64) gn_long_kernel(const dgp::GnParams p) {
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   DevCtx cx;
-  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr;
+  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr; cx.chain_ = nullptr;
   cx.long_ = dyn_lds;
   dgp::gn_long_program<DOF, IO, MODE>(p, cx);
 }
@@ -203,7 +208,7 @@ template <int DOF, typename IO>
 __global__ void __launch_bounds__(64) gn_long_backward_kernel(const dgp::GnParams p, const dgp::GnGradParams g) {
   extern __shared__ __attribute__((aligned(16))) char dyn_lds[];
   DevCtx cx;
-  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr;
+  cx.lds_ = nullptr; cx.stash_ = nullptr; cx.wb_ = nullptr; cx.chain_ = nullptr;
   cx.long_ = dyn_lds;
   dgp::gn_long_backward_program<DOF, IO>(p, g, cx);
 }

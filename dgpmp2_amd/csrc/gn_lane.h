@@ -2818,6 +2818,22 @@ DGP_HD void lds_get_rows(Ctx& cx, double (&v)[C][D]) {
   }
 }
 
+// the same slots at another base address, one row at a time (the chain backward's running cotangent, gn_backward.h)
+template <int C, int D>
+DGP_HD void lds_put_row_at(char* base, int lane, int k, const double (&v)[D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  char* l = base + lane * WaveStore<double, C, D>::kStride + k * D * 8;
+#pragma unroll
+  for (int i = 0; i < D / 2; ++i) { V2 t; t[0] = v[2 * i]; t[1] = v[2 * i + 1]; *(V2*)(l + i * 16) = t; }
+}
+template <int C, int D>
+DGP_HD void lds_get_row_at(const char* base, int lane, int k, double (&v)[D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  const char* l = base + lane * WaveStore<double, C, D>::kStride + k * D * 8;
+#pragma unroll
+  for (int i = 0; i < D / 2; ++i) { const V2 t = *(const V2*)(l + i * 16); v[2 * i] = t[0]; v[2 * i + 1] = t[1]; }
+}
+
 }  // namespace dgp
 #include "gn_woodbury.h"
 namespace dgp {

@@ -1,12 +1,30 @@
 // gn_long_inst.hip -- the long-trajectory kernels (gn_long.h, n > 256) of every (dof, io dtype) and their launcher.
 #include "gn_device.h"
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace {
 
+// more than 64 KB of dynamic LDS needs the attribute (gfx950: up to 160 KB per workgroup).  Raised ONCE per kernel (and device) to the largest
+// block any trajectory length needs, not per launch: hipFuncSetAttribute is host time on every call and not a call to make under stream capture.
+constexpr int kLongLdsMax = 160 * 1024;
+template <typename K>
+hipError_t ensure_lds_limit(K kernel) {
+  static std::mutex mu;                               // (K is one function TYPE per signature, not per kernel: keyed on the kernel's address)
+  static std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  for (const auto& d : done) if (d.first == (const void*)kernel && d.second == dev) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLongLdsMax);
+  if (e == hipSuccess) done.emplace_back((const void*)kernel, dev);
+  return e;
+}
+
 template <typename K, typename... A>
 hipError_t launch_dyn(K kernel, int lds_bytes, int B, hipStream_t s, const A&... args) {
-  // more than 64 KB of dynamic LDS needs the attribute (gfx950: up to 160 KB per workgroup)
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  hipError_t e = ensure_lds_limit(kernel);
   if (e != hipSuccess) return e;
   dgp_host::LaunchEvents& le = dgp_host::launch_events();
   const hipEvent_t ev0 = (hipEvent_t)le.start, ev1 = (hipEvent_t)le.stop;

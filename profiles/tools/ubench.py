@@ -90,6 +90,15 @@ def main():
       tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev); eh = torch.empty(B, a.iters, device=dev, dtype=dt)
       eeh = torch.empty_like(eh)
       f = lambda k: s.gn_solve(B, tp[0], P(start), P(goal), sa, covs, a.iters, 0.0, P(tho), P(it), P(eh), P(eeh), None, P(info), st)
+    elif what in ('traced', 'chain'):
+      # dgp_gn_solve_traced (the fused loop + its fp64 history) / dgp_gn_solve_backward (the whole loop's backward, one launch); static covariances
+      tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev)
+      hist = torch.empty((a.iters, B, n, d), dtype=torch.float64, device=dev)
+      gfin = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
+      trace = lambda k: s.gn_solve_traced(B, tp[0], P(start), P(goal), sa, None, a.iters, 0.0, P(tho), P(it), None, None, None, P(info), P(hist), st)
+      trace(0)
+      if what == 'traced': f = trace
+      else: f = lambda k: s.gn_solve_backward(B, P(start), P(goal), sa, a.iters, P(hist), P(tho), P(it), P(gfin), P(gth), P(gst), P(ggo), None, 0, st)
     elif what == 'eval':
       f = lambda k: s.eval_errors(B, tp[k % 4], P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st)
     elif what.startswith('bwd'):
@@ -106,11 +115,11 @@ def main():
                                        P(gq), P(gw), P(gp), st, g_sdf_copies=copies)
     else:
       raise SystemExit('unknown --what ' + what)
-    reps = a.reps if what != 'solve' else max(20, a.reps // a.iters)
+    reps = a.reps if what not in ('solve', 'traced', 'chain') else max(20, a.reps // a.iters)
     period, kmean, kmed = measure(f, reps, timer)
     out[what] = dict(period_us=period, kernel_us=kmean, kernel_med_us=kmed)
     if what == 'step': out[what]['alg_GBs'] = round(by / (kmean * 1e-6) / 1e9, 1)
-    if what == 'solve': out[what]['us_per_iter'] = round(kmean / a.iters, 2)
+    if what in ('solve', 'traced', 'chain'): out[what]['us_per_iter'] = round(kmean / a.iters, 2)
   print(json.dumps(out), flush=True)
 
 

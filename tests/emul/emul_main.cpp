@@ -22,6 +22,7 @@ struct WaveShared {
   int islot[64];
   alignas(16) char lds[64 * (4 * 6 * 8 + 16) + 64 * 544];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64) + dgp::SinvStash
   alignas(16) char wb[dgp::kWbLdsBytes];                        // LDS copy of the Woodbury constant table
+  alignas(16) char chain[64 * (4 * 6 * 8 + 16)];                // the chain backward's running cotangent (dgp::WaveStore<double, 4, 6> layout, the largest)
   alignas(16) char longb[160 * 1024];                           // gn_long.h: the dynamic LDS block of the long-trajectory kernels (gfx950: 160 KB per workgroup)
 };
 
@@ -35,6 +36,7 @@ struct HostCtx {
   char* lds() { return ws->lds; }
   char* stash() { return ws->lds + 64 * (4 * 6 * 8 + 16); }
   char* wb_lds() { return ws->wb; }
+  char* chain_lds() { return ws->chain; }
   char* long_lds() { return ws->longb; }
   void mem_sync() { pthread_barrier_wait(&ws->bar); }
   const double* wb_source(const dgp::GnParams& p) const { return p.wb_tab; }
