@@ -2260,10 +2260,13 @@ template <int D, int C, int MODE> struct SinvStashBlocks {
   // Round 3, STEP kernels with four states per lane (block elimination: static with velocity limits, per-state, general): TWO blocks parked --
   // per-state 48.1 -> 44.7 us (one block 45.5, three 48.3), static + velocity limits 30.6 -> 29.3 us, q_full (16,4) 85.4 -> 83.7 us; the two-states-per-lane
   // shapes do not react, and the fused loop loses with one block or two (profiles/r03_kernel_variants.txt).
+#ifndef DGP_STASH_STEP_D4
+#define DGP_STASH_STEP_D4 0
+#endif
 #ifndef DGP_STASH_STEP_D6
 #define DGP_STASH_STEP_D6 2
 #endif
-  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : ((D == 6 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D6 : 0);
+  static constexpr int kWant = (D == 6 && MODE == MODE_BACKWARD_SOLVE) ? 3 : ((D == 6 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D6 : ((D == 4 && MODE == MODE_STEP && C == 4) ? DGP_STASH_STEP_D4 : 0));
   static constexpr int value = kWant < kInterior ? kWant : kInterior;
 };
 template <int D, int NS> struct SinvStash {

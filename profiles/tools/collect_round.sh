@@ -11,6 +11,9 @@ cd "$R"
 (timeout 1500 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
 timeout 600 python bench.py --steps 20 --warmup 5 2>/dev/null | grep -a '^{' > "$O/bench_driver_invocation.json"
 timeout 600 python bench.py 2>/dev/null | grep -a '^{' > "$O/bench_default.json"
+for i in 2 3; do timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep -a '^{' > "$O/bench_driver_invocation_run$i.json"; done
+HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2>/dev/null | grep -a '^{' > "$O/bench_dist_world1.json"
 cd /tmp && export TMPDIR=/tmp
 # the driver's command with --no-extras: the extra workload blocks launch the SAME kernel symbol on other inputs (per-sample grids,
 # velocity limits), so only this trace gives the headline workload's own average; the full command's trace is kept next to it
@@ -29,7 +32,7 @@ U="python profiles/tools/ubench.py"
 ( $U --what step,solve,eval,bwd,bwd_sdf8,bwd_sdf16; DGP_NO_WOODBURY=1 $U --what step,solve,bwd --tag block_elimination; $U --what step,solve,bwd,bwd_sdf16 --covs perstate; $U --what step,solve,bwd --covs qfull; $U --what step,solve,bwd --dof 3;
   DGP_NO_WOODBURY=1 $U --what step,solve,bwd --dof 3 --tag block_elimination; $U --what step,solve --dof 3 --covs perstate; $U --what step --B 32768; $U --what step --n 128 --B 2048; $U --what step --n 256 --B 1024;
   $U --what step --flags vel; $U --what step,bwd,bwd_sdf --sdf persample --grids 6; $U --what step --sdf persample --grids 1; $U --what bwd,bwd_sdf8,bwd_sdf16 --th 0 --tag straight_line_init;
-  $U --what step,bwd --io f64 ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
+  $U --what step,bwd --io f64; $U --what traced,chain; $U --what traced,chain --dof 3; $U --what solve,traced,chain --io f64 ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
 # probes: built HERE before the call (profiles/tools/build_probes.sh cross-compiles them into dgpmp2_amd/lib/, which travels with the snapshot)
 ./dgpmp2_amd/lib/atomic_probe > "$O/atomic_probe.txt" 2>&1
 ./dgpmp2_amd/lib/mfma_probe > "$O/mfma_probe.txt" 2>&1
