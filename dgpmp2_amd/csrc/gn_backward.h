@@ -176,6 +176,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #pragma unroll
     for (int a = 0; a < D; ++a) { gacc_s[a] = 0.0; gacc_g[a] = 0.0; }
     my_iters = traj_ok ? gp.iters[b] : 0;
+    my_iters = my_iters < 0 ? 0 : (my_iters > gp.chain_iters ? gp.chain_iters : my_iters);      // (device data the host cannot validate: never walk past the history)
     int mx = my_iters;                                     // passes = the most iterations any trajectory of this wavefront ran
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { const int o = cx.fetch_i(mx, lane ^ m); mx = o > mx ? o : mx; }
@@ -266,7 +267,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     for (int k = 0; k < C; ++k) {
       const bool valid = traj_ok && g0 + k < n;
       const int64_t row = valid ? b * n + g0 + k : 0;
-      const double* h1 = gp.th_hist + ((int64_t)(it + 1) * p.B * n + row) * D;
+      const int it1 = it + 1 < gp.chain_iters ? it + 1 : gp.chain_iters - 1;      // (never read past the last history row, not even speculatively: behind the last iteration th_final is used)
+      const double* h1 = gp.th_hist + ((int64_t)it1 * p.B * n + row) * D;
       double fin[D];
       ld_row<IO, D>(gp.th_final, row, vec, fin);
 #pragma unroll

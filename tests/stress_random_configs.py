@@ -118,10 +118,12 @@ for case in range(args.cases):
     print('%3d %s dof=%d n=%3d B=%4d %s shape=%s sdf=%dx%d%s cov=%s Qc=%s flags=%s  dth %.1e err %.1e' % (case, status, dof, n, B, io, forced or 'auto', H, W, '(per-sample)' if per_sample else '', cov, qmode,
           ','.join(k for k in ('non_holonomic', 'use_vel_limits') if k in kw), e, ee), flush=True)
     assert not status.startswith('FAIL'), status
-  if case % 3 == 0 and ok.all():      # the fused loop (dgp_gn_solve) on the same configuration
+  # (not for n > 256 with fp32 I/O: the loop kernels keep the fused loop's state in th_out, i.e. rounded to fp32 between iterations, so neither the f64-I/O
+  #  loop nor a host-side chain of f32 steps -- which rounds dtheta AND the sum -- is a reference at better than cond(Lambda) x 6e-8 per iteration;
+  #  tests/parity_cases.py::case_long_trajectories pins that path)
+  if case % 3 == 0 and ok.all() and not (io == 'f32' and n > 256):      # the fused loop (dgp_gn_solve) on the same configuration
     tho, its, eh, eeh, ef, sinfo = be.solve(p, th, start, goal, sdf, 3, 0.0, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
-    long_f32 = (io == 'f32' and n > 256)      # the loop kernels keep the fused loop's state in th_out, i.e. in the I/O type: their f32 loop IS a chain of f32 steps
-    if io == 'f64' or long_f32:       # three iterations == three chained steps
+    if io == 'f64':                   # three iterations == three chained steps
       cur = th.copy(); good = True
       for k in range(3):
         d_k, e_k, _, i_k = be.step(p, cur, start, goal, sdf, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
@@ -134,7 +136,7 @@ for case in range(args.cases):
       good = not i2.any() and np.all(np.isfinite(cur)); ref_name = 'the f64-I/O fused loop on the same fp32-rounded inputs'    # that); compare the two I/O builds
     if good and not sinfo.any():
       es = np.abs(tho - cur).max() / (np.abs(cur).max() + 1e-300)
-      assert es < (1e-7 if io == 'f64' else (1e-4 if long_f32 else 1e-5)) * (30 if p.reg < 0.01 else 1), ('fused loop differs from ' + ref_name, case, es, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, qmode=qmode, reg=p.reg, flags=kw))
+      assert es < (1e-7 if io == 'f64' else 1e-5) * (30 if p.reg < 0.01 else 1), ('fused loop differs from ' + ref_name, case, es, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, qmode=qmode, reg=p.reg, flags=kw))
   # the backward kernel of the same configuration against an INDEPENDENT gradient oracle: torch autograd over the dense restatement of
   # the reference's step (oracle/autograd_torch.py; pinned to the reference's own autograd fixtures) -- every backward variant, on
   # batches small enough for the dense solve

@@ -43,6 +43,15 @@ def _worker(rank, world, port, B, n, iters, q):
   sdf_b = sdf.expand(B, 1, 64, 64)                       # shared grid as an expand()ed view: must not be sliced per rank
   full = parallel.plan_sharded(_solve_fn(n, iters), th, start, goal, sdf_b)
   lo, hi = parallel.shard_range(B, rank, world)
+  # the same gather into a buffer allocated once (what a loop that gathers every outer iteration, and bench.py's timed regions, do)
+  buf = parallel.gather_buffer(full[lo:hi], B)
+  again = parallel.all_gather_trajectories(full[lo:hi].clone(), B, out=buf)
+  assert torch.equal(again, full) and (again.data_ptr() == buf.data_ptr() or B % world != 0)
+  try:
+    parallel.all_gather_trajectories(full[lo:hi], B, out=buf[:-1])
+    raise AssertionError('a wrongly sized out= buffer must be rejected')
+  except ValueError:
+    pass
   q.put((rank, lo, hi, full.numpy()))
   dist.barrier()
   dist.destroy_process_group()
