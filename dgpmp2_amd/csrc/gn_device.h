@@ -17,7 +17,7 @@ struct DevCtx {
   char* stash_;    // dgp::SinvStash block (d = 6 kernels), or null
   char* wb_;       // LDS copy of the Woodbury constant table (QK_WB kernels), dgp::kWbLdsBytes
   char* long_;     // gn_long.h: the wavefront's dynamic LDS block (per-row S_k^-1, z_k slots), or null
-  char* chain_;    // the chain backward kernels: lane-private slots of the running cotangent (dgp::WaveStore<double, C, d> layout), or null
+  char* chain_;    // the chain backward kernels: lane-private slots of the running cotangent and the accumulated start / goal gradients (dgp::ChainSlots<C, d>), or null
   __device__ __forceinline__ char* chain_lds() const { return chain_; }
   __device__ __forceinline__ char* long_lds() const { return long_; }
   // writes of this wavefront to global memory become visible to its own later loads (gn_long.h: MODE_SOLVE keeps the state in th_out)
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_a
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
-  constexpr int kChain = CHAIN ? dgp::WaveStore<double, C, 2 * DOF>::kLdsBytes : 0;
+  constexpr int kChain = CHAIN ? dgp::ChainSlots<C, 2 * DOF>::kBytes : 0;
   __shared__ __attribute__((aligned(16))) char lds[kAll + kWb + kChain];
   DevCtx cx;
   cx.lds_ = lds;

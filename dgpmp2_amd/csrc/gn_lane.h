@@ -2821,20 +2821,27 @@ DGP_HD void lds_get_rows(Ctx& cx, double (&v)[C][D]) {
   }
 }
 
-// the same slots at another base address, one row at a time (the chain backward's running cotangent, gn_backward.h)
+// Lane-private LDS slots of the chain backward kernels (gn_backward.h, cx.chain_lds()): the running cotangent's C rows and the two accumulated
+// mean gradients (start, goal), d doubles each; lane stride an odd number of 16-byte cells (conflict-free 128-bit accesses).  Vector index v:
+// 0 .. C-1 the rows, C the start gradient, C + 1 the goal gradient.
+template <int C, int D> struct ChainSlots {
+  static constexpr int kCells = (C + 2) * D / 2;
+  static constexpr int kStride = ((kCells % 2) ? kCells : kCells + 1) * 16;
+  static constexpr int kBytes = 64 * kStride;
+};
 template <int C, int D>
-DGP_HD void lds_put_row_at(char* base, int lane, int k, const double (&v)[D]) {
+DGP_HD void chain_put(char* base, int lane, int v, const double (&x)[D]) {
   typedef double V2 __attribute__((vector_size(16)));
-  char* l = base + lane * WaveStore<double, C, D>::kStride + k * D * 8;
+  char* l = base + lane * ChainSlots<C, D>::kStride + v * D * 8;
 #pragma unroll
-  for (int i = 0; i < D / 2; ++i) { V2 t; t[0] = v[2 * i]; t[1] = v[2 * i + 1]; *(V2*)(l + i * 16) = t; }
+  for (int i = 0; i < D / 2; ++i) { V2 t; t[0] = x[2 * i]; t[1] = x[2 * i + 1]; *(V2*)(l + i * 16) = t; }
 }
 template <int C, int D>
-DGP_HD void lds_get_row_at(const char* base, int lane, int k, double (&v)[D]) {
+DGP_HD void chain_get(const char* base, int lane, int v, double (&x)[D]) {
   typedef double V2 __attribute__((vector_size(16)));
-  const char* l = base + lane * WaveStore<double, C, D>::kStride + k * D * 8;
+  const char* l = base + lane * ChainSlots<C, D>::kStride + v * D * 8;
 #pragma unroll
-  for (int i = 0; i < D / 2; ++i) { const V2 t = *(const V2*)(l + i * 16); v[2 * i] = t[0]; v[2 * i + 1] = t[1]; }
+  for (int i = 0; i < D / 2; ++i) { const V2 t = *(const V2*)(l + i * 16); x[2 * i] = t[0]; x[2 * i + 1] = t[1]; }
 }
 
 }  // namespace dgp

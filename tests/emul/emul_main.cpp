@@ -22,7 +22,7 @@ struct WaveShared {
   int islot[64];
   alignas(16) char lds[64 * (4 * 6 * 8 + 16) + 64 * 544];      // dgp::WaveStore staging block (largest chunk: C=4, d=6, f64) + dgp::SinvStash
   alignas(16) char wb[dgp::kWbLdsBytes];                        // LDS copy of the Woodbury constant table
-  alignas(16) char chain[64 * (4 * 6 * 8 + 16)];                // the chain backward's running cotangent (dgp::WaveStore<double, 4, 6> layout, the largest)
+  alignas(16) char chain[dgp::ChainSlots<4, 6>::kBytes];         // the chain backward's running cotangent + accumulated start / goal gradients (the largest layout)
   alignas(16) char longb[160 * 1024];                           // gn_long.h: the dynamic LDS block of the long-trajectory kernels (gfx950: 160 KB per workgroup)
 };
 

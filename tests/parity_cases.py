@@ -670,6 +670,29 @@ def case_solve_backward(be, golden, io):
   else:
     for k, key in (('th', 'g_th0'), ('start', 'g_start'), ('goal', 'g_goal')):
       assert rel_err(r[k], g[key]) < 2e-3, (k, rel_err(r[k], g[key]))
+  if io != 'f64': return
+  # the (x, y, theta) robot with its non-holonomic factor (the reference cannot run it in batch): the chain kernel -- whose d = 6 instantiations
+  # keep their accumulators in LDS and re-read means and rows per pass -- against the single-step backward chained by hand
+  gg = golden('g3_c4_xyh')
+  th6, st6, go6 = gg['th'][:3], gg['start'][:3], gg['goal'][:3]
+  n6 = th6.shape[1]
+  p6 = O.OracleParams(dof=3, total_time_step=n6 - 1, non_holonomic=True, epsilon_dist=0.2, reg=0.05)
+  sdf6 = O.circles_sdf(int(gg['G']), gg['circles'])[None, None]
+  d0 = be.step(p6, th6, st6, go6, sdf6, io=io)[0]
+  nrm = np.sqrt((d0.reshape(3, -1) ** 2).sum(1))
+  K6 = 3
+  tho6, its6, hist6, info6 = be.solve_traced(p6, th6, st6, go6, sdf6, K6, float(np.sort(nrm)[0] * 1.01), io=io)       # one trajectory stops after its first iteration
+  assert not info6.any() and its6.min() == 1 and its6.max() == K6
+  gb6 = np.random.RandomState(8).randn(*th6.shape)
+  r6 = be.solve_backward(p6, st6, go6, sdf6, K6, hist6, tho6, its6, gb6, io=io)
+  gcur = gb6.copy(); a_s = np.zeros_like(st6); a_g = np.zeros_like(go6); a_f = np.zeros_like(sdf6)
+  for k in range(K6 - 1, -1, -1):
+    on = its6 > k
+    thk = np.where(on[:, None, None], np.nan_to_num(hist6[k]), tho6)
+    nxt = np.where((its6 > k + 1)[:, None, None], np.nan_to_num(hist6[min(k + 1, K6 - 1)]), tho6)
+    one = be.backward(p6, thk, st6, go6, sdf6, nxt - thk, gcur * on[:, None, None], None, io=io)
+    gcur = gcur + one['th'] * on[:, None, None]; a_s += one['start'] * on[:, None, None]; a_g += one['goal'] * on[:, None, None]; a_f += one['sdf']
+  assert rel_err(r6['th'], gcur) < 1e-9 and rel_err(r6['start'], a_s) < 1e-9 and rel_err(r6['goal'], a_g) < 1e-9 and rel_err(r6['sdf'], a_f) < 1e-7
 
 
 ALL_CASES.append(case_solve_backward)
