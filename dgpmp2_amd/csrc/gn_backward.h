@@ -259,6 +259,31 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     }
   }
   first_pass = false;
+  // d = 6 block-elimination kernels (bit QK of DGP_BWD_RELOAD_D6; round 4): th and the start / goal means are read AGAIN behind the adjoint solve
+  // (L2 hits) instead of being carried through it in 2 C d + 4 d registers.  Measured at B = 4096 (profiles/r04_kernel_variants.txt): static
+  // covariances with velocity limits 64.0 -> 54.2 us (scratch 848 -> 408 B per lane), q_full tensors 122.9 -> 101.7 us; the per-state
+  // (Kronecker) kernel 68.0 -> 69.3 and the Woodbury kernel 36.7 -> 37.6 us lose and keep their rows in registers.
+#ifndef DGP_BWD_RELOAD_D6
+#define DGP_BWD_RELOAD_D6 3      // QK_GENERAL | QK_STATIC
+#endif
+  if constexpr (!CHAIN && D == 6 && !is_wb(QK) && (((DGP_BWD_RELOAD_D6) >> QK) & 1) != 0) {
+    if (have_gbar) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" ::: "memory");
+#endif
+      load_rows(p.th, x);
+      if (gp.th_addend) {
+        double dq[C][D];
+        load_rows(gp.th_addend, dq);
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+#pragma unroll
+          for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)x[k][a] + (IO)dq[k][a]);
+      }
+      ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
+      ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
+    }
+  }
   if constexpr (kLean) {
     // d = 6: the trajectory rows are read again behind the adjoint solve (L2 hits) instead of being carried through it in 2 C d registers
 #if defined(__HIP_DEVICE_COMPILE__)
