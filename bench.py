@@ -15,8 +15,10 @@ reported as `prewarm_s`): a cold MI355X runs the first milliseconds ~12 % slower
 The timed region -- synchronise, EXACTLY K launches, synchronise -- is repeated R times (9 <= R <= 41, about 0.4 s in all; each
 repetition is the whole region, nothing skipped) and `value` is K / the MEDIAN region: one 0.2 ms window right after an idling
 synchronisation is decided by a single 40-70 us hiccup (`regions` in the JSON holds min / quartiles / max and the first region).
-`roofline` is computed from the dominant kernel's own average duration (per-launch begin / end HIP events on the launch stream,
-`kernel_avg_ms`), which is what rocprofv3 --kernel-trace reports; the region's event span per launch is a separate field.
+`roofline` is computed from the dominant kernel's average duration in the regime it is benchmarked in (`kernel_avg_ms`: HIP events on
+the launch stream around 2000 back-to-back launches / 2000, median of three passes), which is what rocprofv3 --kernel-trace --stats
+reports as the kernel's average for this command; the mean over launches that each record their own begin / end events
+(`kernel_isolated_avg_ms`) and the event span of a K-launch region per launch (`region_span_ms_per_launch`) are separate fields.
 N > 1 is launched by the driver with torch.distributed.run, one rank per GPU (RCCL): every rank owns its own 4096
 trajectories (weak scaling, no data-path collective); the only collective is one all-gather of the final trajectories
 at the end of each timed region, through the product's helper dgpmp2_amd.parallel.all_gather_trajectories into a
@@ -664,12 +666,15 @@ def main():
         'regions': regions,
         'kernel_events': {'launches': int(kdur.size), 'mean_ms': float(kdur.mean()), 'median_ms': float(np.median(kdur)),
                           'note': 'per-launch begin/end events (dgp_time_next_launch), a separate pass after the timed regions'},
-        'roofline': roofline_block(bytes_per_launch, kernel_ms * 1e3, kname, traffic_key='gn_step',
-                                   note='kernel_avg_ms = mean duration of the dominant kernel over 1000 launches, each recording its own begin / end HIP events on the '
-                                        'launch stream (what rocprofv3 --kernel-trace calls the kernel\'s duration: profiles/r04_kernel_trace.txt); HBM is the bound SURVEY '
-                                        '8(d) prescribes, the measured limiter is fp64 VALU issue (see valu_fp64 and DESIGN.md section 5)'),
+        'roofline': roofline_block(bytes_per_launch, period_ms * 1e3, kname, traffic_key='gn_step',
+                                   note='kernel_avg_ms = the dominant kernel\'s average duration in the regime it is benchmarked in -- HIP events on the launch stream around 2000 '
+                                        'back-to-back launches / 2000, median of three passes -- which is what rocprofv3 --kernel-trace --stats reports as its average for this '
+                                        'command (profiles/r04_kernel_trace.txt: within 2 % on every box so far); kernel_isolated_avg_ms = mean over 1000 launches that each record '
+                                        'their OWN begin / end events (dgp_time_next_launch): such launches dispatch ~5 us apart, every kernel starts on an idle GPU without '
+                                        'overlapping its predecessor\'s tail, and runs 2-5 % longer.  HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU '
+                                        'issue (see valu_fp64 and DESIGN.md section 5)'),
     }
-    out['roofline']['launch_period_ms'] = period_ms                    # kernel + gap to the next dependent launch, 3 x 2000 back-to-back launches
+    out['roofline']['kernel_isolated_avg_ms'] = kernel_ms                # per-launch begin / end events, launches dispatched one by one
     out['roofline']['region_span_ms_per_launch'] = region_span_ms      # events around one K-launch region / K (median region): start-up and gaps included
     if region_fixed_us is not None:
       out['region_fixed_us'] = region_fixed_us
@@ -677,7 +682,7 @@ def main():
                                   'that is not GN steps; at --steps 20 it is a visible share of the region, at the default 5000 steps it is noise')
     if ks:
       flops = (2 * ks['fma_f64'] + ks['mul_f64'] + ks['add_f64']) * 64 * waves
-      tf = flops / (kernel_ms * 1e-3) / 1e12
+      tf = flops / (period_ms * 1e-3) / 1e12
       out['valu_fp64'] = {'achieved_tflops': tf, 'peak_tflops': FP64_VECTOR_PEAK_TFLOPS, 'frac': tf / FP64_VECTOR_PEAK_TFLOPS, 'flops_per_launch': flops,
                           'insts_per_wave': {k: ks[k] for k in ('valu', 'fma_f64', 'mul_f64', 'add_f64', 'rcp_f64', 'dpp', 'agpr_moves')},
                           'registers': {'vgpr': ks.get('vgpr'), 'agpr': ks.get('agpr'), 'scratch_bytes_per_lane': ks.get('scratch_bytes_per_lane')},

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/regions
 rm -rf "$O"; mkdir -p "$O"
 cd "$R"
-show='import json,sys; d=json.loads(sys.stdin.read()); r=d["regions"]["ms_per_step"]; print(sys.argv[1], round(d["value"]), "ms/step", {k: round(v*1e3,2) for k,v in r.items()}, "kernel", round(d["roofline"]["kernel_avg_ms"]*1e3,2), "period", round(d["roofline"]["launch_period_ms"]*1e3,2), "span", round(d["roofline"]["region_span_ms_per_launch"]*1e3,2), "frac", round(d["roofline"]["frac"],4), "fixed", d.get("region_fixed_us"))'
+show='import json,sys; d=json.loads(sys.stdin.read()); r=d["regions"]["ms_per_step"]; print(sys.argv[1], round(d["value"]), "ms/step", {k: round(v*1e3,2) for k,v in r.items()}, "kernel", round(d["roofline"]["kernel_avg_ms"]*1e3,2), "span", round(d["roofline"]["region_span_ms_per_launch"]*1e3,2), "frac", round(d["roofline"]["frac"],4), "fixed", d.get("region_fixed_us"))'
 for i in 1 2 3 4; do
   timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline 2> "$O/bench_$i.err" | grep -a '^{' | tee "$O/bench_driver_$i.json" | python -c "$show" driver_$i
 done
