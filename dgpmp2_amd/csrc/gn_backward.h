@@ -266,7 +266,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #ifndef DGP_BWD_RELOAD_D6
 #define DGP_BWD_RELOAD_D6 3      // QK_GENERAL | QK_STATIC
 #endif
-  if constexpr (!CHAIN && D == 6 && !is_wb(QK) && (((DGP_BWD_RELOAD_D6) >> QK) & 1) != 0) {
+#ifndef DGP_BWD_RELOAD_D4
+#define DGP_BWD_RELOAD_D4 0      // (measured: see profiles/r04_kernel_variants.txt)
+#endif
+  if constexpr (!CHAIN && !is_wb(QK) && ((((D == 6) ? (DGP_BWD_RELOAD_D6) : (DGP_BWD_RELOAD_D4)) >> QK) & 1) != 0) {
     if (have_gbar) {
 #if defined(__HIP_DEVICE_COMPILE__)
       asm volatile("" ::: "memory");

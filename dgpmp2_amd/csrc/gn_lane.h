@@ -1919,7 +1919,8 @@ DGP_HD void pcr_last_round_ldl(Ctx& cx, int i, Sym<D>& Dm, const Mat<D>& U, doub
 #else
 #define DGP_PCR_LEAN_D(D) ((D) == 6)
 #endif
-template <int D, int LPT, int S, bool LEAN, typename Ctx>
+// LDL6: the caller asks for the LDL^T rounds at d = 6 as well (round 4: the forward Woodbury kernels, whose recovery state is parked in LDS during the rounds)
+template <int D, int LPT, int S, bool LEAN, bool LDL6 = false, typename Ctx>
 DGP_HD void pcr_round_any(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   constexpr bool last = (2 * S >= LPT);
   // Only the rounds whose exchanges are DPP row shifts (LPT = 16; LPT = 32 from stride 2 on).  With the lean order on the ds_bpermute
@@ -1928,23 +1929,23 @@ DGP_HD void pcr_round_any(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D],
   // And not in the general-covariance kernels (LEAN = false there): <3,16,4,double,STEP,general> -- 355 spilled VGPRs, 1.4 KB of scratch
   // per lane -- came out wrong (O(1) errors) with the lean rounds, again only on the GPU (tests/test_hip_every_kernel.py pins every
   // instantiation against the C oracle since).
-  constexpr bool kLdl = LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && Nbr<LPT, S, Ctx>::kDpp && LPT != 64;
+  constexpr bool kLdl = LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D || (LDL6 && D == 6)) && Nbr<LPT, S, Ctx>::kDpp && LPT != 64;
   if constexpr (kLdl && !last) pcr_round_ldl<D, LPT, S>(cx, i, Dm, U, r, ok);
   else if constexpr (kLdl && last) pcr_last_round_ldl<D, LPT, S>(cx, i, Dm, U, r, ok);
   else if constexpr (LEAN && DGP_PCR_LEAN_D(D) && !last && Nbr<LPT, S, Ctx>::kDpp && LPT != 64) pcr_round_lean<D, LPT, S>(cx, i, Dm, U, r, ok);
   else pcr_round<D, LPT, S>(cx, i, Dm, U, r, ok);
 }
 
-template <int D, int LPT, bool LEAN, typename Ctx>
+template <int D, int LPT, bool LEAN, bool LDL6 = false, typename Ctx>
 DGP_HD void pcr_solve(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], double (&x)[D], SpdCheck<Ctx>& ok) {
-  if constexpr (LPT > 1) pcr_round_any<D, LPT, 1, LEAN>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 2) pcr_round_any<D, LPT, 2, LEAN>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 4) pcr_round_any<D, LPT, 4, LEAN>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 8) pcr_round_any<D, LPT, 8, LEAN>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 16) pcr_round_any<D, LPT, 16, LEAN>(cx, i, Dm, U, r, ok);
-  if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 1) pcr_round_any<D, LPT, 1, LEAN, LDL6>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 2) pcr_round_any<D, LPT, 2, LEAN, LDL6>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 4) pcr_round_any<D, LPT, 4, LEAN, LDL6>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 8) pcr_round_any<D, LPT, 8, LEAN, LDL6>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 16) pcr_round_any<D, LPT, 16, LEAN, LDL6>(cx, i, Dm, U, r, ok);
+  if constexpr (LPT > 32) pcr_round_any<D, LPT, 32, LEAN, LDL6>(cx, i, Dm, U, r, ok);
   if constexpr (LEAN && DGP_PCR_LEAN_D(D) && LPT != 64) sched_fence();
-  if constexpr (LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D) && LPT == 16) {
+  if constexpr (LEAN && (DGP_PCR_LDL == 1 || DGP_PCR_LDL == D || (LDL6 && D == 6)) && LPT == 16) {
     Ldl<D> F;
     F.factor(Dm, ok);
     F.solve(r, x);

@@ -601,7 +601,12 @@ DGP_HD void gn_linear_solve_wb(const GnParams& p, Ctx& cx, int64_t b, int j, boo
   if constexpr (kFence) sched_fence();
   before_pcr(acc);
   double xs[D];
-  pcr_solve<D, LPT, true>(cx, j, Ds, Us, rs, xs, ok);
+  // d = 6 forward kernels: the rounds on LDL^T factors, as d = 4 (measured with the recovery state parked in LDS, B = 4096: step 22.43 -> 21.91 us, fused loop
+  // 20.13 -> 19.11 us per iteration; the adjoint solve of the backward kernels, RHS_OVERRIDE, loses 1 % with them and keeps the block inverse)
+#ifndef DGP_WB_LDL6
+#define DGP_WB_LDL6 1
+#endif
+  pcr_solve<D, LPT, true, (DGP_WB_LDL6 != 0) && !RHS_OVERRIDE>(cx, j, Ds, Us, rs, xs, ok);
   if constexpr (kFence) sched_fence();
   if constexpr (kPark) {
     double flat[2 * kParkCells];
