@@ -2978,13 +2978,34 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       // row (it, b, g).  The pointer travels in GnParams::dtheta, which the fused loop does not otherwise use.  Wave-uniform test.
       if (p.dtheta) {
         double* hist = (double*)p.dtheta;
+        // d = 4, a fully populated wavefront block of a length that fills the shape, every trajectory of it still iterating: the parked state in LDS IS
+        // the staging layout of store_rows_through_lds<double> (lane-private chunks, padded stride), so the block goes out as full cache lines
+        // straight from LDS -- lane l stores the l-th 16 bytes of each 1 KB -- instead of 32 bytes per lane at a 128-byte stride
+        bool block_hist = false;
+        if constexpr (kPark && LPT != 32) block_hist = n == LPT * C && ((int64_t)cx.wave() + 1) * TPW <= (int64_t)p.B && !cx.any(!active);
+        if (block_hist) {
+          if constexpr (kPark && LPT != 32) {
+            typedef WaveStore<double, C, D> WS;
+            typedef double V2 __attribute__((vector_size(16)));
+            cx.lds_sync();
+            const char* l = cx.lds();
+            char* o = (char*)(hist + (((int64_t)it * p.B + (int64_t)cx.wave() * TPW) * n) * D);
 #pragma unroll
-        for (int k = 0; k < C; ++k) {
-          const int g = j * C + k;
-          if (active && g < n) {
-            double* row = hist + (((int64_t)it * p.B + b) * n + g) * D;
+            for (int i = 0; i < WS::kCells; ++i) {
+              const int c = i * 64 + lane;
+              *(V2*)(o + (int64_t)c * 16) = *(const V2*)(l + (c / WS::kCells) * WS::kStride + (c % WS::kCells) * 16);
+            }
+            cx.lds_sync();
+          }
+        } else {
 #pragma unroll
-            for (int a = 0; a < D; ++a) row[a] = x[k][a];
+          for (int k = 0; k < C; ++k) {
+            const int g = j * C + k;
+            if (active && g < n) {
+              double* row = hist + (((int64_t)it * p.B + b) * n + g) * D;
+#pragma unroll
+              for (int a = 0; a < D; ++a) row[a] = x[k][a];
+            }
           }
         }
       }
