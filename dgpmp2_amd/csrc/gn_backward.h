@@ -411,12 +411,27 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       }
       // dL = u^T Q de + ebar e^T Qfix de,  de = dx_{g+1} - Phi dx_g   ->  this row's share: -Phi^T (Q u + ebar Qfix e)
       double t[D];
+      if constexpr (QK == QK_STATIC || is_wb(QK)) {
+        // static covariances with a diagonal Q_c_inv: Q IS the fixed Q^-1 and entry (a, c) is zero unless a = c (mod dof) -- half the products
+        // (two thirds at d = 6) vanish, and the two terms share the matrix
+        double w[D];
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double s = 0.0;
+        for (int c = 0; c < D; ++c) w[c] = u[c] + ebar * e[c];
 #pragma unroll
-        for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
-        t[a] = s + ggp * e[a];
+        for (int a = 0; a < D; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; ++c) if (gp_nz<D>(a, c)) s += Q(a, c) * w[c];
+          t[a] = s + ggp * e[a];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
+          t[a] = s + ggp * e[a];
+        }
       }
 #pragma unroll
       for (int a = 0; a < DOF; ++a) {
@@ -468,12 +483,25 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         u[a] = (lm[a] + dt * lm[DOF + a]) - lk[a];
         u[DOF + a] = lm[DOF + a] - lk[DOF + a];
       }
+      if constexpr (QK == QK_STATIC || is_wb(QK)) {
+        double w[D];
 #pragma unroll
-      for (int a = 0; a < D; ++a) {
-        double s = 0.0;
+        for (int c = 0; c < D; ++c) w[c] = u[c] + ebar * e[c];
 #pragma unroll
-        for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
-        gx[a] += s + ggp * e[a];
+        for (int a = 0; a < D; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; ++c) if (gp_nz<D>(a, c)) s += Q(a, c) * w[c];
+          gx[a] += s + ggp * e[a];
+        }
+      } else {
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+          double s = 0.0;
+#pragma unroll
+          for (int c = 0; c < D; ++c) s += Q(a, c) * u[c] + ebar * Qf(a, c) * e[c];
+          gx[a] += s + ggp * e[a];
+        }
       }
     }
     // ---- obstacle factor: e = c, H = [hx, hy, 0..], K = omega
