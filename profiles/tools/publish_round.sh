@@ -5,7 +5,7 @@ set -eu
 P=${1:?round prefix, e.g. r02}
 R=$(cd "$(dirname "$0")/../.." && pwd)
 O=$R/gpurun_out/round
-for f in bench_driver_invocation.json bench_default.json kernel_trace.txt kernel_trace_full.txt pmc_counters.txt atomic_probe.txt mfma_probe.txt phase_timeline.txt; do
+for f in bench_driver_invocation.json bench_driver_invocation_run2.json bench_driver_invocation_run3.json bench_dist_world1.json bench_default.json kernel_trace.txt kernel_trace_full.txt pmc_counters.txt atomic_probe.txt mfma_probe.txt phase_timeline.txt; do
   cp "$O/$f" "$R/profiles/${P}_$f"
 done
 cp "$O/pytest_gpu.log" "$R/profiles/${P}_pytest_gpu.log"
