@@ -14,10 +14,10 @@ import torch  # noqa: F401  -- must be imported BEFORE the HIP library is dlopen
 # device" on the first launch).  With torch first, our library's libamdhip64.so.7 dependency resolves to the one already loaded.
 
 DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
-DGP_F32, DGP_F64 = 0, 1
+DGP_F32, DGP_F64, DGP_U8 = 0, 1, 2
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
-DGP_ABI_VERSION = 4
+DGP_ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
@@ -51,7 +51,7 @@ class CApi(object):
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
              'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward', 'gn_step_errors',
-             'gn_step_errors_backward', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
+             'gn_step_errors_backward', 'sdf_2d_workspace_bytes', 'sdf_2d', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -89,6 +89,10 @@ class CApi(object):
     self.gn_step_errors_backward = f('gn_step_errors_backward'); self.gn_step_errors_backward.restype = C.c_int
     self.gn_step_errors_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64,
                                              i32, vp, vp, vp, vp, vp]
+    self.sdf_2d_workspace_bytes = f('sdf_2d_workspace_bytes'); self.sdf_2d_workspace_bytes.restype = C.c_size_t
+    self.sdf_2d_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    self.sdf_2d = f('sdf_2d'); self.sdf_2d.restype = C.c_int
+    self.sdf_2d.argtypes = [vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, C.c_size_t, vp]
     self.time_next_launch = f('time_next_launch'); self.time_next_launch.restype = C.c_int; self.time_next_launch.argtypes = [vp, vp]
     self.event_create = f('event_create'); self.event_create.restype = C.c_int; self.event_create.argtypes = [C.POINTER(vp)]
     self.event_destroy = f('event_destroy'); self.event_destroy.restype = None; self.event_destroy.argtypes = [vp]

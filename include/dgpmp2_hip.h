@@ -24,13 +24,14 @@
 #ifndef DGPMP2_HIP_H
 #define DGPMP2_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define DGP_ABI_VERSION 4
+#define DGP_ABI_VERSION 5
 
 /* status codes */
 #define DGP_OK              0
@@ -41,6 +42,7 @@ extern "C" {
 /* io_dtype */
 #define DGP_F32 0
 #define DGP_F64 1
+#define DGP_U8  2   /* dgp_sdf_2d images only */
 
 /* flags */
 #define DGP_FLAG_NONHOLONOMIC 1u   /* planner_params['non_holonomic'] (plan_layer.py:32), needs dof == 3 */
@@ -241,6 +243,19 @@ int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch,
                                 void* g_th, void* g_start, void* g_goal,
                                 void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                                 void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace, void* stream);
+
+/* Signed distance fields of a batch of occupancy images on the GPU: utils/sdf_utils.py:6-21 (sdf_2d) for every image of the batch --
+ *   im = image > 0.75 (free space), padded by `padlen` pixels of free space on every side (:13-15),
+ *   sdf = (distance_transform_edt(im) - distance_transform_edt(1 - im)) * res (:16-20; scipy.ndimage underneath),
+ * i.e. positive distances to the nearest obstacle pixel in free space, negative distances to the nearest free pixel inside obstacles.
+ * image (batch, rows, cols) contiguous, image_dtype DGP_F32 / DGP_F64 / DGP_U8; sdf_out (batch, rows + 2 padlen, cols + 2 padlen),
+ * out_dtype DGP_F32 / DGP_F64 (the reference returns float64).  Bit-identical to scipy's result in float64 (squared distances are
+ * integers), including its convention for an image with no pixel of the other kind (distances from the pixel at row -1, column 0).
+ * workspace: device memory of at least dgp_sdf_2d_workspace_bytes(...) bytes, 4-byte aligned, owned by the call until the stream has
+ * passed it.  Two stream-ordered launches (+ one memset of batch words); padded sides up to 8192, batch up to 65535. */
+size_t dgp_sdf_2d_workspace_bytes(int32_t batch, int32_t rows, int32_t cols, int32_t padlen);
+int dgp_sdf_2d(const void* image, int32_t image_dtype, int32_t batch, int32_t rows, int32_t cols, int32_t padlen, double res,
+               void* sdf_out, int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement aid (no counterpart in the reference): the NEXT kernel launched by the calling thread through any entry point
  * above records its own begin and end on the two HIP events (hipEvent_t, created with timing enabled, cast to void*), the way

@@ -211,6 +211,11 @@ int emul_create(const DgpConfig* cfg, DgpHandle** out) { return dgp_host::create
 void emul_destroy(DgpHandle* h) { delete h; }
 int emul_num_factor_rows(const DgpHandle* h) { return h ? h->M : DGP_EINVAL; }
 
+// dgp_sdf_2d is not a lane program: nothing to emulate (tests/test_sdf_edt.py checks the HIP kernels against scipy and oracle/edt_oracle.py)
+size_t emul_sdf_2d_workspace_bytes(int32_t, int32_t, int32_t, int32_t) { return 0; }
+int emul_sdf_2d(const void*, int32_t, int32_t, int32_t, int32_t, int32_t, double, void*, int32_t, void*, size_t, void*) {
+  return dgp_host::fail(DGP_EUNSUPPORTED, "the emulator covers the wavefront lane programs only");
+}
 int emul_time_next_launch(void*, void*) { return DGP_OK; }      // nothing to time: the emulator runs on the host
 
 int emul_launch_shape(const DgpHandle* h, int32_t batch, int32_t* lpt, int32_t* c) {

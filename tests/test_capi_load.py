@@ -20,7 +20,7 @@ def api():
 def test_exports_every_declared_symbol(api):
   hdr = open(os.path.join(ROOT, 'include', 'dgpmp2_hip.h')).read()
   hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-  declared = set(re.findall(r'\b(dgp_[a-z_]+)\s*\(', hdr))
+  declared = set(re.findall(r'\b(dgp_[a-z0-9_]+)\s*\(', hdr))
   assert declared == set('dgp_' + s for s in _capi.CApi.SYMBOLS)
   for name in declared:
     assert hasattr(api.lib, name), name
