@@ -26,7 +26,7 @@ buffer allocated once; a region opens with barrier + synchronise and closes when
 it cannot before every rank has contributed -- and the slowest rank's clock counts (all-reduce MAX per region).
 Rank 0 prints ONE JSON line.  Beside the headline it carries (rank 0, N = 1, outside the timed region): the fused 10-iteration
 launch, BASELINE configs[2] and [3], the per-sample-SDF and learned-covariance regimes of configs[1], each with its own
-roofline block, the planner-API call rate, and the CPU baselines.
+roofline block, the planner-API call rate, the signed-distance-field transform (dgp_sdf_2d), and the CPU baselines.
 """
 import argparse
 import contextlib
@@ -252,6 +252,33 @@ def roofline_block(bytes_per_launch, us, kernel, traffic_key=None, note=None):
        'algorithmic_bytes_per_launch': bytes_per_launch}
   if note: r['note'] = note
   return r
+
+
+def sdf_fields_rate(device, batch=256):
+  """dgp_sdf_2d (csrc/sdf_edt.hip): the signed distance fields of `batch` occupancy images of the benchmark's grid size in one call, next to the reference's host path
+  (utils/sdf_utils.py:6-21, two scipy distance transforms per image) timed on one image on this host."""
+  from dgpmp2_amd.utils import sdf_utils
+  rs = np.random.RandomState(5)
+  yy, xx = np.ogrid[:GRID, :GRID]
+  ims = np.ones((batch, GRID, GRID), dtype=np.float32)
+  for b in range(batch):
+    for _ in range(3 + b % 5):
+      cy, cx, r = rs.randint(0, GRID), rs.randint(0, GRID), rs.randint(5, GRID // 8)
+      ims[b][(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0.0
+  d = torch.as_tensor(ims).to(device)
+  res = 10.0 / GRID
+  for _ in range(3): out = sdf_utils.sdf_2d_batch(d, padlen=1, res=res)
+  torch.cuda.synchronize(device)
+  t0 = time.perf_counter()
+  for _ in range(10): out = sdf_utils.sdf_2d_batch(d, padlen=1, res=res)
+  torch.cuda.synchronize(device)
+  us = (time.perf_counter() - t0) / 10 * 1e6
+  t0 = time.perf_counter(); ref = sdf_utils.sdf_2d(ims[0], padlen=1, res=res); host_ms = (time.perf_counter() - t0) * 1e3
+  alg = batch * (GRID * GRID * 4 + (GRID + 2) ** 2 * 8)
+  return {'workload': '%d occupancy images of %dx%d (3-7 random discs), padlen 1, float32 in, float64 out' % (batch, GRID, GRID), 'us_per_call': us, 'us_per_image': us / batch,
+          'host_scipy_ms_per_image': host_ms, 'bit_identical_to_host': bool(np.array_equal(out[0].cpu().numpy(), ref)),
+          'roofline': {'bound': 'hbm', 'achieved': alg / us * 1e-3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / us * 1e-3 / HBM_PEAK_GBS, 'traffic': None},
+          'note': 'algorithmic bytes = image in + field out per padded pixel; the call is bound by the row pass, whose search length is the distance itself (DESIGN.md section 3)'}
 
 
 def extra_workloads(device, stream, reps=1500):
@@ -693,6 +720,7 @@ def main():
     if world == 1 and not args.no_extras:
       out['two_streams'] = two_stream_rate(solver, B, th_ptrs, sp, gp, sdf_arg, device)
       out.update(extra_workloads(device, stream))
+      out['sdf_fields'] = sdf_fields_rate(device)
       out['planner_step_api'] = planner_api_rate(device)
       out['planner_step_backward_api'] = planner_api_backward_rate(device)
     if world == 1 and not args.no_cpu_baseline:

@@ -47,7 +47,6 @@ def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=im.device)
     api.check(api.sdf_2d(im.data_ptr(), codes[im.dtype], B, H, W, padlen, float(res), out.data_ptr(), codes[dtype], ws.data_ptr(), ws.numel() * 4,
                          torch.cuda.current_stream(im.device).cuda_stream))
-    ws.record_stream(torch.cuda.current_stream(im.device))
   return out[0] if squeeze else out
 
 
