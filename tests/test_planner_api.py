@@ -53,6 +53,44 @@ def test_step_matches_reference_c2mini(golden):
   assert not err.requires_grad
 
 
+def test_step_loop_is_capturable_in_a_hip_graph(golden):
+  """A planning loop of planner.step() calls (examples/diff_gpmp2_2d_batch_step_example.py) captured once in a HIP graph (torch.cuda.CUDAGraph) and replayed:
+  every launch goes to the capturing stream, nothing in the call path synchronises or allocates outside torch's allocator -- the replay reproduces the eager
+  loop bit for bit, and again after the static input has been overwritten."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  im = (sdf > 0).double()
+  start, goal = T(g['start']), T(g['goal'])
+  th0 = T(g['th_hist'][0])
+
+  def loop(th):
+    for _ in range(5):
+      th = th + planner.step(th, start, goal, im, sdf)[0]
+    return th
+
+  with torch.no_grad():
+    eager = loop(th0)
+    static_in = th0.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+      loop(static_in)                              # warm-up on the side stream, as torch's capture recipe asks
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      static_out = loop(static_in)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, eager)
+    assert rel_err(static_out.cpu().numpy(), g['th_hist'][5]) < 1e-8
+    static_in.copy_(T(g['th_hist'][2]))
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(static_out, loop(T(g['th_hist'][2])))
+
+
 def test_step_float32_tensors(golden):
   g = golden('g3_c2mini')
   B, n, G = 8, 64, int(g['G'])
