@@ -493,13 +493,35 @@ def planner_api_backward_rate(device, reps=200):
   k_bwd = time_launches(lambda k: sv.gn_solve_backward(B, start.data_ptr(), goal.data_ptr(), sarg, GN_ITERS, hist.data_ptr(), tho.data_ptr(), its.data_ptr(),
                                                        g.data_ptr(), gth.data_ptr(), gst.data_ptr(), ggo.data_ptr(), None, 0, raw), 100, warm_s=0.1)
 
+  def graphed(f):
+    """f (forward + torch.autograd.grad) captured once in a HIP graph (torch.cuda.CUDAGraph, torch's whole-iteration capture recipe: warm-up on a side
+    stream, then capture) -> the replay callable.  Replay re-issues the recorded launches without Python, Function.apply or the autograd engine."""
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+      for _ in range(3): f()
+    torch.cuda.current_stream(device).wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+      f()
+    return gr.replay
+
   a, b = wall(static_fb), wall(learned_fb)
   t2, t1 = wall(train_iteration_two_calls), wall(train_iteration_fused)
+  try:
+    ga, gt1, gk = wall(graphed(static_fb)), wall(graphed(train_iteration_fused)), wall(graphed(tbptt_fb)) / 10.0
+  except Exception as e:      # noqa: BLE001  (measurement extra: a torch build without graph capture must not cost the bench line)
+    print('bench: HIP-graph capture of the training iteration failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+    ga = gt1 = gk = None
   reps = max(20, reps // 10)
   c = wall(tbptt_fb) / 10.0
   fb = wall(forward_backward)
   return {'us_per_call': a, 'learned_covariances_us_per_call': b, 'tbptt_window10_us_per_step': c,
-          'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1,
+          'hip_graph_replay': {'us_per_call': ga, 'train_iteration_us': gt1, 'tbptt_window10_us_per_step': gk,
+                               'note': 'the same forward + backward callables captured ONCE in a HIP graph (torch.cuda.CUDAGraph) and replayed: the recorded launches '
+                                       'without Python, Function.apply or the autograd engine -- what is left is the kernels (results bit-identical to the eager calls, '
+                                       'tests/test_planner_api.py)'},
+          'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1, 'step_with_errors_hip_graph_replay_us': gt1,
                                   'note': 'learned covariances (per-state qc_inv / obscov_inv / eps that require grad): step + unweighted errors at th + dtheta + '
                                           'backward of a loss on all four outputs w.r.t. all four inputs, wall per iteration -- PlanLayer.forward + '
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '

@@ -91,6 +91,52 @@ def test_step_loop_is_capturable_in_a_hip_graph(golden):
     assert torch.equal(static_out, loop(T(g['th_hist'][2])))
 
 
+def test_training_iteration_is_capturable_in_a_hip_graph(golden):
+  """One iteration of the training loop -- step_with_errors with learned per-state covariances + the backward of all four outputs w.r.t. the trajectory
+  and the three covariance tensors (learning/train_planner.py:311-327, 366) -- captured in a HIP graph: forward AND backward launches are recorded
+  (torch's whole-iteration capture), the replay returns the eager gradients bit for bit and follows new values written into the static inputs."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  start, goal = T(g['start']), T(g['goal'])
+  gen = torch.Generator(device=DEV).manual_seed(3)
+  thr = T(g['th_hist'][1]).requires_grad_(True)
+  A = torch.randn(B, n - 1, 2, 2, device=DEV, dtype=torch.float64, generator=gen) * 0.2
+  qc = (torch.eye(2, device=DEV, dtype=torch.float64) + A @ A.transpose(-1, -2)).requires_grad_(True)
+  ow = (torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 1e4 + 50).requires_grad_(True)
+  ep = (torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 0.5 + 0.1).requires_grad_(True)
+  c_dth = torch.randn(B, n, 4, device=DEV, dtype=torch.float64, generator=gen)
+  c_e = torch.randn(B, 1, 1, device=DEV, dtype=torch.float64, generator=gen)
+  leaves = (thr, qc, ow, ep)
+
+  def iteration():
+    dth, _, eex, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdf, qc, ow, ep)
+    return torch.autograd.grad((dth, eex, sg, gp_, ob), leaves, (c_dth, c_e, c_e.view(B, 1), c_e, c_e))
+
+  eager = [t.clone() for t in iteration()]
+  side = torch.cuda.Stream()
+  side.wait_stream(torch.cuda.current_stream())
+  with torch.cuda.stream(side):
+    for _ in range(2): iteration()
+  torch.cuda.current_stream().wait_stream(side)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    outs = iteration()
+  graph.replay()
+  torch.cuda.synchronize()
+  for a, b in zip(outs, eager):
+    assert torch.equal(a, b)
+  with torch.no_grad():
+    thr.copy_(T(g['th_hist'][3])); ow.mul_(0.5)
+  graph.replay()
+  torch.cuda.synchronize()
+  replayed = [t.clone() for t in outs]
+  for a, b in zip(replayed, iteration()):
+    assert torch.equal(a, b)
+  assert not torch.equal(replayed[0], eager[0])
+
+
 def test_step_float32_tensors(golden):
   g = golden('g3_c2mini')
   B, n, G = 8, 64, int(g['G'])
