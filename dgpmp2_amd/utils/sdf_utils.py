@@ -18,7 +18,7 @@ def sdf_2d(image, padlen=1, res=1.0):
 
 def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
   """sdf_2d for a whole batch of occupancy images on the GPU: ONE C-ABI call (dgp_sdf_2d, two launches of csrc/sdf_edt.hip) instead of
-  two scipy distance transforms per image on the host.  images: CUDA tensor (B, H, W) or (H, W), float32 / float64 / uint8, free space
+  two scipy distance transforms per image on the host.  images: CUDA tensor (B, H, W), (B, 1, H, W) or (H, W), float32 / float64 / uint8, free space
   > 0.75 as in sdf_2d; -> (B, H + 2 padlen, W + 2 padlen) (or without the batch axis for a 2-D input), float64 like the reference unless
   `dtype` says float32.  The float64 result is bit-identical to sdf_2d's (tests/test_sdf_edt.py).  No CPU path: host arrays go through sdf_2d."""
   import torch
@@ -26,9 +26,10 @@ def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
   if not torch.is_tensor(images) or not images.is_cuda:
     raise RuntimeError('dgpmp2_amd.sdf_2d_batch: `images` must be a CUDA/ROCm tensor (host arrays: use sdf_2d)')
   squeeze = images.dim() == 2
-  im = images.unsqueeze(0) if squeeze else images
+  channel = images.dim() == 4 and images.shape[1] == 1      # (B, 1, H, W), the dataset's image layout (datasets/planning_dataset.py:54): -> (B, 1, H + 2 p, W + 2 p)
+  im = images.unsqueeze(0) if squeeze else (images[:, 0] if channel else images)
   if im.dim() != 3 or im.numel() == 0:
-    raise ValueError('sdf_2d_batch: images must be (B, H, W) or (H, W) and non-empty, got %s' % (tuple(images.shape),))
+    raise ValueError('sdf_2d_batch: images must be (B, H, W), (B, 1, H, W) or (H, W) and non-empty, got %s' % (tuple(images.shape),))
   codes = {torch.float32: _capi.DGP_F32, torch.float64: _capi.DGP_F64, torch.uint8: _capi.DGP_U8}
   if im.dtype not in codes:
     raise TypeError('sdf_2d_batch: float32, float64 or uint8 images, got %s' % im.dtype)
@@ -47,7 +48,7 @@ def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=im.device)
     api.check(api.sdf_2d(im.data_ptr(), codes[im.dtype], B, H, W, padlen, float(res), out.data_ptr(), codes[dtype], ws.data_ptr(), ws.numel() * 4,
                          torch.cuda.current_stream(im.device).cuda_stream))
-  return out[0] if squeeze else out
+  return out[0] if squeeze else (out.unsqueeze(1) if channel else out)
 
 
 def rgb2gray(rgb):

@@ -138,6 +138,24 @@ def test_hip_degenerate_images_and_2d_input():
 
 
 @pytest.mark.gpu
+def test_hip_dataset_layout_and_views():
+  """(B, 1, H, W) images as the dataset stores them, and a non-contiguous view: same fields, the channel axis kept."""
+  import torch
+  rs = np.random.RandomState(21)
+  ims = _random_images(rs, 3, 40, 56, 0.8)
+  ref = np.stack([_scipy_sdf_2d(a, padlen=1, res=0.1) for a in ims])
+  d = torch.as_tensor(ims).cuda()
+  out4 = sdf_utils.sdf_2d_batch(d[:, None], padlen=1, res=0.1)
+  assert out4.shape == (3, 1, 42, 58)
+  np.testing.assert_array_equal(out4[:, 0].cpu().numpy(), ref)
+  wide = torch.zeros(3, 40, 112, dtype=torch.float64, device='cuda')
+  wide[:, :, ::2] = d
+  np.testing.assert_array_equal(sdf_utils.sdf_2d_batch(wide[:, :, ::2], padlen=1, res=0.1).cpu().numpy(), ref)
+  with pytest.raises(ValueError):
+    sdf_utils.sdf_2d_batch(d[:, None, None])
+
+
+@pytest.mark.gpu
 def test_hip_full_size_batch_properties():
   """BASELINE-sized grids (64 images of 512 x 512, sparse obstacles: the longest searches): spot-check against scipy, and size-independent properties
   on the whole batch -- sign = occupancy, |sdf| >= res next to nothing closer, 1-Lipschitz in pixel units along rows and columns."""
