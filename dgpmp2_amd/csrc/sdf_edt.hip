@@ -8,8 +8,9 @@
 //
 // Exact two-pass transform (separable in the squared distance):
 //   1. edt_columns: one lane per image column walks its column down and up: for every pixel the vertical distance to the
-//      nearest OBSTACLE pixel and to the nearest FREE pixel of that column (0xFFFF: none), packed into one 32-bit word per pixel.
-//      Adjacent lanes own adjacent columns, so every row step is one coalesced line; the image is read once.
+//      nearest OBSTACLE pixel and to the nearest FREE pixel of that column -- of which one is always 0, so a 16-bit word per pixel holds the class bit and the other distance (0x7FFF: none).
+//      Adjacent lanes own adjacent columns, so every row step is one coalesced line; the image is read once and the downward values of a strip of
+//      64 columns wait in LDS for the upward walk (images of up to 512 padded rows; taller ones make that round trip through the workspace).
 //   2. edt_rows: one workgroup per image row; the row's words are staged in LDS and every lane resolves its pixels by an outward
 //      search  D^2 = min_x' (x - x')^2 + g(x', y)^2  that stops as soon as (x - x')^2 alone reaches the best candidate -- the search
 //      radius is the answer itself, a handful of pixels next to an obstacle.  A free pixel looks for the nearest obstacle and gets
@@ -17,7 +18,7 @@
 // An image without any obstacle (or, unpadded, without any free pixel) has no nearest pixel of the other kind; scipy then measures
 // from the pixel at (row -1, column 0), and so does this kernel (tests/test_sdf_edt.py pins that).
 //
-// HBM traffic per padded pixel: image in (once) + 3 x 4 bytes of the packed words (written, updated in the upward walk, read by
+// HBM traffic per padded pixel: image in (once) + 2 x 2 bytes of the words (written by the column pass, read by
 // the row pass) + the field out; no arithmetic to speak of -- an HBM-bound byte kernel, not MFMA work.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,13 +28,18 @@ namespace {
 
 using dgp_host::fail;
 
-constexpr uint32_t kNone = 0xFFFFu;            // "no such pixel in this column"
+constexpr uint32_t kNone = 0x7FFFu;            // "no such pixel in this column"
+constexpr uint32_t kFreeBit = 0x8000u;
 constexpr int kMaxDim = 8192;                  // padded rows / columns: squared distances stay below 2^27 + 2^27, and the row pass keeps two rows of them in 64 KB of LDS
+#ifndef DGP_EDT_LDS_STRIP
+#define DGP_EDT_LDS_STRIP 0       // measured (profiles/r04_sdf_edt.txt): 33 KB of LDS per wavefront leaves four wavefronts per CU -- 3.0 against 1.2 ms at batch 4096; 92 against 98 us for one image
+#endif
+constexpr int kColsLdsRows = 512;              // tallest padded image whose 64-column strip (2 bytes per pixel) fits the 64 KB of LDS of the column pass
 
 struct EdtArgs {
   const void* image;      // (B, rows, cols), contiguous
   void* out;              // (B, rows + 2 pad, cols + 2 pad)
-  uint32_t* words;        // workspace: (B, Hp, Wp) packed column distances
+  uint16_t* words;        // workspace: (B, Hp, Wp), per pixel: bit 15 = free space, bits 0-14 = vertical distance to the nearest pixel of the OTHER kind in its column
   uint32_t* flags;        // workspace: per image, bit 0: has an obstacle pixel, bit 1: has a free pixel
   int32_t B, rows, cols, pad, Hp, Wp;
   double res;
@@ -48,44 +54,51 @@ __device__ __forceinline__ bool is_free(const EdtArgs& a, int b, int y, int x) {
   return (double)v > 0.75;
 }
 
-// word: low half = vertical distance to the nearest obstacle pixel of the column, high half = to the nearest free pixel
-template <typename T>
+__device__ __forceinline__ uint32_t step_dist(uint32_t d) { return d == kNone ? kNone : d + 1; }
+
+// One lane per image column, one wavefront per strip of 64 columns.  Downward walk: per pixel its class and the distance to the nearest pixel of the other
+// kind ABOVE it; upward walk: the same from BELOW, the smaller of the two is the word.  LDS = true: the strip's downward values wait in LDS (2 bytes per pixel,
+// Hp <= kColsLdsRows) and only the final words reach memory; otherwise they make the round trip through the workspace itself.
+template <typename T, bool LDS>
 __global__ void __launch_bounds__(64) edt_columns(const EdtArgs a) {
+  extern __shared__ uint16_t strip[];            // [Hp][64] (LDS variant)
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int b = blockIdx.y;
-  if (x >= a.Wp) return;
-  uint32_t* w = a.words + (int64_t)b * a.Hp * a.Wp + x;
+  const bool on = x < a.Wp;
+  uint16_t* w = a.words + (int64_t)b * a.Hp * a.Wp + (on ? x : 0);
   uint32_t d_obs = kNone, d_free = kNone, seen = 0;
-  // downward walk: distance to the nearest pixel of each kind ABOVE (or at) the current one
-  for (int y0 = 0; y0 < a.Hp; y0 += 8) {
-    bool f[8];
+  for (int y0 = 0; y0 < a.Hp; y0 += 16) {
+    bool f[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = (y0 + k < a.Hp) ? is_free<T>(a, b, y0 + k, x) : true;      // (eight independent loads in flight)
+    for (int k = 0; k < 16; ++k) f[k] = (on && y0 + k < a.Hp) ? is_free<T>(a, b, y0 + k, x) : true;      // (sixteen independent loads in flight)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       if (y0 + k < a.Hp) {
-        d_obs = f[k] ? (d_obs == kNone ? kNone : d_obs + 1) : 0;
-        d_free = f[k] ? 0 : (d_free == kNone ? kNone : d_free + 1);
+        d_obs = f[k] ? step_dist(d_obs) : 0;
+        d_free = f[k] ? 0 : step_dist(d_free);
         seen |= f[k] ? 2u : 1u;
-        w[(int64_t)(y0 + k) * a.Wp] = d_obs | (d_free << 16);
+        const uint16_t v = (uint16_t)(f[k] ? (kFreeBit | d_obs) : d_free);
+        if (LDS) strip[(y0 + k) * 64 + threadIdx.x] = v;
+        else if (on) w[(int64_t)(y0 + k) * a.Wp] = v;
       }
     }
   }
-  if (seen) atomicOr(a.flags + b, seen);
-  // upward walk: combine with the nearest pixel BELOW
+  if (on && seen) atomicOr(a.flags + b, seen);
   d_obs = kNone; d_free = kNone;
-  for (int y0 = a.Hp - 1; y0 >= 0; y0 -= 8) {
-    uint32_t v[8];
+  for (int y0 = a.Hp - 1; y0 >= 0; y0 -= 16) {
+    uint16_t v[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (y0 - k >= 0) ? w[(int64_t)(y0 - k) * a.Wp] : 0u;
+    for (int k = 0; k < 16; ++k) v[k] = (y0 - k >= 0) ? (LDS ? strip[(y0 - k) * 64 + threadIdx.x] : (on ? w[(int64_t)(y0 - k) * a.Wp] : (uint16_t)0)) : (uint16_t)0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       if (y0 - k >= 0) {
-        const uint32_t up_obs = v[k] & 0xFFFFu, up_free = v[k] >> 16;
-        d_obs = (up_obs == 0) ? 0 : (d_obs == kNone ? kNone : d_obs + 1);
-        d_free = (up_free == 0) ? 0 : (d_free == kNone ? kNone : d_free + 1);
-        const uint32_t o = up_obs < d_obs ? up_obs : d_obs, fr = up_free < d_free ? up_free : d_free;
-        w[(int64_t)(y0 - k) * a.Wp] = o | (fr << 16);
+        const bool fr = (v[k] & kFreeBit) != 0;
+        const uint32_t up = v[k] & kNone;
+        d_obs = fr ? step_dist(d_obs) : 0;
+        d_free = fr ? 0 : step_dist(d_free);
+        const uint32_t below = fr ? d_obs : d_free;
+        const uint32_t m = up < below ? up : below;
+        if (on) w[(int64_t)(y0 - k) * a.Wp] = (uint16_t)((fr ? kFreeBit : 0u) | m);
       }
     }
   }
@@ -103,12 +116,14 @@ __global__ void __launch_bounds__(256) edt_rows(const EdtArgs a) {
   extern __shared__ int32_t sq[];                // squared distance to the nearest obstacle of each column, then to the nearest free pixel
   const int y = blockIdx.x, b = blockIdx.y, Wp = a.Wp;
   const int span = PAD ? 3 * Wp : Wp, off = PAD ? Wp : 0;
-  const uint32_t* w = a.words + ((int64_t)b * a.Hp + y) * Wp;
+  const uint16_t* w = a.words + ((int64_t)b * a.Hp + y) * Wp;
   const uint32_t have = a.flags[b];
   for (int x = threadIdx.x; x < Wp; x += 256) {
     const uint32_t v = w[x];
-    sq[off + x] = sq_or_far(v & 0xFFFFu);
-    sq[span + off + x] = sq_or_far(v >> 16);
+    const bool fr = (v & kFreeBit) != 0;
+    const int32_t d2 = sq_or_far(v & kNone);
+    sq[off + x] = fr ? d2 : 0;                   // to the nearest obstacle (an obstacle pixel is its own)
+    sq[span + off + x] = fr ? 0 : d2;            // to the nearest free pixel
     if (PAD) { sq[x] = kFar; sq[2 * Wp + x] = kFar; sq[span + x] = kFar; sq[span + 2 * Wp + x] = kFar; }
   }
   __syncthreads();
@@ -162,7 +177,7 @@ __global__ void __launch_bounds__(256) edt_rows(const EdtArgs a) {
   }
 }
 
-size_t words_bytes(int64_t B, int64_t Hp, int64_t Wp) { return (size_t)(B * Hp * Wp) * sizeof(uint32_t); }
+size_t words_bytes(int64_t B, int64_t Hp, int64_t Wp) { return ((size_t)(B * Hp * Wp) * sizeof(uint16_t) + 3) / 4 * 4; }
 size_t flags_bytes(int64_t B) { return (size_t)((B * sizeof(uint32_t) + 255) / 256) * 256; }
 
 }  // namespace
@@ -188,13 +203,21 @@ int dgp_sdf_2d(const void* image, int32_t image_dtype, int32_t batch, int32_t ro
   EdtArgs a;
   a.image = image; a.out = sdf_out;
   a.flags = (uint32_t*)workspace;
-  a.words = (uint32_t*)((char*)workspace + flags_bytes(batch));
+  a.words = (uint16_t*)((char*)workspace + flags_bytes(batch));
   a.B = batch; a.rows = rows; a.cols = cols; a.pad = padlen; a.Hp = (int32_t)Hp; a.Wp = (int32_t)Wp; a.res = res;
   if (hipMemsetAsync(a.flags, 0, flags_bytes(batch), s) != hipSuccess) return fail(DGP_EHIP, "dgp_sdf_2d: hipMemsetAsync failed");
   const dim3 gc((unsigned)((Wp + 63) / 64), (unsigned)batch), gr((unsigned)Hp, (unsigned)batch);
-  if (image_dtype == DGP_F32) hipLaunchKernelGGL(edt_columns<float>, gc, dim3(64), 0, s, a);
-  else if (image_dtype == DGP_F64) hipLaunchKernelGGL(edt_columns<double>, gc, dim3(64), 0, s, a);
-  else hipLaunchKernelGGL(edt_columns<uint8_t>, gc, dim3(64), 0, s, a);
+  const bool strip = DGP_EDT_LDS_STRIP != 0 && Hp <= kColsLdsRows;
+  const size_t clds = strip ? (size_t)Hp * 64 * sizeof(uint16_t) : 0;
+#define DGP_EDT_COLS(T)                                                                          \
+  do {                                                                                           \
+    if (strip) hipLaunchKernelGGL((edt_columns<T, true>), gc, dim3(64), clds, s, a);              \
+    else hipLaunchKernelGGL((edt_columns<T, false>), gc, dim3(64), 0, s, a);                      \
+  } while (0)
+  if (image_dtype == DGP_F32) DGP_EDT_COLS(float);
+  else if (image_dtype == DGP_F64) DGP_EDT_COLS(double);
+  else DGP_EDT_COLS(uint8_t);
+#undef DGP_EDT_COLS
   const bool pad = Wp <= kPadMaxW;
   const size_t lds = (pad ? 6 : 2) * (size_t)Wp * sizeof(int32_t);
   if (out_dtype == DGP_F32) { if (pad) hipLaunchKernelGGL((edt_rows<float, true>), gr, dim3(256), lds, s, a); else hipLaunchKernelGGL((edt_rows<float, false>), gr, dim3(256), lds, s, a); }

@@ -64,7 +64,7 @@ def test_host_mirror_sdf_2d_matches_the_reference_fixture():
 
 def test_capi_rejects_bad_arguments_without_launching():
   api = _capi.get_api()
-  assert api.sdf_2d_workspace_bytes(2, 10, 12, 1) == 256 + 2 * 12 * 14 * 4
+  assert api.sdf_2d_workspace_bytes(2, 10, 12, 1) == 256 + 2 * 12 * 14 * 2
   assert api.sdf_2d_workspace_bytes(0, 10, 12, 1) == 0 and api.sdf_2d_workspace_bytes(1, 10, 12, -1) == 0
   buf = (C.c_char * 4096)()
   p = C.addressof(buf)
