@@ -16,7 +16,7 @@ import torch  # noqa: F401  -- must be imported BEFORE the HIP library is dlopen
 DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64, DGP_U8 = 0, 1, 2
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
-DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL = 0, 1, 2
+DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL, DGP_QC_SCALAR = 0, 1, 2, 3
 DGP_ABI_VERSION = 5
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

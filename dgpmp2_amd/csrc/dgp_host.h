@@ -212,7 +212,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 // Fill the per-call part of the kernel arguments; returns DGP_OK or an error code.
 inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
-                     const DgpCovs* covs, dgp::GnParams& p, bool sdf_optional = false) {
+                     const DgpCovs* covs, dgp::GnParams& p, bool sdf_optional = false, bool scalar_qc_ok = false) {
   if (!h) return fail(DGP_EINVAL, "null handle");
   if (batch <= 0) return fail(DGP_EINVAL, "batch must be positive, got %d", batch);
   if (!th || !start || !goal) return fail(DGP_EINVAL, "th/start/goal must be non-null device pointers");
@@ -235,7 +235,11 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   p.qc_mode = DGP_QC_STATIC; p.qc = nullptr; p.obs_w = nullptr; p.eps = nullptr;
   p.vec_mu = (aligned16(start) && aligned16(goal)) ? 1 : 0;
   if (covs) {
-    if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_QFULL) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+    if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+    if (covs->qc_mode == DGP_QC_SCALAR && !scalar_qc_ok)
+      return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is implemented by dgp_gn_step only (pass the (B,n-1,dof,dof) tensors elsewhere)");
+    if (covs->qc_mode == DGP_QC_SCALAR && h->base.qc_diag == 0)
+      return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR needs a diagonal Q_c_inv in the configuration");
     if ((covs->qc_mode == DGP_QC_STATIC) != (covs->qc_inv == nullptr))
       return fail(DGP_EINVAL, "qc_inv must be NULL iff qc_mode == DGP_QC_STATIC");
     p.qc_mode = covs->qc_mode; p.qc = covs->qc_inv; p.obs_w = covs->obs_w; p.eps = covs->eps;
@@ -246,8 +250,9 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
 
 inline int fill_step(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
                      const DgpCovs* covs, void* dtheta, void* err, void* err_ext, int32_t* info, dgp::GnParams& p) {
-  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p, /*sdf_optional=*/false, /*scalar_qc_ok=*/true);
   if (rc != DGP_OK) return rc;
+  if (p.qc_mode == dgp::QC_SCALAR && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is not implemented for num_states > 256");
   if (!dtheta) return fail(DGP_EINVAL, "dtheta must be non-null");
   p.dtheta = dtheta; p.err = err; p.err_ext = err_ext; p.info = info;
   p.vec_io = (aligned16(th) && aligned16(dtheta)) ? 1 : 0;

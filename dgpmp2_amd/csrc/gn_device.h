@@ -227,6 +227,7 @@ inline int launch_group(int mode, const dgp::GnParams& p) {
   if (mode == dgp::MODE_EVAL) return GROUP_GENERIC;
   if (mode == MODE_CHAIN) return GROUP_CHAIN;
   const int qk = dgp::kernel_variant(p);
+  if (qk == dgp::QK_SCALED) return GROUP_STATIC;      // (STEP only, host-checked)
   if (qk == dgp::QK_KRON) return GROUP_KRON;
   if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
   return qk == dgp::QK_STATIC ? GROUP_STATIC : GROUP_GENERIC;
@@ -256,6 +257,11 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
     if constexpr (GROUP == GROUP_STATIC) {                                                                                 \
+      if (dgp::kernel_variant(p) == dgp::QK_SCALED) {                                                                      \
+        if (mode != dgp::MODE_STEP) return hipErrorInvalidValue;                                                           \
+        DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_SCALED>));                                           \
+        return hipGetLastError();                                                                                          \
+      }                                                                                                                    \
       if constexpr (CC == 4) {                                                                                             \
         if (dgp::wb_applies(p, L, CC)) {                                                                                   \
           if (p.n == L * CC) {                                                                                             \

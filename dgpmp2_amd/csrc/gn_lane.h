@@ -62,7 +62,7 @@
 namespace dgp {
 
 enum { MODE_STEP = 0, MODE_SOLVE = 1, MODE_EVAL = 2 };
-enum { QC_STATIC = 0, QC_PERSTATE = 1, QC_QFULL = 2 };
+enum { QC_STATIC = 0, QC_PERSTATE = 1, QC_QFULL = 2, QC_SCALAR = 3 };
 enum { FLAG_NONHOLONOMIC = 1u, FLAG_VEL_LIMITS = 2u };
 // Kernel variant by covariance representation (template parameter QK of the kernels; see Coupling):
 //   QK_STATIC : static covariances with a diagonal Q_c_inv (the reference's default planner) -- constant GP blocks as scalar operands
@@ -74,7 +74,10 @@ enum { FLAG_NONHOLONOMIC = 1u, FLAG_VEL_LIMITS = 2u };
 //   QK_WBR    : the same for trajectory lengths that do not fill the shape (n < 4 LPT: the goal row inside a lane, lanes of padding rows);
 //               a separate instantiation because the lane-type arithmetic and the two extra table versions cost the n = 4 LPT kernel
 //               (the benchmark's) 0.25 us when they are compiled into it
-enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2, QK_WB = 3, QK_WBR = 4 };
+//   QK_SCALED : one scalar per GP factor, Q_c^-1 = s_k Q_c_inv with a diagonal Q_c_inv (qc_mode SCALAR: the learned mode diag_identity, q_k^2 I) -- every GP block of
+//               factor k is s_k times the constant block of QK_STATIC, so the lane masks that multiply those blocks carry s_k and the static block elimination
+//               applies (STEP kernels only: the learned planner chains step() calls)
+enum { QK_GENERAL = 0, QK_STATIC = 1, QK_KRON = 2, QK_WB = 3, QK_WBR = 4, QK_SCALED = 5 };
 constexpr DGP_HD bool is_wb(int qk) { return qk == QK_WB || qk == QK_WBR; }
 
 // Layout of the QK_WB constant table (GnParams::wb_tab; doubles, per version -- by what the lane's three interior rows are:
@@ -143,7 +146,10 @@ static_assert(offsetof(GnParams, wb_tab) % 16 == 0, "wb_tab must start on a 16-b
 
 // The QK_STATIC kernel variants (see Coupling below) apply to static covariances with a diagonal Q_c_inv.
 DGP_HD bool use_static_kernels(const GnParams& p) { return p.qc_mode == QC_STATIC && p.qc_diag != 0; }
-DGP_HD int kernel_variant(const GnParams& p) { return use_static_kernels(p) ? QK_STATIC : (p.qc_mode == QC_PERSTATE ? QK_KRON : QK_GENERAL); }
+DGP_HD int kernel_variant(const GnParams& p) {
+  if (p.qc_mode == QC_SCALAR) return QK_SCALED;      // (host-checked: diagonal Q_c_inv)
+  return use_static_kernels(p) ? QK_STATIC : (p.qc_mode == QC_PERSTATE ? QK_KRON : QK_GENERAL);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // tiny fixed-size linear algebra, fully unrolled so that everything lives in registers
@@ -761,7 +767,9 @@ DGP_HD void eval_state(const GnParams& p, int64_t b, int g, bool valid, const do
 template <int DOF>
 DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2 * DOF], const double (&xm)[2 * DOF],
                        const double (&xp)[2 * DOF], const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF],
-                       double (&r)[2 * DOF], ErrAcc& acc) {
+                       double (&r)[2 * DOF], ErrAcc& acc, double s_next = 1.0, double s_prev = 1.0) {
+  // s_next / s_prev (QK_SCALED): the scalars of the factors (g -> g+1) and (g-1 -> g), Q^-1 = s * q_fix; they weigh the system and err,
+  // not err_ext / the unweighted errors (fixed weights, plan_layer.py:318-321, 374-377)
   // priors + GP factors: everything of row g that does NOT depend on the SDF lookup (runs while the taps are in flight)
   constexpr int D = 2 * DOF;
   const int n = p.n;
@@ -796,7 +804,8 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
     q += eo[a] * t;
     so += eo[a] * eo[a];
   }
-  acc.e += mN * (0.5 * q); acc.eext += mN * (0.5 * q); acc.ugp += mN * (0.5 * so);
+  const double wN = mN * s_next, wP = mP * s_prev;
+  acc.e += wN * (0.5 * q); acc.eext += mN * (0.5 * q); acc.ugp += mN * (0.5 * so);
 #pragma unroll
   for (int a = 0; a < D; ++a) {
     double tu = 0.0, tq = 0.0;
@@ -805,17 +814,17 @@ DGP_HD void static_rhs(const GnParams& p, int g, bool valid, const double (&x)[2
       tu += p.u_fix[a * D + c] * eo[c];                    // (U e_own)_a :  eta += Phi^T Q e = -U e
       tq += p.q_fix[Sym<D>::idx(a, c)] * em[c];            // (Q e_prev)_a:  eta -= Q e_prev
     }
-    r[a] = w * ep[a] - mN * tu - mP * tq;
+    r[a] = w * ep[a] - wN * tu - wP * tq;
   }
 }
 
 // diagonal block of row g without the single-state factors; m_next = 1 iff the row couples to row g+1
 template <int DOF>
-DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next) {
+DGP_HD void static_diag(const GnParams& p, int g, bool valid, Sym<2 * DOF>& Dm, double& m_next, double s_next = 1.0, double s_prev = 1.0) {
   constexpr int D = 2 * DOF;
   const int n = p.n;
   const bool is_start = valid && g == 0, is_goal = valid && g == n - 1;
-  const double mN = (valid && g < n - 1) ? 1.0 : 0.0, mP = (valid && g > 0) ? 1.0 : 0.0;
+  const double mN = ((valid && g < n - 1) ? 1.0 : 0.0) * s_next, mP = ((valid && g > 0) ? 1.0 : 0.0) * s_prev;      // (QK_SCALED: mask x the factor's scalar)
   m_next = mN;
   const double w = is_start ? p.w_s : (is_goal ? p.w_g : 0.0);
   const double dbase = valid ? p.reg : 1.0;                // delta I (plan_layer.py:219); padding rows: identity row, x = 0
@@ -840,6 +849,7 @@ template <int D, int C> struct LaneQ<D, C, QK_GENERAL> { Sym<D> q[C]; Sym<D> qm0
 template <int D, int C> struct LaneQ<D, C, QK_STATIC> {};
 template <int D, int C> struct LaneQ<D, C, QK_WB> {};
 template <int D, int C> struct LaneQ<D, C, QK_WBR> {};
+template <int D, int C> struct LaneQ<D, C, QK_SCALED> { double s[C]; double sm0; };      // the scalars of the lane's C + 1 GP factors
 template <int D, int C> struct LaneQ<D, C, QK_KRON> { Sym<D / 2> c[C]; Sym<D / 2> cm0; };      // C_k = Q_c^-1 of the factor, read as a symmetric matrix
 
 // N consecutive elements starting at src: 16-byte vector loads when `vec` (host-checked alignment) and N is a whole number of
@@ -904,6 +914,15 @@ DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, Q
 template <int DOF, int C, typename IO>
 DGP_HD void load_lane_Q(const GnParams&, int64_t, int, bool, LaneQ<2 * DOF, C, QK_WBR>&) {}
 
+template <int DOF, int C, typename IO>
+DGP_HD void load_lane_Q(const GnParams& p, int64_t b, int g0, bool traj_ok, LaneQ<2 * DOF, C, QK_SCALED>& L) {
+  const int64_t bb = traj_ok ? b : 0;
+  const int fmax = p.n - 2;
+  const IO* sc = (const IO*)p.qc + bb * (p.n - 1);
+#pragma unroll
+  for (int k = 0; k < C; ++k) L.s[k] = (double)sc[imin32(g0 + k, fmax)];
+  L.sm0 = (double)sc[imin32(imax32(g0 - 1, 0), fmax)];
+}
 // per-state C = Q_c^-1 (dof x dof) of factor f, upper triangle (qc_mode PERSTATE only: p.qc is the (B, n-1, dof, dof) tensor)
 template <int DOF, typename IO>
 DGP_HD void load_Qc_block(const GnParams& p, int64_t b, int f, Sym<DOF>& Cm) {
@@ -2003,6 +2022,7 @@ template <int D, int N, int QK> struct Coupling;
 template <int D, int N> struct Coupling<D, N, QK_GENERAL> { Sym<D> q[N]; double m[N]; double dt; };
 template <int D, int N> struct Coupling<D, N, QK_STATIC> { double m[N]; };
 template <int D, int N> struct Coupling<D, N, QK_KRON> { Sym<D / 2> c[N]; double m[N]; };
+template <int D, int N> struct Coupling<D, N, QK_SCALED> : Coupling<D, N, QK_STATIC> {};      // m[k] = mask x s_k: every product below is linear in it, except ...
 
 // G = S^-1 U_k
 template <int D, int N>
@@ -2070,6 +2090,19 @@ DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, QK_STATIC>&
 #pragma unroll
       for (int q = 0; q < D; ++q) if (gp_nz<D>(q, a)) t -= p.u_fix[q * D + a] * B.v[q][c];
       S(a, c) = t;
+    }
+}
+// (... U^T B with B = S^-1 U: the static form above leans on m^2 = m; with a scalar in the mask the second factor is applied here)
+template <int D, int N>
+DGP_HD void coup_sub_UtB_sym(const GnParams& p, const Coupling<D, N, QK_SCALED>& cp, int k, Sym<D>& S, const Mat<D>& B) {
+#pragma unroll
+  for (int a = 0; a < D; ++a)
+#pragma unroll
+    for (int c = a; c < D; ++c) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) if (gp_nz<D>(q, a)) t += p.u_fix[q * D + a] * B.v[q][c];
+      S(a, c) -= cp.m[k] * t;
     }
 }
 // o -= U_k^T v
@@ -2351,7 +2384,8 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
                             const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], const LaneQ<2 * DOF, C, QK>& lq,
                             const double (&rhs)[C][2 * DOF], double (&dx)[C][2 * DOF], ErrAcc& acc, SpdCheck<Ctx>& ok, Hook&& before_pcr) {
   constexpr int D = 2 * DOF;
-  constexpr bool QSTAT = (QK == QK_STATIC);
+  constexpr bool QSTAT = (QK == QK_STATIC || QK == QK_SCALED);
+  constexpr bool QSCAL = (QK == QK_SCALED);
   constexpr int CI = (C > 1) ? C - 1 : 1;       // interior rows (array extent; unused when C == 1)
   constexpr int KL = (C > 1) ? C - 2 : 0;       // last interior row
   const int n = p.n;
@@ -2378,6 +2412,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       const double (&xm)[D] = (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0];
       const double (&xp)[D] = (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0];
       if constexpr (QK == QK_STATIC) static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, rgp[k], acc);
+      else if constexpr (QSCAL) static_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, rgp[k], acc, lq.s[k], (k == 0) ? lq.sm0 : lq.s[k > 0 ? k - 1 : 0]);
       else if constexpr (QK == QK_KRON) kron_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, lq.c[k],
                                                       (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], rgp[k], acc);
       else generic_rhs<DOF>(p, g0 + k, traj_ok && g0 + k < n, x[k], xm, xp, mu_s, mu_ga, lq.q[k], (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0],
@@ -2418,7 +2453,9 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
   auto assemble = [&](int k, Sym<D>& Dk, double (&rk)[D]) {
     const int g = g0 + k;
     const bool valid = traj_ok && g < n;
-    if constexpr (QK == QK_STATIC) {
+    if constexpr (QSCAL) {
+      static_diag<DOF>(p, g, valid, Dk, cp.m[k], lq.s[k], (k == 0) ? lq.sm0 : lq.s[k > 0 ? k - 1 : 0]);
+    } else if constexpr (QK == QK_STATIC) {
       static_diag<DOF>(p, g, valid, Dk, cp.m[k]);
     } else if constexpr (QK == QK_KRON) {
       kron_diag<DOF>(p, g, valid, lq.c[k], (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], Dk, cp.m[k]);
@@ -2445,6 +2482,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
       // left spike L_0 = (block (g, g-1)) = U_{g-1}^T = -(Phi^T Qm)^T = -Qm Phi   (zero for the first row of a trajectory)
       const bool has_prev = traj_ok && g0 > 0 && g0 < n;
       m_prev0 = has_prev ? 1.0 : 0.0;
+      if constexpr (QSCAL) m_prev0 *= lq.sm0;
 #pragma unroll
       for (int a = 0; a < D; ++a) z[0][a] = rk[a];
     } else {
@@ -2535,7 +2573,7 @@ DGP_HD void gn_linear_solve(const GnParams& p, Ctx& cx, int64_t b, int j, bool t
         for (int c = a; c < D; ++c) {                      // D_s -= U_s N'_0 U_s^T   (m_s^2 = m_s)
           double t = Ds(a, c);
 #pragma unroll
-          for (int q = 0; q < D; ++q) if (gp_nz<D>(c, q)) t -= T.v[a][q] * p.u_fix[c * D + q];
+          for (int q = 0; q < D; ++q) if (gp_nz<D>(c, q)) t -= (QSCAL ? ms * T.v[a][q] : T.v[a][q]) * p.u_fix[c * D + q];      // (QK_SCALED: m_s^2 is not m_s)
           Ds(a, c) = t;
         }
       coup_sub_U_v<D, C>(p, cp, C - 1, rs, Pn);           // r_s -= U_s P'_0
@@ -2884,6 +2922,7 @@ template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_KRON>& L) {
   }
 }
 template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_STATIC>&) {}
+template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_SCALED>&) {}
 template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_WB>&) {}
 template <int D, int C> DGP_HD void lane_q_opaque(LaneQ<D, C, QK_WBR>&) {}
 

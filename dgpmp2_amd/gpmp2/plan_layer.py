@@ -124,7 +124,7 @@ class _GNStep(torch.autograd.Function):
     if start.get_device() != dev or goal.get_device() != dev:
       _same_device(dev, startb=start, goalb=goal)
     sd = layer._sdf_args(sdf, dtype, B, dev)
-    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static)
+    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
     proto = layer._err_protos.get((B, dtype, dev))
@@ -142,6 +142,8 @@ class _GNStep(torch.autograd.Function):
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
+    if cv[0] == _capi.DGP_QC_SCALAR:            # the backward kernels read the blocks themselves
+      cv = layer._cov_args(qc, ow, eps, dtype, B, dev, static) if own_info else None
     return dth, err, eex, (thc, stc, goc), (sd, cv)
 
   @staticmethod
@@ -267,7 +269,7 @@ class _GNStepErrors(torch.autograd.Function):
     if start.get_device() != dev or goal.get_device() != dev:
       _same_device(dev, startb=start, goalb=goal)
     sd = layer._sdf_args(sdf, dtype, B, dev)
-    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static)
+    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
     proto = layer._err_protos.get((B, dtype, dev))
@@ -283,6 +285,8 @@ class _GNStepErrors(torch.autograd.Function):
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
+    if cv[0] == _capi.DGP_QC_SCALAR:
+      cv = layer._cov_args(qc, ow, eps, dtype, B, dev, static) if own_info else None
     return dth, err, eex, usg, ugp, uobs, (thc, stc, goc), (sd, cv)
 
   @staticmethod
@@ -525,6 +529,8 @@ class PlanLayer(nn.Module):
     self._info_bufs = {}               # (B, device index, raw stream) -> the int32 flag buffer launches on that stream write
     q = gp_params['Q_c_inv']
     self._qc_rows = [[float(v) for v in row] for row in (q.tolist() if torch.is_tensor(q) else q)]
+    # DGP_QC_SCALAR scales the configuration's Q_c_inv: q_k^2 I (diag_identity) is that only for Q_c_inv = I
+    self._scalar_qc = all(self._qc_rows[i][j] == (1.0 if i == j else 0.0) for i in range(len(self._qc_rows)) for j in range(len(self._qc_rows)))
     self._pc = _capi.get_pycall()      # fails loudly if the library / trampoline have not been built
     self._solver(torch.float64)        # validates the configuration now
 
@@ -608,7 +614,7 @@ class PlanLayer(nn.Module):
     DiffGPMP2Planner tagged as the expand()ed view of its own static covariance."""
     return (qc is None or '_dgp_static' in qc.__dict__, ow is None or '_dgp_static' in ow.__dict__, eps is None or '_dgp_static' in eps.__dict__)
 
-  def _cov_args(self, qc, ow, eps, dtype, B, dev, static=(False, False, False)):
+  def _cov_args(self, qc, ow, eps, dtype, B, dev, static=(False, False, False), scalar_ok=False):
     """Covariance tensors -> (qc_mode, qc_inv, obs_w, eps addresses, keep-alive list).  A static entry selects the constants of the
     handle (no per-state tensor is streamed)."""
     if static == _ALL_STATIC:
@@ -628,8 +634,15 @@ class PlanLayer(nn.Module):
 
     mode, qc_p, ow_p, ep_p = _capi.DGP_QC_STATIC, None, None, None
     if qc is not None and not static[0]:
-      mode = _capi.DGP_QC_QFULL if self._q_full else _capi.DGP_QC_PERSTATE
-      qc_p = prep(qc, (n - 1) * (d * d if self._q_full else dof * dof), 'qc_inv_trajb')
+      # scalar_ok (the forward launch of step()): a tensor the planner tagged as q_k^2 I (dynamics_mode 'diag_identity') goes down as its n - 1 scalars
+      tag = qc.__dict__.get('_dgp_scalar') if (scalar_ok and self._scalar_qc and not self._q_full and n <= 256) else None
+      sc = tag[0] if (tag is not None and tag[1] == qc._version) else None
+      if sc is not None and sc.shape == (B, n - 1):
+        mode = _capi.DGP_QC_SCALAR
+        qc_p = prep(sc, n - 1, 'qc_inv_trajb (one scalar per GP factor)')
+      else:
+        mode = _capi.DGP_QC_QFULL if self._q_full else _capi.DGP_QC_PERSTATE
+        qc_p = prep(qc, (n - 1) * (d * d if self._q_full else dof * dof), 'qc_inv_trajb')
     if ow is not None and not static[1]: ow_p = prep(ow, n * self.nlinks, 'obscov_inv_trajb')
     if eps is not None and not static[2]: ep_p = prep(eps, n * self.nlinks, 'eps_trajb')
     return (mode, qc_p, ow_p, ep_p, keep)

@@ -4,7 +4,7 @@ profiles/tools/devbuild.py library and DGP_FORCE_SHAPE).  Two numbers per case: 
 back-to-back launches / reps (kernel + inter-kernel gap), `kernel_us` = mean of per-kernel begin/end events
 (dgp_time_next_launch; what rocprofv3 reports as the kernel's duration).
 
-  python profiles/tools/ubench.py --what step,solve,bwd,bwd_sdf8 [--covs static|perstate|qfull] [--dof 2|3] [--sdf shared|persample]
+  python profiles/tools/ubench.py --what step,solve,bwd,bwd_sdf8 [--covs static|perstate|qfull|scalar] [--dof 2|3] [--sdf shared|persample]
                                   [--B 4096] [--n 64] [--G 256] [--io f32|f64] [--flags vel|nonhol] [--reps 1000] [--tag text]
 """
 import argparse, ctypes, json, os, sys, time
@@ -64,6 +64,8 @@ def main():
   if a.covs != 'static':
     if a.covs == 'perstate':
       qc = torch.eye(dof, device=dev, dtype=dt).expand(B, n - 1, dof, dof).contiguous(); mode = _capi.DGP_QC_PERSTATE
+    elif a.covs == 'scalar':      # one scalar per GP factor (dynamics_mode diag_identity): DGP_QC_SCALAR, the static kernels with scaled lane masks (step only)
+      qc = torch.ones(B, n - 1, device=dev, dtype=dt); mode = _capi.DGP_QC_SCALAR
     else:
       from oracle import gpmp2_oracle as O
       p = O.OracleParams(dof=dof, total_time_step=n - 1)
@@ -85,7 +87,7 @@ def main():
   for what in a.what.split(','):
     if what == 'step':
       f = lambda k: s.gn_step(B, tp[k % 4], P(start), P(goal), sas[k % len(sas)], covs, P(dth), P(err), P(eex), P(info), st)
-      by = algorithmic_bytes_per_trajectory(n, d, io_bytes=4 if a.io == 'f32' else 8, cov_tensors=(a.covs == 'perstate')) * B
+      by = algorithmic_bytes_per_trajectory(n, d, io_bytes=4 if a.io == 'f32' else 8, cov_tensors=(a.covs in ('perstate', 'scalar'))) * B
     elif what == 'solve':
       tho = torch.empty_like(th0); it = torch.empty(B, dtype=torch.int32, device=dev); eh = torch.empty(B, a.iters, device=dev, dtype=dt)
       eeh = torch.empty_like(eh)

@@ -130,6 +130,7 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
       }
       if (mode == dgp::MODE_STEP) {
         if (qk == dgp::QK_STATIC) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_STATIC>(p, cx);
+        else if (qk == dgp::QK_SCALED) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_SCALED>(p, cx);
         else if (qk == dgp::QK_KRON) dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_KRON>(p, cx);
         else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_STEP, dgp::QK_GENERAL>(p, cx);
       } else if (mode == dgp::MODE_SOLVE) {

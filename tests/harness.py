@@ -113,6 +113,7 @@ class Backend(object):
       H, W = sdf.shape[-2], sdf.shape[-1]
       sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
     mode = _capi.DGP_QC_STATIC if qc is None else (_capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE)
+    if qc is not None and np.asarray(qc).ndim == 2: mode = _capi.DGP_QC_SCALAR      # (B, n-1) scalars: Q_c^-1 = s_k Q_c_inv (dgp_gn_step only)
     _, qc_p = self.to_dev(qc, io)
     _, ow_p = self.to_dev(ow, io)
     _, eps_p = self.to_dev(eps, io)

@@ -35,6 +35,7 @@ def check_step(be, p, th, start, goal, sdf, io, qc=None, ow=None, eps=None, q_fu
   sdf_full = np.broadcast_to(sdf, (B,) + sdf.shape[1:])
   sq, so, se = p.static_covs(B)
   o_qc = sq if qc_ is None else qc_
+  if qc_ is not None and qc_.ndim == 2: o_qc = qc_[:, :, None, None] * p.Q_c_inv      # DGP_QC_SCALAR: one scalar per GP factor, Q_c^-1 = s_k Q_c_inv
   o_ow = so if ow_ is None else ow_.reshape(so.shape)
   o_eps = se if eps_ is None else eps_.reshape(se.shape)
   if oracle_memo is not None and 'r' in oracle_memo:
@@ -426,6 +427,39 @@ def case_static_qc_variants(be, golden, io):
     check_step(be, p, th, start, goal, sdf, io, tag='static Qc dof=%d diag=%s' % (dof, bool(np.all(Qc == np.diag(np.diag(Qc))))))
 
 
+def case_scalar_covariances(be, golden, io):
+  """DGP_QC_SCALAR (the learned mode diag_identity, diff_gpmp2_planner.py:255-258: Q_c^-1 = q_k^2 I): one scalar per GP factor on the static block-elimination
+  kernels with scaled lane masks (QK_SCALED) -- against the oracle on the dense tensors s_k Q_c_inv, and against the per-state (Kronecker) kernels on the same
+  tensors; identity and diagonal Q_c_inv, dof 2 and 3 (+ non-holonomic, velocity limits), full, ragged and single-lane lengths, with and without per-state
+  obstacle weights / epsilons."""
+  rs = np.random.RandomState(33)
+  confs = [(2, 64, 5, None, {}), (2, 33, 3, np.diag([0.7, 2.5]), {}), (2, 16, 9, None, dict(use_vel_limits=True, K_v=0.01, v_x=1.0, v_y=1.0)),
+           (3, 64, 4, None, dict(non_holonomic=True, K_d=0.01)), (3, 21, 3, np.diag([0.5, 1.0, 3.0]), {}), (2, 5, 2, None, {}), (2, 2, 1, None, {})]
+  for dof, n, B, Qc, kw in confs:
+    p = O.OracleParams(dof=dof, total_time_step=n - 1, Q_c_inv=Qc, **kw)
+    d = 2 * dof
+    start = np.zeros((B, 1, d)); goal = np.zeros((B, 1, d))
+    start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2))
+    if dof == 3: goal[:, 0, 2] = rs.uniform(-1.5, 1.5, B)
+    th = np.zeros((B, n, d))
+    t = np.linspace(0, 1, n)[None, :, None]
+    th[:, :, :dof] = start[:, :, :dof] + t * (goal[:, :, :dof] - start[:, :, :dof])
+    th[:, :, dof:] = (goal[:, :, :dof] - start[:, :, :dof]) / 10.0
+    th = th + rs.randn(B, n, d) * 0.1
+    sdf = O.circles_sdf(96, O.C2_CIRCLES)[None, None]
+    s_ = rs.uniform(0.3, 3.0, (B, n - 1)) ** 2
+    for with_obs in (False, True):
+      ow = rs.uniform(50, 2e4, (B, n, 1, 1)) if with_obs else None
+      eps = rs.uniform(0.1, 0.6, (B, n, 1, 1)) if with_obs else None
+      tag = 'scalar covs dof=%d n=%d %s%s' % (dof, n, 'diag' if Qc is not None else 'identity', ' + obstacle tensors' if with_obs else '')
+      d1, e1, x1 = check_step(be, p, th, start, goal, sdf, io, qc=s_, ow=ow, eps=eps, tag=tag)
+      dense = rnd(s_, io)[:, :, None, None] * p.Q_c_inv
+      d2, e2, x2 = check_step(be, p, th, start, goal, sdf, io, qc=dense, ow=ow, eps=eps, tag=tag + ' (per-state tensors)')
+      if io == 'f64':
+        assert rel_err(d1, d2) < 1e-9 and rel_err(e1, e2) < 1e-12 and rel_err(x1, x2) < 1e-12, (tag, rel_err(d1, d2), rel_err(e1, e2), rel_err(x1, x2))
+
+
+ALL_CASES.append(case_scalar_covariances)
 ALL_CASES.append(case_static_qc_variants)
 ALL_CASES.append(case_tiny_and_odd_sizes)
 ALL_CASES.append(case_shared_sdf_gradient_partial_copies)

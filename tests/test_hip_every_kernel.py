@@ -90,6 +90,31 @@ def test_hip_every_forward_kernel_vs_c_oracle(be, dof, io, monkeypatch):
 
 @pytest.mark.parametrize('io', ['f64', 'f32'])
 @pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_scaled_kernel_vs_c_oracle(be, dof, io, monkeypatch):
+  """The 36 QK_SCALED step kernels (DGP_QC_SCALAR: one scalar per GP factor, the learned mode diag_identity): every launch shape, a length that fills it
+  and a ragged one, per-state obstacle weights / epsilons next to the scalars -- against the C oracle on the dense tensors s_k I."""
+  rs = np.random.RandomState(300 * dof + (io == 'f32'))
+  bad = []
+  for lpt, c in SHAPES:
+    monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+    for n in (lpt * c, max(2, lpt * c - 3)):
+      B = 64 // lpt + 1
+      p, th, start, goal, sdf, _, ow, eps, _ = _inputs(rs, dof, n, B, 'perstate', io)
+      s_ = PC.rnd(rs.uniform(0.3, 3.0, (B, n - 1)) ** 2, io)
+      sh = (B, n, 1, 1)
+      dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=s_, ow=ow, eps=eps, io=io)
+      dense = s_[:, :, None, None] * np.eye(dof)
+      c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, qc=dense, ow=ow.reshape(sh), eps=eps.reshape(sh))
+      e = PC.rel_err_per_traj(dth, c_dth) if np.all(np.isfinite(dth)) else np.inf
+      ee = PC.rel_err(err, c_err) if np.all(np.isfinite(err)) else np.inf
+      ex = PC.rel_err(eex, c_eex) if np.all(np.isfinite(eex)) else np.inf
+      if not (e < PC.TOL[io] and ee < 10 * PC.TOL_ERR[io] and ex < 10 * PC.TOL_ERR[io] and not info.any()):
+        bad.append(('dof %d %s shape (%d,%d) n %d' % (dof, io, lpt, c, n), e, ee, ex))
+  assert not bad, '%d scaled-mask kernel instantiations differ from the C oracle:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
 def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
   """Every BACKWARD kernel instantiation (2 robots x 2 I/O types x 9 shapes x static [block elimination / Woodbury, exact fit and ragged] /
   general / per-state) on one small batch each, every gradient tensor, against torch autograd over the dense restatement of the

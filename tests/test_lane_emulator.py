@@ -31,6 +31,8 @@ def test_emul_backward_fd(be, golden): PC.case_backward_fd(be, golden, 'f64')
 def test_emul_tiny_sizes(be, golden): PC.case_tiny_and_odd_sizes(be, golden, 'f64')
 def test_emul_sdf_grad_copies(be, golden): PC.case_shared_sdf_gradient_partial_copies(be, golden, 'f64')
 def test_emul_static_qc_variants(be, golden): PC.case_static_qc_variants(be, golden, 'f64')
+def test_emul_scalar_covariances(be, golden): PC.case_scalar_covariances(be, golden, 'f64')
+def test_emul_scalar_covariances_f32(be, golden): PC.case_scalar_covariances(be, golden, 'f32')
 def test_emul_unaligned(be, golden): PC.case_unaligned_buffers(be, golden, 'f64')
 def test_emul_unaligned_f32(be, golden): PC.case_unaligned_buffers(be, golden, 'f32')
 def test_emul_solve_with_covariances(be, golden): PC.case_solve_with_covariances(be, golden, 'f64')

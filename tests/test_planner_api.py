@@ -137,6 +137,40 @@ def test_training_iteration_is_capturable_in_a_hip_graph(golden):
   assert not torch.equal(replayed[0], eager[0])
 
 
+def test_diag_identity_covariances_run_the_scaled_static_kernels(golden):
+  """dynamics_mode 'diag_identity' (the reference's default learned mode): get_covariances() returns q_k^2 I blocks AND tags them with the scalars, PlanLayer.forward
+  hands the scalars to the kernel (DGP_QC_SCALAR) -- same step as with the untagged blocks (the per-state kernels), same gradients (the backward reads the blocks),
+  and an in-place edit of the blocks voids the tag."""
+  from dgpmp2_amd import _capi
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  pl = planner.plan_layer
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  start, goal, th = T(g['start']), T(g['goal']), T(g['th_hist'][2])
+  gen = torch.Generator(device=DEV).manual_seed(9)
+  out = (torch.rand(B, 1, (n - 1) + n, device=DEV, dtype=torch.float64, generator=gen) + 0.5).requires_grad_(True)
+  out.data[:, :, n - 1:] *= 80.0                                     # obstacle part: o^2 ~ 1e3 .. 1e4
+
+  def run(tagged):
+    qc, ow = planner.get_covariances(out, 'diag_identity')
+    assert '_dgp_scalar' in qc.__dict__
+    if not tagged: qc = qc * 1.0                                     # same values, no tag
+    mode = pl._cov_args(qc, ow, None, torch.float64, B, 0, (False, False, True), True)[0]
+    dth, err, eex = pl(th, start, goal, None, sdf, qc, ow, None)
+    gr, = torch.autograd.grad((dth * dth).sum() + eex.sum(), out)
+    return mode, dth.detach(), err, eex.detach(), gr
+
+  m1, d1, e1, x1, g1 = run(True)
+  m0, d0, e0, x0, g0 = run(False)
+  assert m1 == _capi.DGP_QC_SCALAR and m0 == _capi.DGP_QC_PERSTATE
+  assert rel_err(d1.cpu().numpy(), d0.cpu().numpy()) < 1e-9 and rel_err(e1.cpu().numpy(), e0.cpu().numpy()) < 1e-12
+  assert rel_err(x1.cpu().numpy(), x0.cpu().numpy()) < 1e-12 and rel_err(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-8
+  qc, ow = planner.get_covariances(out.detach(), 'diag_identity')
+  qc.mul_(2.0)                                                        # the blocks no longer are what the tag says
+  assert pl._cov_args(qc, ow, None, torch.float64, B, 0, (False, False, True), True)[0] == _capi.DGP_QC_PERSTATE
+
+
 def test_step_float32_tensors(golden):
   g = golden('g3_c2mini')
   B, n, G = 8, 64, int(g['G'])
