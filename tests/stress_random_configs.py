@@ -56,8 +56,16 @@ for case in range(args.cases):
     else:
       A = rs.randn(B, n - 1, d, d) * 0.2; qc = (np.eye(d) + A @ np.swapaxes(A, -1, -2)) * rs.uniform(0.5, 3.0); q_full = True
   r = lambda a: None if a is None else PC.rnd(a, io)
+  # every other per-state case with a diagonal Q_c_inv becomes a ONE-SCALAR-PER-FACTOR case (dynamics_mode diag_identity): the step receives the (B, n-1) scalars
+  # (DGP_QC_SCALAR: the static kernels with scaled lane masks), everything else -- oracles, fused loop, backward -- the dense tensors s_k Q_c_inv (no extra random draws)
+  qc_step = None
+  if cov == 'perstate' and qmode != 'full' and n <= 256 and case % 2 == 0:
+    s2 = r(1.0 + 4.0 * A[..., 0, 0] ** 2)
+    qc = s2[:, :, None, None] * p.Q_c_inv
+    qc_step = s2
+    cov = 'scalar'
   th, start, goal, sdf, qc, ow, eps = r(th), r(start), r(goal), r(sdf), r(qc), r(ow), r(eps)
-  dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
+  dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc if qc_step is None else qc_step, ow=ow, eps=eps, q_full=q_full, io=io)
   sh = (B, n, 1, 1)
   c_dth, c_err, c_eex, c_info = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh),
                                            q_full=q_full, nthreads=4)
