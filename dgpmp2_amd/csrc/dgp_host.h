@@ -237,7 +237,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   if (covs) {
     if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
     if (covs->qc_mode == DGP_QC_SCALAR && !scalar_qc_ok)
-      return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is implemented by dgp_gn_step only (pass the (B,n-1,dof,dof) tensors elsewhere)");
+      return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is implemented by dgp_gn_step[_errors] and their backward only (pass the (B,n-1,dof,dof) tensors elsewhere)");
     if (covs->qc_mode == DGP_QC_SCALAR && h->base.qc_diag == 0)
       return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR needs a diagonal Q_c_inv in the configuration");
     if ((covs->qc_mode == DGP_QC_STATIC) != (covs->qc_inv == nullptr))
@@ -293,7 +293,8 @@ inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, cons
                          const DgpCovs* covs, const void* dtheta, const void* g_dtheta, const void* g_err_ext, void* g_th,
                          void* g_start, void* g_goal, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* g_qc_inv,
                          void* g_obs_w, void* g_eps, dgp::GnParams& p, dgp::GnGradParams& g) {
-  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p);
+  int rc = fill_call(h, batch, th, start, goal, sdf, covs, p, /*sdf_optional=*/false, /*scalar_qc_ok=*/true);
+  if (rc == DGP_OK && p.qc_mode == dgp::QC_SCALAR && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is not implemented for num_states > 256");
   if (rc != DGP_OK) return rc;
   if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
   if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);

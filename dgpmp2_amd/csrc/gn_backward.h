@@ -264,7 +264,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   // covariances with velocity limits 64.0 -> 54.2 us (scratch 848 -> 408 B per lane), q_full tensors 122.9 -> 101.7 us; the per-state
   // (Kronecker) kernel 68.0 -> 69.3 and the Woodbury kernel 36.7 -> 37.6 us lose and keep their rows in registers.
 #ifndef DGP_BWD_RELOAD_D6
-#define DGP_BWD_RELOAD_D6 3      // QK_GENERAL | QK_STATIC
+#define DGP_BWD_RELOAD_D6 35     // QK_GENERAL | QK_STATIC | QK_SCALED
 #endif
 #ifndef DGP_BWD_RELOAD_D4
 #define DGP_BWD_RELOAD_D4 0      // (measured: see profiles/r04_kernel_variants.txt)
@@ -396,7 +396,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g -> g+1), owned by this row: e = x_{g+1} - Phi x_g, H = [Phi, -I], K = Q^-1
     if (g < n - 1) {
       Sym<D> Q;
-      if constexpr (QK == QK_STATIC || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
+      if constexpr (QK == QK_STATIC || QK == QK_SCALED || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
       else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, lq.c[k], Q);
       else Q = lq.q[k];
       double e[D], u[D], rho[D];
@@ -411,12 +411,16 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       }
       // dL = u^T Q de + ebar e^T Qfix de,  de = dx_{g+1} - Phi dx_g   ->  this row's share: -Phi^T (Q u + ebar Qfix e)
       double t[D];
-      if constexpr (QK == QK_STATIC || is_wb(QK)) {
+      if constexpr (QK == QK_STATIC || QK == QK_SCALED || is_wb(QK)) {
         // static covariances with a diagonal Q_c_inv: Q IS the fixed Q^-1 and entry (a, c) is zero unless a = c (mod dof) -- half the products
         // (two thirds at d = 6) vanish, and the two terms share the matrix
         double w[D];
+        // (QK_SCALED: the factor's scalar weighs the system (u), not err_ext (ebar) or the unweighted error (ggp))
 #pragma unroll
-        for (int c = 0; c < D; ++c) w[c] = u[c] + ebar * e[c];
+        for (int c = 0; c < D; ++c) {
+          if constexpr (QK == QK_SCALED) w[c] = lq.s[k] * u[c] + ebar * e[c];
+          else w[c] = u[c] + ebar * e[c];
+        }
 #pragma unroll
         for (int a = 0; a < D; ++a) {
           double s = 0.0;
@@ -452,7 +456,16 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
             const double va = e[a] - rho[a], vc = e[c] - rho[c];
             Gm[a][c] = u[a] * e[c] - 0.5 * (u[a] * vc + va * u[c]);
           }
-        if (p.qc_mode == QC_QFULL) {
+        if constexpr (QK == QK_SCALED) {
+          // the gradient of the dof x dof blocks s_k I, entry by entry as for per-state tensors (it does not depend on Q)
+          const int64_t base = (b * (n - 1) + g) * (DOF * DOF);
+#pragma unroll
+          for (int a = 0; a < DOF; ++a)
+#pragma unroll
+            for (int c = 0; c < DOF; ++c)
+              st<IO>(gp.g_qc, base + a * DOF + c,
+                     p.qa * Gm[a][c] + p.qb * (Gm[a][DOF + c] + Gm[DOF + a][c]) + p.qc_ * Gm[DOF + a][DOF + c]);
+        } else if (p.qc_mode == QC_QFULL) {
           const int64_t base = (b * (n - 1) + g) * (D * D);
 #pragma unroll
           for (int a = 0; a < D; ++a)
@@ -472,7 +485,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
     // ---- GP factor (g-1 -> g): this row's share is +(Q_{g-1} u_{g-1} + ebar Qfix e_{g-1})
     if (g > 0) {
       Sym<D> Q;
-      if constexpr (QK == QK_STATIC || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
+      if constexpr (QK == QK_STATIC || QK == QK_SCALED || is_wb(QK)) fixed_Qinv<DOF>(p, Q);
       else if constexpr (QK == QK_KRON) kron_to_sym<DOF>(p, (k == 0) ? lq.cm0 : lq.c[k > 0 ? k - 1 : 0], Q);
       else Q = (k == 0) ? lq.qm0 : lq.q[k > 0 ? k - 1 : 0];
       double e[D], u[D];
@@ -483,10 +496,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         u[a] = (lm[a] + dt * lm[DOF + a]) - lk[a];
         u[DOF + a] = lm[DOF + a] - lk[DOF + a];
       }
-      if constexpr (QK == QK_STATIC || is_wb(QK)) {
+      if constexpr (QK == QK_STATIC || QK == QK_SCALED || is_wb(QK)) {
         double w[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) w[c] = u[c] + ebar * e[c];
+        for (int c = 0; c < D; ++c) {
+          if constexpr (QK == QK_SCALED) w[c] = ((k == 0) ? lq.sm0 : lq.s[k > 0 ? k - 1 : 0]) * u[c] + ebar * e[c];
+          else w[c] = u[c] + ebar * e[c];
+        }
 #pragma unroll
         for (int a = 0; a < D; ++a) {
           double s = 0.0;

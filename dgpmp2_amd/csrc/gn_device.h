@@ -227,7 +227,7 @@ inline int launch_group(int mode, const dgp::GnParams& p) {
   if (mode == dgp::MODE_EVAL) return GROUP_GENERIC;
   if (mode == MODE_CHAIN) return GROUP_CHAIN;
   const int qk = dgp::kernel_variant(p);
-  if (qk == dgp::QK_SCALED) return GROUP_STATIC;      // (STEP only, host-checked)
+  if (qk == dgp::QK_SCALED) return mode == MODE_BACKWARD ? GROUP_BACKWARD : GROUP_STATIC;      // (STEP and the single-step backward, host-checked)
   if (qk == dgp::QK_KRON) return GROUP_KRON;
   if (mode == MODE_BACKWARD) return GROUP_BACKWARD;
   return qk == dgp::QK_STATIC ? GROUP_STATIC : GROUP_GENERIC;
@@ -295,6 +295,10 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));            \
       else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_KRON>));                                             \
     } else {                                                                                                               \
+      if (dgp::kernel_variant(p) == dgp::QK_SCALED) {                                                                      \
+        DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_SCALED>));                                              \
+        return hipGetLastError();                                                                                          \
+      }                                                                                                                    \
       if constexpr (CC == 4) {                                                                                             \
         if (qstat && dgp::wb_applies(p, L, CC)) {                                                                          \
           if (p.n == L * CC) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB>));                             \

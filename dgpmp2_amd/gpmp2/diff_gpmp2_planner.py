@@ -356,8 +356,8 @@ class DiffGPMP2Planner(nn.Module):
       n_gp = self.num_gp_factors
       q = out[:, 0, 0:n_gp].reshape(B, self.num_gp_factors, 1, 1)
       qc_inv_traj = (q * q.transpose(2, 3)) * torch.eye(self.dof, device=out.device, dtype=out.dtype)
-      # the tensor IS q_k^2 I: PlanLayer.forward may hand the kernel the n - 1 scalars instead of the blocks (DGP_QC_SCALAR: the static kernels
-      # with scaled lane masks); the backward and every other consumer read the blocks themselves
+      # the tensor IS q_k^2 I: PlanLayer.forward (and its backward) may hand the kernels the n - 1 scalars instead of the blocks (DGP_QC_SCALAR: the
+      # static kernels with scaled lane masks); every other consumer reads the blocks themselves
       qc_inv_traj.__dict__['_dgp_scalar'] = ((q * q).detach().reshape(B, self.num_gp_factors), qc_inv_traj._version)      # (the version: an in-place edit of the blocks voids the tag)
     elif mode == 'diag':
       raise NotImplementedError

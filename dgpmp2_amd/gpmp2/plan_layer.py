@@ -142,8 +142,6 @@ class _GNStep(torch.autograd.Function):
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
-    if cv[0] == _capi.DGP_QC_SCALAR:            # the backward kernels read the blocks themselves
-      cv = layer._cov_args(qc, ow, eps, dtype, B, dev, static) if own_info else None
     return dth, err, eex, (thc, stc, goc), (sd, cv)
 
   @staticmethod
@@ -285,8 +283,6 @@ class _GNStepErrors(torch.autograd.Function):
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
                          '(the reference raises from torch.cholesky here)' % (int(info.sum()), B))
-    if cv[0] == _capi.DGP_QC_SCALAR:
-      cv = layer._cov_args(qc, ow, eps, dtype, B, dev, static) if own_info else None
     return dth, err, eex, usg, ugp, uobs, (thc, stc, goc), (sd, cv)
 
   @staticmethod
@@ -634,7 +630,8 @@ class PlanLayer(nn.Module):
 
     mode, qc_p, ow_p, ep_p = _capi.DGP_QC_STATIC, None, None, None
     if qc is not None and not static[0]:
-      # scalar_ok (the forward launch of step()): a tensor the planner tagged as q_k^2 I (dynamics_mode 'diag_identity') goes down as its n - 1 scalars
+      # scalar_ok (step() / step_with_errors(), forward and backward launches): a tensor the planner tagged as q_k^2 I (dynamics_mode 'diag_identity') goes down as its
+      # n - 1 scalars; the gradient the backward kernel writes is that of the (B,n-1,dof,dof) blocks all the same
       tag = qc.__dict__.get('_dgp_scalar') if (scalar_ok and self._scalar_qc and not self._q_full and n <= 256) else None
       sc = tag[0] if (tag is not None and tag[1] == qc._version) else None
       if sc is not None and sc.shape == (B, n - 1):

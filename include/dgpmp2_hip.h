@@ -53,7 +53,7 @@ extern "C" {
 #define DGP_QC_PERSTATE 1   /* qc_inv (B, n-1, dof, dof): Q^-1 built as in gp_factor.py:65-73                       */
 #define DGP_QC_QFULL    2   /* qc_inv (B, n-1, d, d) is Q^-1 itself ('q_full', plan_layer.py:90)                    */
 #define DGP_QC_SCALAR   3   /* qc_inv (B, n-1): one scalar s_k per GP factor, Q_c^-1 = s_k * DgpConfig.Q_c_inv (diagonal) --      */
-                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] only, n <= 256 */
+                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] and their backward (g_qc_inv: the (B,n-1,dof,dof) gradient of the blocks s_k I), n <= 256 */
 
 /* Constructor arguments of PlanLayer / DiffGPMP2Planner that the math depends on
  * (plan_layer.py:14-81).  All lengths in the reference's units. */

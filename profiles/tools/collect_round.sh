@@ -30,7 +30,7 @@ timeout 900 python profiles/tools/shape_sweep.py 2>/dev/null > "$O/shape_sweep.j
 timeout 600 python profiles/tools/microbench.py 2>/dev/null | grep -a '^{' > "$O/microbench.jsonl"
 U="python profiles/tools/ubench.py"
 ( $U --what step,solve,eval,bwd,bwd_sdf8,bwd_sdf16; DGP_NO_WOODBURY=1 $U --what step,solve,bwd --tag block_elimination; $U --what step,solve,bwd,bwd_sdf16 --covs perstate; $U --what step,solve,bwd --covs qfull; $U --what step,solve,bwd --dof 3;
-  DGP_NO_WOODBURY=1 $U --what step,solve,bwd --dof 3 --tag block_elimination; $U --what step,solve --dof 3 --covs perstate; $U --what step --covs scalar; $U --what step --covs scalar --dof 3; $U --what step --B 32768; $U --what step --n 128 --B 2048; $U --what step --n 256 --B 1024;
+  DGP_NO_WOODBURY=1 $U --what step,solve,bwd --dof 3 --tag block_elimination; $U --what step,solve --dof 3 --covs perstate; $U --what step,bwd --covs scalar; $U --what step,bwd --covs scalar --dof 3; $U --what bwd --covs perstate --dof 3; $U --what step --B 32768; $U --what step --n 128 --B 2048; $U --what step --n 256 --B 1024;
   $U --what step --flags vel; $U --what step,bwd,bwd_sdf --sdf persample --grids 6; $U --what step --sdf persample --grids 1; $U --what bwd,bwd_sdf8,bwd_sdf16 --th 0 --tag straight_line_init;
   $U --what step,bwd --io f64; $U --what traced,chain; $U --what traced,chain --dof 3; $U --what solve,traced,chain --io f64 ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
 # probes: built HERE before the call (profiles/tools/build_probes.sh cross-compiles them into dgpmp2_amd/lib/, which travels with the snapshot)

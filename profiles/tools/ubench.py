@@ -106,7 +106,7 @@ def main():
     elif what.startswith('bwd'):
       g = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
       ge = torch.ones(B, device=dev, dtype=dt)
-      gq = torch.empty_like(keep[0]) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
+      gq = (torch.empty(B, n - 1, dof, dof, device=dev, dtype=dt) if a.covs == 'scalar' else torch.empty_like(keep[0])) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
       gp = torch.empty(B, n, device=dev, dtype=dt) if covs else None
       copies = int(what[7:]) if what.startswith('bwd_sdf') and what[7:] else 1
       gs = None

@@ -143,6 +143,7 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
         dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC, true>(p, *g, cx);      // (dgp_gn_solve_backward: static covariances only, host-checked)
       } else {
         if (qk == dgp::QK_STATIC) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC>(p, *g, cx);
+        else if (qk == dgp::QK_SCALED) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_SCALED>(p, *g, cx);
         else if (qk == dgp::QK_KRON) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_KRON>(p, *g, cx);
         else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_GENERAL>(p, *g, cx);
       }

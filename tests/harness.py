@@ -164,7 +164,8 @@ class Backend(object):
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
     sdf = np.asarray(sdf)
     gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
-    gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
+    qshape = None if qc is None else (np.asarray(qc).shape if np.asarray(qc).ndim != 2 else np.asarray(qc).shape + (p.dof, p.dof))      # DGP_QC_SCALAR: the gradient of the blocks s_k I
+    gqc, gqc_p = self.empty(qshape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
     stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]

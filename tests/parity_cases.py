@@ -457,6 +457,17 @@ def case_scalar_covariances(be, golden, io):
       d2, e2, x2 = check_step(be, p, th, start, goal, sdf, io, qc=dense, ow=ow, eps=eps, tag=tag + ' (per-state tensors)')
       if io == 'f64':
         assert rel_err(d1, d2) < 1e-9 and rel_err(e1, e2) < 1e-12 and rel_err(x1, x2) < 1e-12, (tag, rel_err(d1, d2), rel_err(e1, e2), rel_err(x1, x2))
+      # the backward: the scaled-mask kernels (scalars in) against the Kronecker kernels (blocks in) -- every gradient, incl. the dense (B,n-1,dof,dof) one of the blocks
+      gb = rnd(rs.randn(B, n, d), io); ge = rnd(rs.randn(B), io)
+      a_ow = None if ow is None else rnd(ow, io).reshape(B, -1); a_eps = None if eps is None else rnd(eps, io).reshape(B, -1)
+      args = (p, rnd(th, io), rnd(start, io), rnd(goal, io), rnd(sdf, io), d2, gb, ge)
+      r1 = be.backward(*args, qc=rnd(s_, io), ow=a_ow, eps=a_eps, io=io)
+      r2 = be.backward(*args, qc=dense, ow=a_ow, eps=a_eps, io=io)
+      for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
+        if r2[key] is None: continue
+        scale = max(np.abs(r2[key]).max(), np.abs(r2['th']).max() if key == 'sdf' else 0.0, 1e-300 if io == 'f64' else 1e-6 * np.abs(r2['th']).max())
+        eb = np.abs(r1[key] - r2[key]).max() / scale
+        assert eb < (1e-8 if io == 'f64' else 3e-3), (tag, 'backward', key, eb)
 
 
 ALL_CASES.append(case_scalar_covariances)

@@ -157,7 +157,7 @@ for case in range(args.cases):
     gbar = rs.randn(B, n, d); gext = rs.randn(B)
     shared = sdf.shape[0] == 1
     kwb = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io, sdf_copies=(16 if shared and case % 2 else 1))
-    rh = be.backward(p, th, start, goal, sdf, dth, r(gbar), r(gext), **kwb)
+    rh = be.backward(p, th, start, goal, sdf, dth, r(gbar), r(gext), **dict(kwb, qc=qc if qc_step is None else qc_step))      # (scalar-mode cases: the scaled-mask backward)
     ro = AT.step_gradients(p, th, start, goal, sdf, r(gbar), r(gext), qc=qc, ow=ow, eps=eps, q_full=q_full)
     for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
       if rh[key] is None: continue

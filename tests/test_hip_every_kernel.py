@@ -91,7 +91,7 @@ def test_hip_every_forward_kernel_vs_c_oracle(be, dof, io, monkeypatch):
 @pytest.mark.parametrize('io', ['f64', 'f32'])
 @pytest.mark.parametrize('dof', [2, 3])
 def test_hip_every_scaled_kernel_vs_c_oracle(be, dof, io, monkeypatch):
-  """The 36 QK_SCALED step kernels (DGP_QC_SCALAR: one scalar per GP factor, the learned mode diag_identity): every launch shape, a length that fills it
+  """The 36 QK_SCALED step kernels and the 36 backward kernels (DGP_QC_SCALAR: one scalar per GP factor, the learned mode diag_identity): every launch shape, a length that fills it
   and a ragged one, per-state obstacle weights / epsilons next to the scalars -- against the C oracle on the dense tensors s_k I."""
   rs = np.random.RandomState(300 * dof + (io == 'f32'))
   bad = []
@@ -110,6 +110,15 @@ def test_hip_every_scaled_kernel_vs_c_oracle(be, dof, io, monkeypatch):
       ex = PC.rel_err(eex, c_eex) if np.all(np.isfinite(eex)) else np.inf
       if not (e < PC.TOL[io] and ee < 10 * PC.TOL_ERR[io] and ex < 10 * PC.TOL_ERR[io] and not info.any()):
         bad.append(('dof %d %s shape (%d,%d) n %d' % (dof, io, lpt, c, n), e, ee, ex))
+      # ... and the 36 backward kernels of the same variant against the Kronecker kernels on the dense blocks (themselves pinned to the autograd oracle above)
+      gb = PC.rnd(rs.randn(B, n, 2 * dof), io); ge = PC.rnd(rs.randn(B), io)
+      r1 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=s_, ow=ow, eps=eps, io=io)
+      r2 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=PC.rnd(dense, io), ow=ow, eps=eps, io=io)
+      for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
+        # (the grid gradient is a sum of signed tap contributions accumulated by atomics: judged against the size of the summands, for which the trajectory gradient stands in)
+        scale = max(np.abs(r2[key]).max(), np.abs(r2['th']).max() if key == 'sdf' else 0.0, (1e-300 if io == 'f64' else 1e-6 * np.abs(r2['th']).max()))
+        eb = np.abs(r1[key] - r2[key]).max() / scale if np.all(np.isfinite(r1[key])) else np.inf
+        if not eb < (1e-7 if io == 'f64' else 5e-3): bad.append(('dof %d %s shape (%d,%d) n %d backward' % (dof, io, lpt, c, n), key, eb))
   assert not bad, '%d scaled-mask kernel instantiations differ from the C oracle:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
