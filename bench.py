@@ -472,6 +472,26 @@ def planner_api_backward_rate(device, reps=200):
     dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc, ow, ep)
     torch.autograd.grad((dth, sg, gp_, ob), leaves, (g, cws, cw, cw))
 
+  # the same iteration in the reference's DEFAULT learned mode, dynamics_mode 'diag_identity' (diff_gpmp2_planner.py:255-258): the learn module's output vector ->
+  # get_covariances -> q_k^2 I blocks (tagged with their scalars: DGP_QC_SCALAR, the static kernels with scaled lane masks) + obstacle weights; gradients w.r.t.
+  # the trajectory and the module output
+  lm_out = torch.cat([torch.ones(B, 1, n - 1, device=device), torch.full((B, 1, n), 100.0, device=device)], dim=2).requires_grad_(True)
+
+  with torch.no_grad():
+    qc_t, ow_t = planner.get_covariances(lm_out, 'diag_identity')
+  tag = qc_t.__dict__['_dgp_scalar'][0]
+  qc_l = qc_t.detach().clone().requires_grad_(True); ow_l = ow_t.detach().clone().requires_grad_(True)
+  qc_l.__dict__['_dgp_scalar'] = (tag, qc_l._version)      # (what get_covariances puts on the tensor it returns)
+
+  def train_iteration_diag_identity_layer_only():      # the layer's share: the tagged blocks as leaves, no covariance construction in the measurement
+    dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc_l, ow_l, None)
+    torch.autograd.grad((dth, sg, gp_, ob), (thr, qc_l, ow_l), (g, cws, cw, cw))
+
+  def train_iteration_diag_identity():
+    qc_s, ow_s = planner.get_covariances(lm_out, 'diag_identity')
+    dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc_s, ow_s, None)
+    torch.autograd.grad((dth, sg, gp_, ob), (thr, lm_out), (g, cws, cw, cw))
+
   # planner.forward with the graph kept (examples/diff_gpmp2_2d_example.py:77): 10 GN iterations + the backward pass through all of them, two launches
   sdf_leaf = sdf.clone().requires_grad_(True)
   planner.optim_params['tol_delta'] = 0.0            # all 10 iterations, as the fused_forward block
@@ -508,11 +528,13 @@ def planner_api_backward_rate(device, reps=200):
 
   a, b = wall(static_fb), wall(learned_fb)
   t2, t1 = wall(train_iteration_two_calls), wall(train_iteration_fused)
+  tdi = wall(train_iteration_diag_identity)
   try:
     ga, gt1, gk = wall(graphed(static_fb)), wall(graphed(train_iteration_fused)), wall(graphed(tbptt_fb)) / 10.0
+    gdi = wall(graphed(train_iteration_diag_identity)); gdl = wall(graphed(train_iteration_diag_identity_layer_only))
   except Exception as e:      # noqa: BLE001  (measurement extra: a torch build without graph capture must not cost the bench line)
     print('bench: HIP-graph capture of the training iteration failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
-    ga = gt1 = gk = None
+    ga = gt1 = gk = gdi = gdl = None
   reps = max(20, reps // 10)
   c = wall(tbptt_fb) / 10.0
   fb = wall(forward_backward)
@@ -522,6 +544,10 @@ def planner_api_backward_rate(device, reps=200):
                                        'without Python, Function.apply or the autograd engine -- what is left is the kernels (results bit-identical to the eager calls, '
                                        'tests/test_planner_api.py)'},
           'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1, 'step_with_errors_hip_graph_replay_us': gt1,
+                                  'diag_identity_mode': {'step_with_errors_us': tdi, 'hip_graph_replay_us': gdi, 'layer_only_hip_graph_replay_us': gdl,
+                                                         'note': "the reference's default learned mode: get_covariances(out, 'diag_identity') -> one scalar per GP factor -> DGP_QC_SCALAR "
+                                                                 '(scaled-mask static kernels, forward and backward).  get_covariances and its backward -- a dozen small torch kernels: slices, q q^T, x I -- are inside the first two '
+                                                                 'figures and cost more than the solver; layer_only: the tagged blocks as leaves'},
                                   'note': 'learned covariances (per-state qc_inv / obscov_inv / eps that require grad): step + unweighted errors at th + dtheta + '
                                           'backward of a loss on all four outputs w.r.t. all four inputs, wall per iteration -- PlanLayer.forward + '
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '

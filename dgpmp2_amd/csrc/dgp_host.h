@@ -320,7 +320,7 @@ inline int fill_eval_backward(const DgpHandle* h, int32_t batch, const void* th,
   if (no_grid && (g_err_ext || g_unw_obs || g_sdf))
     return fail(DGP_EINVAL, "sdf may be NULL only when g_err_ext, g_unw_obs and g_sdf (what reads / writes the grid) are NULL");
   DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
-  if (covs && (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_QFULL)) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+  if (covs && (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR)) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);      // (whatever the mode: only eps is read)
   int rc = fill_call(h, batch, th, start, goal, sdf, &c, p, /*sdf_optional=*/true);
   if (rc != DGP_OK) return rc;
   if (no_grid) p.sdf = nullptr;

@@ -54,6 +54,47 @@ class _PerSampleHistory(object):
     return 'PerSampleHistory(%d samples)' % len(self)
 
 
+class _SquaredCovs(torch.autograd.Function):
+  """get_covariances for single-link robots in the modes whose tensors are plain squares of the learn module's output (diff_gpmp2_planner.py:247-290 with nlinks = 1:
+  q q^T and o o^T of 1 x 1 blocks): 'fix_dynamics' and 'diag_identity', with or without learned epsilons -- the same values bit for bit (x * x, and x * x times
+  the 0 / 1 entries of the identity), in 3-4 small kernels forward and 4 backward instead of the ~20 that autograd spends on the slices, outer products and
+  broadcasts of the literal formulation.  Under HIP-graph replay of a training iteration that glue costs more than the solver."""
+
+  @staticmethod
+  def forward(ctx, out, n_gp, n_obs, dof, learn_eps):
+    B = out.shape[0]
+    v = out[:, 0, :]
+    sq = v * v
+    ctx.save_for_backward(out)
+    ctx.dims = (n_gp, n_obs, dof, learn_eps)
+    res = []
+    if n_gp:
+      s = sq[:, :n_gp].contiguous()
+      res.append(s.view(B, n_gp, 1, 1) * torch.eye(dof, device=out.device, dtype=out.dtype))
+      res.append(s)                                                    # (the scalars themselves, for the DGP_QC_SCALAR tag; not differentiable)
+      ctx.mark_non_differentiable(s)
+    res.append(sq[:, n_gp:n_gp + n_obs].reshape(B, n_obs, 1, 1))
+    if learn_eps: res.append(sq[:, n_gp + n_obs:n_gp + 2 * n_obs].reshape(B, n_obs, 1, 1))
+    return tuple(res)
+
+  @staticmethod
+  def backward(ctx, *grads):
+    out, = ctx.saved_tensors
+    n_gp, n_obs, dof, learn_eps = ctx.dims
+    B, W = out.shape[0], out.shape[2]
+    parts, i = [], 0
+    if n_gp:
+      g_qc = grads[0]; i = 2
+      parts.append(out.new_zeros(B, n_gp) if g_qc is None else g_qc.diagonal(dim1=-2, dim2=-1).sum(-1))
+    for k in range(1 + int(learn_eps)):
+      g = grads[i + k]
+      parts.append(out.new_zeros(B, n_obs) if g is None else g.reshape(B, n_obs))
+    used = n_gp + n_obs * (1 + int(learn_eps))
+    if used < W: parts.append(out.new_zeros(B, W - used))
+    g_sq = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    return (2.0 * out[:, 0, :] * g_sq).unsqueeze(1), None, None, None, None
+
+
 class DiffGPMP2Planner(nn.Module):
   def __init__(self, gp_params, obs_params, planner_params, optim_params, env_params, robot_model, learn_params=None, batch_size=1,
                use_cuda=False, learn_module_conv=None, learn_module_fcn=None):
@@ -349,6 +390,17 @@ class DiffGPMP2Planner(nn.Module):
     nl = self.robot_model.nlinks
     B = out.shape[0]
     n_obs = self.num_obs_factors * nl
+    if nl == 1 and mode in ('fix_dynamics', 'diag_identity') and out.dim() == 3 and out.shape[1] == 1:
+      # single-link robot, tensors that are plain squares of the module output: one small autograd node instead of the literal formulation below (same values)
+      n_gp = self.num_gp_factors if mode == 'diag_identity' else 0
+      res = _SquaredCovs.apply(out, n_gp, n_obs, self.dof, bool(learn_eps))
+      if n_gp:
+        qc_inv_traj, s = res[0], res[1]
+        # the tensor IS q_k^2 I: PlanLayer.forward (and its backward) may hand the kernels the n - 1 scalars instead of the blocks (DGP_QC_SCALAR: the
+        # static kernels with scaled lane masks); every other consumer reads the blocks themselves.  (The version: an in-place edit of the blocks voids the tag.)
+        qc_inv_traj.__dict__['_dgp_scalar'] = (s, qc_inv_traj._version)
+        return (qc_inv_traj,) + tuple(res[2:])
+      return res[0] if len(res) == 1 else tuple(res)
     if mode == 'fix_dynamics':
       n_gp = 0
       qc_inv_traj = None

@@ -161,6 +161,16 @@ def test_diag_identity_covariances_run_the_scaled_static_kernels(golden):
     gr, = torch.autograd.grad((dth * dth).sum() + eex.sum(), out)
     return mode, dth.detach(), err, eex.detach(), gr
 
+  def run_iteration(tagged):      # the training iteration: step + unweighted errors at th + dtheta as one node, backward of all of it
+    qc, ow = planner.get_covariances(out, 'diag_identity')
+    if not tagged: qc = qc * 1.0
+    dth, _, eex, sg, gp_, ob = pl.forward_with_errors(th, start, goal, None, sdf, qc, ow, None)
+    gr, = torch.autograd.grad((dth * dth).sum() + eex.sum() + 3.0 * sg.sum() + 5.0 * gp_.sum() + 7.0 * ob.sum(), out)
+    return dth.detach(), sg.detach(), gr
+
+  i1, i0 = run_iteration(True), run_iteration(False)
+  for a_, b_ in zip(i1, i0):
+    assert rel_err(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-8
   m1, d1, e1, x1, g1 = run(True)
   m0, d0, e0, x0, g0 = run(False)
   assert m1 == _capi.DGP_QC_SCALAR and m0 == _capi.DGP_QC_PERSTATE
