@@ -18,7 +18,10 @@ Differences a caller can observe (all deliberate):
     forward() on that stream -- clone() it to keep an iteration's flags; a differentiable step or check_spd gets its own tensor;
   * the autograd node of forward() holds plain references to its inputs (addresses + a version-counter check instead of
     SavedVariables, ~1.5 us per tensor): they are released with the node, not at the end of backward(), and
-    torch.autograd.graph.saved_tensors_hooks (save_on_cpu, checkpointing) do not see them -- only `dtheta` is a SavedVariable.
+    torch.autograd.graph.saved_tensors_hooks (save_on_cpu, checkpointing) do not see them -- only `dtheta` is a SavedVariable;
+  * a `qc_inv_trajb` tensor that DiffGPMP2Planner.get_covariances built in the 'diag_identity' mode carries its n - 1 scalars as a tag (and its version counter: an
+    in-place edit voids it); forward() / forward_with_errors() and their backward then launch the scaled-mask static kernels (DGP_QC_SCALAR) instead of the per-state
+    ones.  Same values to rounding, the gradient returned for the tensor is that of its dof x dof blocks either way; a copy of the tensor (no tag) takes the per-state path.
 """
 import ctypes
 import weakref
