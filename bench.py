@@ -565,6 +565,94 @@ def planner_api_backward_rate(device, reps=200):
                   'trivial custom Function on this host) is paid once per window, as in the training loop'}
 
 
+def _bench_planner(B, n):
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  t = lambda v: torch.tensor(v, dtype=torch.float64)
+  gp = {'Q_c_inv': torch.eye(2, dtype=torch.float64), 'K_s': t(0.01), 'K_g': t(0.01)}
+  ob = {'cost_sigma': t(0.01), 'epsilon_dist': t(0.4)}
+  pp = {'dof': 2, 'state_dim': 4, 'total_time_sec': 10.0, 'total_time_step': n - 1}
+  op = {'method': 'gauss_newton', 'reg': 0.1, 'max_iters': GN_ITERS, 'tol_err': 1e-3, 'tol_delta': 1e-4}
+  return DiffGPMP2Planner(gp, ob, pp, op, {'x_lims': [-5.0, 5.0], 'y_lims': [-5.0, 5.0]}, PointRobot2D(t(0.4), B, n, use_cuda=True),
+                          batch_size=B, use_cuda=True)
+
+
+def train_iteration_sdf_grad(device, batches=(B_PER_GPU, 32), reps=100):
+  """One iteration of the reference's training loop WITH the gradient set that loop really asks for (learning/train_planner.py:267-268,
+  311-327,366-374): `sdf_b.requires_grad_(True)` on PER-SAMPLE grids (B,1,H,W) and `th.requires_grad_(True)`, learned per-state
+  covariance tensors -- planner.step_with_errors + backward of (dtheta, err_sg, err_gp, err_obs) w.r.t. th, qc_inv, obscov_inv, eps
+  AND sdf.  Wall microseconds per iteration, eager and replayed from a HIP graph, at B = 4096 and B = 32, for per-sample grids (the
+  gradient is a (B,1,H,W) tensor in the reference: 1 GiB at B = 4096 -- `sdf_grad` says in which form the layer returns it) and for a
+  shared grid; `no_sdf_grad` is the same iteration without the grid gradient."""
+  n = N_STATES
+  res = {}
+  for B in batches:
+    planner = _bench_planner(B, n)
+    pl = planner.plan_layer
+    th0, start, goal, sdf = make_inputs(B, n, GRID, device)
+    g = torch.randn_like(th0); cw = torch.randn(B, 1, 1, device=device); cws = cw.view(B, 1).contiguous()
+    thr = th0.clone().requires_grad_(True)
+    qc = torch.eye(2, device=device).expand(B, n - 1, 2, 2).contiguous().requires_grad_(True)
+    ow = torch.full((B, n, 1, 1), 1e4, device=device, requires_grad=True)
+    ep = torch.full((B, n, 1, 1), 0.4, device=device, requires_grad=True)
+    grids = {'per_sample': make_per_sample_sdfs(B, GRID, device, seed=1).requires_grad_(True),
+             'shared': sdf.clone().requires_grad_(True)}
+
+    def iteration(sdf_in, with_sdf):
+      sdfb = sdf_in if sdf_in.shape[0] == B else sdf_in.expand(B, 1, GRID, GRID)
+      if not with_sdf: sdfb = sdfb.detach()
+      dth, _, _, sg, gp_, ob = pl.forward_with_errors(thr, start, goal, None, sdfb, qc, ow, ep)
+      leaves = (thr, qc, ow, ep) + ((sdf_in,) if with_sdf else ())
+      return torch.autograd.grad((dth, sg, gp_, ob), leaves, (g, cws, cw, cw))
+
+    def wall(f):
+      best = float('inf')
+      for _ in range(10): f()
+      for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(reps): f()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / reps * 1e6)
+      return best
+
+    def graphed(f):
+      side = torch.cuda.Stream(device)
+      side.wait_stream(torch.cuda.current_stream(device))
+      with torch.cuda.stream(side):
+        for _ in range(3): f()
+      torch.cuda.current_stream(device).wait_stream(side)
+      gr = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(gr):
+        f()
+      return gr.replay
+
+    blk = {}
+    for name, leaf in grids.items():
+      row = {}
+      for tag, with_sdf in (('no_sdf_grad', False), ('sdf_grad', True)):
+        f = lambda leaf=leaf, with_sdf=with_sdf: iteration(leaf, with_sdf)
+        out = f()
+        e = {'eager_us': wall(f)}
+        if with_sdf:
+          gs = out[-1]
+          e['grad_layout'] = str(gs.layout).replace('torch.', '')
+          e['grad_bytes'] = int(gs._values().numel() * gs._values().element_size() + gs._indices().numel() * 8) if gs.is_sparse else int(gs.numel() * gs.element_size())
+        try:
+          e['hip_graph_replay_us'] = wall(graphed(f))
+        except Exception as ex:      # noqa: BLE001
+          e['hip_graph_replay_us'] = None; e['graph_error'] = '%s: %s' % (type(ex).__name__, str(ex)[:200])
+          torch.cuda.synchronize()
+        row[tag] = e
+      blk[name] = row
+    res['B%d' % B] = blk
+    del grids, planner
+    torch.cuda.empty_cache()
+  res['note'] = ('planner.plan_layer.forward_with_errors + torch.autograd.grad of (dtheta, err_sg, err_gp, err_obs) w.r.t. (th, qc_inv, obscov_inv, eps[, sdf]); '
+                 'per_sample: sdfb (B,1,256,256) leaf as learning/train_planner.py:267; shared: one (1,1,256,256) leaf expand()ed over the batch; wall us per iteration '
+                 '(best of three batches of %d), eager and replayed from a HIP graph' % reps)
+  return res
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -627,7 +715,7 @@ def main():
   sdf_ptr = sdf.data_ptr()
 
   def step(k):
-    rc = pc.gn_step(hnd, B, th_ptrs[k % GN_ITERS], sp, gp, sdf_ptr, GRID, GRID, 0, 0, None, None, None, dp, ep, xp, ip, raw_stream)
+    rc = pc.gn_step(hnd, B, th_ptrs[k % GN_ITERS], sp, gp, sdf_ptr, GRID, GRID, 0, 0, 0, None, 0, None, None, None, 0, 0, None, None, None, dp, ep, xp, ip, raw_stream)
     if rc: solver.api.check(rc)
 
   prewarm_s = prewarm(step)
@@ -771,6 +859,7 @@ def main():
       out['sdf_fields'] = sdf_fields_rate(device)
       out['planner_step_api'] = planner_api_rate(device)
       out['planner_step_backward_api'] = planner_api_backward_rate(device)
+      out['train_iteration_sdf_grad'] = train_iteration_sdf_grad(device)
     if world == 1 and not args.no_cpu_baseline:
       hist_cpu = [t.cpu() for t in th_hist]
       out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())

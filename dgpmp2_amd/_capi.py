@@ -17,7 +17,10 @@ DGP_OK, DGP_EINVAL, DGP_EUNSUPPORTED, DGP_EHIP = 0, -1, -2, -3
 DGP_F32, DGP_F64, DGP_U8 = 0, 1, 2
 DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL, DGP_QC_SCALAR = 0, 1, 2, 3
-DGP_ABI_VERSION = 5
+DGP_SDF_ROWMAJOR, DGP_SDF_TILED4 = 0, 1
+DGP_GSDF_DENSE, DGP_GSDF_DENSE_F64, DGP_GSDF_SPARSE = 0, 1, 2
+DGP_COVS_SQUARED = 1
+DGP_ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DGP_LIB_PATH') or os.path.join(_HERE, 'lib', 'libdgpmp2_hip.so')   # override: tuning builds only
@@ -33,11 +36,13 @@ class DgpConfig(C.Structure):
 
 
 class DgpSdf(C.Structure):
-  _fields_ = [('data', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32), ('batch_stride', C.c_int64)]
+  _fields_ = [('data', C.c_void_p), ('rows', C.c_int32), ('cols', C.c_int32), ('batch_stride', C.c_int64), ('layout', C.c_int32),
+              ('grad_mode', C.c_int32), ('grad_indices', C.c_void_p)]
 
 
 class DgpCovs(C.Structure):
-  _fields_ = [('qc_mode', C.c_int32), ('qc_inv', C.c_void_p), ('obs_w', C.c_void_p), ('eps', C.c_void_p)]
+  _fields_ = [('qc_mode', C.c_int32), ('qc_inv', C.c_void_p), ('obs_w', C.c_void_p), ('eps', C.c_void_p), ('flags', C.c_uint32), ('pad_', C.c_int32),
+              ('row_stride', C.c_int64), ('sq_qc_inv', C.c_void_p), ('sq_obs_w', C.c_void_p), ('sq_eps', C.c_void_p)]
 
 
 class DgpError(RuntimeError):
@@ -51,7 +56,7 @@ class CApi(object):
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
              'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward', 'gn_step_errors',
-             'gn_step_errors_backward', 'sdf_2d_workspace_bytes', 'sdf_2d', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
+             'gn_step_errors_backward', 'sum_partial_grids', 'sdf_2d_workspace_bytes', 'sdf_2d', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -89,6 +94,8 @@ class CApi(object):
     self.gn_step_errors_backward = f('gn_step_errors_backward'); self.gn_step_errors_backward.restype = C.c_int
     self.gn_step_errors_backward.argtypes = [vp, i32, vp, vp, vp, C.POINTER(DgpSdf), C.POINTER(DgpCovs), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64,
                                              i32, vp, vp, vp, vp, vp]
+    self.sum_partial_grids = f('sum_partial_grids'); self.sum_partial_grids.restype = C.c_int
+    self.sum_partial_grids.argtypes = [vp, i32, i32, i64, dbl, vp, i32, vp]
     self.sdf_2d_workspace_bytes = f('sdf_2d_workspace_bytes'); self.sdf_2d_workspace_bytes.restype = C.c_size_t
     self.sdf_2d_workspace_bytes.argtypes = [i32, i32, i32, i32]
     self.sdf_2d = f('sdf_2d'); self.sdf_2d.restype = C.c_int
@@ -151,7 +158,7 @@ import sysconfig
 # never loaded by mistake
 PYCALL_PATH = os.path.join(_HERE, 'lib', '_dgp_pycall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
 _PYCALL_ENTRIES = ('gn_step', 'gn_solve', 'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward',
-                   'gn_step_errors', 'gn_step_errors_backward')
+                   'gn_step_errors', 'gn_step_errors_backward', 'sum_partial_grids')
 
 
 def get_api():
@@ -164,7 +171,7 @@ def get_api():
 
 class CtypesPycall(object):
   """Drop-in for the trampoline module, on the plain ctypes binding: the same positional signatures (addresses as ints / None, the two
-  structs flattened into their fields), 3-5 us slower per call.  Used when the trampoline has not been built or does not load
+  structs flattened into their seven + nine fields), 3-5 us slower per call.  Used when the trampoline has not been built or does not load
   (no Python.h on the build host, another interpreter): the product path is then still the C-ABI, only the marshalling is slower."""
 
   def __init__(self, api):
@@ -172,14 +179,14 @@ class CtypesPycall(object):
 
   @staticmethod
   def _sdf(a, i):
-    return C.byref(DgpSdf(a[i], int(a[i + 1]), int(a[i + 2]), int(a[i + 3]))) if a[i] else None
+    return C.byref(DgpSdf(a[i], int(a[i + 1]), int(a[i + 2]), int(a[i + 3]), int(a[i + 4]), int(a[i + 5]), a[i + 6])) if a[i] else None
 
   @staticmethod
   def _covs(a, i):
-    return C.byref(DgpCovs(int(a[i]), a[i + 1], a[i + 2], a[i + 3]))
+    return C.byref(DgpCovs(int(a[i]), a[i + 1], a[i + 2], a[i + 3], int(a[i + 4]), 0, int(a[i + 5]), a[i + 6], a[i + 7], a[i + 8]))
 
   def _prefixed(self, fn, a):
-    return fn(a[0], a[1], a[2], a[3], a[4], self._sdf(a, 5), self._covs(a, 9), *a[13:])
+    return fn(a[0], a[1], a[2], a[3], a[4], self._sdf(a, 5), self._covs(a, 12), *a[21:])
 
   def gn_step(self, *a): return self._prefixed(self.api.gn_step, a)
   def gn_solve(self, *a): return self._prefixed(self.api.gn_solve, a)
@@ -191,7 +198,9 @@ class CtypesPycall(object):
   def gn_step_errors_backward(self, *a): return self._prefixed(self.api.gn_step_errors_backward, a)
 
   def gn_solve_backward(self, *a):
-    return self.api.gn_solve_backward(a[0], a[1], a[2], a[3], self._sdf(a, 4), *a[8:])
+    return self.api.gn_solve_backward(a[0], a[1], a[2], a[3], self._sdf(a, 4), *a[11:])
+
+  def sum_partial_grids(self, *a): return self.api.sum_partial_grids(*a)
 
 
 def get_pycall():
@@ -274,12 +283,12 @@ class Solver(object):
     return v
 
   @staticmethod
-  def sdf_arg(ptr, rows, cols, batch_stride):
-    return DgpSdf(ptr, int(rows), int(cols), int(batch_stride))
+  def sdf_arg(ptr, rows, cols, batch_stride, layout=DGP_SDF_ROWMAJOR, grad_mode=DGP_GSDF_DENSE, grad_indices=None):
+    return DgpSdf(ptr, int(rows), int(cols), int(batch_stride), int(layout), int(grad_mode), grad_indices)
 
   @staticmethod
-  def covs_arg(qc_mode=DGP_QC_STATIC, qc_inv=None, obs_w=None, eps=None):
-    return DgpCovs(int(qc_mode), qc_inv, obs_w, eps)
+  def covs_arg(qc_mode=DGP_QC_STATIC, qc_inv=None, obs_w=None, eps=None, flags=0, row_stride=0, sq_qc_inv=None, sq_obs_w=None, sq_eps=None):
+    return DgpCovs(int(qc_mode), qc_inv, obs_w, eps, int(flags), 0, int(row_stride), sq_qc_inv, sq_obs_w, sq_eps)
 
   def gn_step(self, batch, th, start, goal, sdf, covs, dtheta, err=None, err_ext=None, info=None, stream=None):
     self.api.check(self.api.gn_step(self.handle, batch, th, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,

@@ -216,13 +216,14 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   if (!h) return fail(DGP_EINVAL, "null handle");
   if (batch <= 0) return fail(DGP_EINVAL, "batch must be positive, got %d", batch);
   if (!th || !start || !goal) return fail(DGP_EINVAL, "th/start/goal must be non-null device pointers");
-  static const DgpSdf no_sdf = {nullptr, 2, 2, 0};      // dgp_eval_errors without obstacle outputs: no grid is read
+  static const DgpSdf no_sdf = {nullptr, 2, 2, 0, DGP_SDF_ROWMAJOR, DGP_GSDF_DENSE, nullptr};      // dgp_eval_errors without obstacle outputs: no grid is read
   if (sdf_optional && (!sdf || !sdf->data)) sdf = &no_sdf;
   else if (!sdf || !sdf->data) return fail(DGP_EINVAL, "sdf must be non-null");
   if (sdf->rows < 1 || sdf->cols < 1) return fail(DGP_EINVAL, "sdf grid must be at least 1x1, got %dx%d", sdf->rows, sdf->cols);
   if (sdf->cols < 2) return fail(DGP_EUNSUPPORTED, "sdf grids with a single column are not implemented (the taps are fetched as column pairs)");
   if (sdf->batch_stride < 0) return fail(DGP_EINVAL, "negative sdf batch stride");
   if ((int64_t)sdf->rows * sdf->cols >= ((int64_t)1 << 31)) return fail(DGP_EUNSUPPORTED, "sdf grid of %dx%d elements is too large", sdf->rows, sdf->cols);
+  if (sdf->layout != DGP_SDF_ROWMAJOR) return fail(DGP_EUNSUPPORTED, "DgpSdf::layout %d is not implemented", sdf->layout);
   p = h->base;
   p.B = batch;
   p.th = th; p.start = start; p.goal = goal;
@@ -236,6 +237,7 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   p.vec_mu = (aligned16(start) && aligned16(goal)) ? 1 : 0;
   if (covs) {
     if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
+    if (covs->flags != 0 || covs->row_stride != 0) return fail(DGP_EUNSUPPORTED, "DgpCovs::flags / row_stride are not implemented");
     if (covs->qc_mode == DGP_QC_SCALAR && !scalar_qc_ok)
       return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is implemented by dgp_gn_step[_errors] and their backward only (pass the (B,n-1,dof,dof) tensors elsewhere)");
     if (covs->qc_mode == DGP_QC_SCALAR && h->base.qc_diag == 0)
@@ -286,7 +288,30 @@ inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const vo
 
 // fields of GnGradParams that only the round-4 entry points set
 inline void clear_extensions(dgp::GnGradParams& g) {
-  g.accumulate = 0; g.g_th_new = nullptr; g.th_addend = nullptr; g.th_hist = nullptr; g.th_final = nullptr; g.iters = nullptr; g.chain_iters = 0; g.pad_ = 0;
+  g.accumulate = 0; g.g_th_new = nullptr; g.th_addend = nullptr; g.th_hist = nullptr; g.th_final = nullptr; g.iters = nullptr; g.chain_iters = 0; g.g_sdf_mode = dgp::GSDF_DENSE; g.g_sdf_idx = nullptr; g.g_sdf_passes = 1; g.g_sdf_pass0 = 0;
+}
+
+// the destination of dL/d(sdf): validation shared by the four backward entry points (call after clear_extensions)
+inline int fill_gsdf(const DgpHandle* h, const DgpSdf* sdf, void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, const dgp::GnParams& p, dgp::GnGradParams& g) {
+  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
+  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
+  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
+  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies;
+  g.g_sdf_mode = dgp::GSDF_DENSE; g.g_sdf_idx = nullptr; g.g_sdf_passes = 1; g.g_sdf_pass0 = 0;
+  if (g_sdf && sdf) {
+    if (sdf->grad_mode < DGP_GSDF_DENSE || sdf->grad_mode > DGP_GSDF_SPARSE) return fail(DGP_EINVAL, "bad DgpSdf::grad_mode %d", sdf->grad_mode);
+    g.g_sdf_mode = sdf->grad_mode;
+    if (sdf->grad_mode == DGP_GSDF_SPARSE) {
+      if (!sdf->grad_indices) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs DgpSdf::grad_indices");
+      if (g_sdf_copies != 1) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE takes no partial copies");
+      if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_SPARSE is not implemented for num_states > 256");
+      if ((reinterpret_cast<uintptr_t>(g_sdf) & 15u) || (reinterpret_cast<uintptr_t>(sdf->grad_indices) & 15u))
+        return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs 16-byte aligned value / index arrays (vector stores)");
+      g.g_sdf_idx = sdf->grad_indices;
+    }
+    if (is_long(p.n) && sdf->grad_mode == DGP_GSDF_DENSE_F64 && h->cfg.io_dtype == DGP_F32) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_DENSE_F64 is not implemented for num_states > 256");
+  }
+  return DGP_OK;
 }
 
 inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
@@ -296,15 +321,14 @@ inline int fill_backward(const DgpHandle* h, int32_t batch, const void* th, cons
   int rc = fill_call(h, batch, th, start, goal, sdf, covs, p, /*sdf_optional=*/false, /*scalar_qc_ok=*/true);
   if (rc == DGP_OK && p.qc_mode == dgp::QC_SCALAR && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is not implemented for num_states > 256");
   if (rc != DGP_OK) return rc;
-  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
-  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
-  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   if (g_dtheta && !dtheta) return fail(DGP_EINVAL, "dtheta (the forward output) is needed with a g_dtheta cotangent");
   if (g_qc_inv && p.qc_mode == DGP_QC_STATIC) return fail(DGP_EINVAL, "g_qc_inv given but qc_mode is DGP_QC_STATIC");
   clear_extensions(g);
+  rc = fill_gsdf(h, sdf, g_sdf, g_sdf_batch_stride, g_sdf_copies, p, g);
+  if (rc != DGP_OK) return rc;
   g.dtheta = dtheta; g.g_dtheta = g_dtheta; g.g_err_ext = g_err_ext; g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
   g.g_unw_sg = g.g_unw_gp = g.g_unw_obs = nullptr;
-  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
+  g.g_qc = g_qc_inv; g.g_obs_w = g_obs_w; g.g_eps = g_eps;
   p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
 }
@@ -319,20 +343,19 @@ inline int fill_eval_backward(const DgpHandle* h, int32_t batch, const void* th,
   const bool no_grid = !sdf || !sdf->data;
   if (no_grid && (g_err_ext || g_unw_obs || g_sdf))
     return fail(DGP_EINVAL, "sdf may be NULL only when g_err_ext, g_unw_obs and g_sdf (what reads / writes the grid) are NULL");
-  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr, 0u, 0, 0, nullptr, nullptr, nullptr};
   if (covs && (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR)) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);      // (whatever the mode: only eps is read)
   int rc = fill_call(h, batch, th, start, goal, sdf, &c, p, /*sdf_optional=*/true);
   if (rc != DGP_OK) return rc;
   if (no_grid) p.sdf = nullptr;
-  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
-  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
-  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   if (g_eps && !c.eps) return fail(DGP_EINVAL, "g_eps given but covs->eps is NULL (static epsilon)");
   clear_extensions(g);
+  rc = fill_gsdf(h, sdf, g_sdf, g_sdf_batch_stride, g_sdf_copies, p, g);
+  if (rc != DGP_OK) return rc;
   g.dtheta = nullptr; g.g_dtheta = nullptr; g.g_err_ext = g_err_ext;
   g.g_unw_sg = g_unw_sg; g.g_unw_gp = g_unw_gp; g.g_unw_obs = g_unw_obs;
   g.g_th = g_th; g.g_start = g_start; g.g_goal = g_goal;
-  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = g_eps;
+  g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = g_eps;
   p.vec_io = (aligned16(th) && aligned16(g_th)) ? 1 : 0;
   return DGP_OK;
 }
@@ -348,14 +371,13 @@ inline int fill_solve_backward(const DgpHandle* h, int32_t batch, const void* st
   if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward is not implemented for num_states > 256 (chain the per-step backward instead)");
   if (!dgp::use_static_kernels(p)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward needs a diagonal static Q_c_inv");
   if (max_iters < 1) return fail(DGP_EINVAL, "max_iters must be >= 1, got %d", max_iters);
-  if (g_sdf_batch_stride < 0) return fail(DGP_EINVAL, "negative g_sdf batch stride");
-  if (g_sdf_copies < 1 || g_sdf_copies > 64) return fail(DGP_EINVAL, "g_sdf_copies must be in 1..64, got %d", g_sdf_copies);
-  if (g_sdf_copies > 1 && g_sdf_batch_stride != 0) return fail(DGP_EINVAL, "partial SDF-gradient copies need a shared grid (stride 0)");
   clear_extensions(g);
+  rc = fill_gsdf(h, sdf, g_sdf, g_sdf_batch_stride, g_sdf_copies, p, g);
+  if (rc != DGP_OK) return rc;
   g.dtheta = nullptr; g.g_dtheta = g_th_out; g.g_err_ext = nullptr; g.g_unw_sg = g.g_unw_gp = g.g_unw_obs = nullptr;
   g.g_th = g_th_init; g.g_start = g_start; g.g_goal = g_goal;
-  g.g_sdf = g_sdf; g.g_sdf_bstride = g_sdf_batch_stride; g.g_sdf_copies = g_sdf_copies; g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = nullptr;
-  g.th_hist = th_hist; g.th_final = th_out; g.iters = iters; g.chain_iters = max_iters;
+  g.g_qc = nullptr; g.g_obs_w = nullptr; g.g_eps = nullptr;
+  g.th_hist = th_hist; g.th_final = th_out; g.iters = iters; g.chain_iters = max_iters; g.g_sdf_passes = max_iters;
   p.max_iters = max_iters;
   p.vec_io = (aligned16(th_out) && aligned16(g_th_out) && aligned16(g_th_init)) ? 1 : 0;
   return DGP_OK;
@@ -401,7 +423,7 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   rc = launch(dgp::MODE_STEP, p, (const dgp::GnGradParams*)nullptr);
   if (rc != DGP_OK || !errs) return rc;
   // the unweighted errors at th + dtheta: the error kernel with dtheta as addend, stream-ordered behind the step (only eps of the covariances enters them)
-  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr, 0u, 0, 0, nullptr, nullptr, nullptr};
   rc = fill_eval(h, batch, th, start, goal, sdf, &c, nullptr, nullptr, unw_sg, unw_gp, unw_obs, p);
   if (rc != DGP_OK) return rc;
   p.dtheta = dtheta;               // MODE_EVAL: the addend (gn_lane.h)
@@ -426,6 +448,7 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
     if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors_backward is not implemented for num_states > 256");
     g.g_eps = g_eps;                // (written by BOTH launches whatever the epsilon source: launch 2 adds to what this one stores)
     g.th_addend = dtheta;
+    g.g_sdf_passes = 2; g.g_sdf_pass0 = 1;      // DGP_GSDF_SPARSE: the taps at th + dtheta are the second block
     p.vec_io = (p.vec_io && aligned16(dtheta)) ? 1 : 0;
     rc = launch((int)kModeBackward, p, &g);
     if (rc != DGP_OK) return rc;
@@ -436,7 +459,7 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
                          g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
   if (rc != DGP_OK) return rc;
   if (errs) {
-    g.g_th_new = workspace; g.accumulate = 1;
+    g.g_th_new = workspace; g.accumulate = 1; g.g_sdf_passes = 2;
     p.vec_io = (p.vec_io && aligned16(workspace)) ? 1 : 0;
   }
   return launch((int)kModeBackward, p, &g);

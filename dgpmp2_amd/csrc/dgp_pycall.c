@@ -36,6 +36,8 @@ typedef int (*gn_step_errors_backward_fn)(const DgpHandle*, int32_t, const void*
                                           const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*, int64_t, int32_t,
                                           void*, void*, void*, void*, void*);
 
+typedef int (*sum_partial_grids_fn)(const void*, int32_t, int32_t, int64_t, double, void*, int32_t, void*);
+static sum_partial_grids_fn f_sum_partial_grids;
 static gn_step_fn f_gn_step;
 static gn_solve_traced_fn f_gn_solve_traced;
 static gn_solve_backward_fn f_gn_solve_backward;
@@ -68,19 +70,20 @@ static inline int64_t as_i64(PyObject* o, int* bad) {
 #define P(i) as_ptr(a[i], &bad)
 #define I(i) as_i64(a[i], &bad)
 
-/* common prefix of every entry point: handle, batch, th, start, goal, sdf_data, sdf_rows, sdf_cols, sdf_batch_stride, qc_mode, qc_inv, obs_w, eps
- * (13 arguments).  sdf_data None/0 -> a NULL DgpSdf* (only dgp_eval_errors[_backward] accept that). */
-#define PREFIX 13
+/* common prefix of every entry point: handle, batch, th, start, goal, the seven fields of DgpSdf (data, rows, cols, batch_stride, layout, grad_mode,
+ * grad_indices), the nine of DgpCovs (qc_mode, qc_inv, obs_w, eps, flags, row_stride, sq_qc_inv, sq_obs_w, sq_eps) -- 21 arguments.
+ * sdf_data None/0 -> a NULL DgpSdf* (only dgp_eval_errors[_backward] accept that). */
+#define PREFIX 21
 #define BUILD_PREFIX                                                                                        \
   const DgpHandle* h = (const DgpHandle*)P(0);                                                              \
   const int32_t batch = (int32_t)I(1);                                                                      \
   const void *th = P(2), *start = P(3), *goal = P(4);                                                       \
-  DgpSdf sdf = {P(5), (int32_t)I(6), (int32_t)I(7), I(8)};                                                  \
-  DgpCovs covs = {(int32_t)I(9), P(10), P(11), P(12)};                                                      \
+  DgpSdf sdf = {P(5), (int32_t)I(6), (int32_t)I(7), I(8), (int32_t)I(9), (int32_t)I(10), (int64_t*)P(11)};  \
+  DgpCovs covs = {(int32_t)I(12), P(13), P(14), P(15), (uint32_t)I(16), 0, I(17), P(18), P(19), P(20)};     \
   const DgpSdf* sdfp = sdf.data ? &sdf : NULL
 
 static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
-  NEED(9, "bind");
+  NEED(10, "bind");
   f_gn_step = (gn_step_fn)P(0);
   f_gn_solve = (gn_solve_fn)P(1);
   f_eval_errors = (eval_errors_fn)P(2);
@@ -90,6 +93,7 @@ static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
   f_gn_solve_backward = (gn_solve_backward_fn)P(6);
   f_gn_step_errors = (gn_step_errors_fn)P(7);
   f_gn_step_errors_backward = (gn_step_errors_backward_fn)P(8);
+  f_sum_partial_grids = (sum_partial_grids_fn)P(9);
   if (bad) return NULL;
   Py_RETURN_NONE;
 }
@@ -102,7 +106,7 @@ static PyObject* py_gn_step(PyObject* self, PyObject* const* a, Py_ssize_t nargs
   NEED(PREFIX + 5, "gn_step");
   BOUND(f_gn_step);
   BUILD_PREFIX;
-  void *dth = P(13), *err = P(14), *eex = P(15), *info = P(16), *stream = P(17);
+  void *dth = P(21), *err = P(22), *eex = P(23), *info = P(24), *stream = P(25);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, stream));
 }
@@ -112,10 +116,10 @@ static PyObject* py_gn_solve(PyObject* self, PyObject* const* a, Py_ssize_t narg
   NEED(PREFIX + 9, "gn_solve");
   BOUND(f_gn_solve);
   BUILD_PREFIX;
-  const int32_t max_iters = (int32_t)I(13);
-  const double tol = PyFloat_AsDouble(a[14]);
+  const int32_t max_iters = (int32_t)I(21);
+  const double tol = PyFloat_AsDouble(a[22]);
   if (tol == -1.0 && PyErr_Occurred()) return NULL;
-  void *th_out = P(15), *iters = P(16), *eh = P(17), *eeh = P(18), *ef = P(19), *info = P(20), *stream = P(21);
+  void *th_out = P(23), *iters = P(24), *eh = P(25), *eeh = P(26), *ef = P(27), *info = P(28), *stream = P(29);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_solve(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info, stream));
 }
@@ -125,7 +129,7 @@ static PyObject* py_eval_errors(PyObject* self, PyObject* const* a, Py_ssize_t n
   NEED(PREFIX + 6, "eval_errors");
   BOUND(f_eval_errors);
   BUILD_PREFIX;
-  void *err = P(13), *eex = P(14), *usg = P(15), *ugp = P(16), *uobs = P(17), *stream = P(18);
+  void *err = P(21), *eex = P(22), *usg = P(23), *ugp = P(24), *uobs = P(25), *stream = P(26);
   if (bad) return NULL;
   return PyLong_FromLong(f_eval_errors(h, batch, th, start, goal, sdfp, &covs, err, eex, usg, ugp, uobs, stream));
 }
@@ -135,11 +139,11 @@ static PyObject* py_gn_step_backward(PyObject* self, PyObject* const* a, Py_ssiz
   NEED(PREFIX + 13, "gn_step_backward");
   BOUND(f_gn_step_backward);
   BUILD_PREFIX;
-  const void *dth = P(13), *g_dth = P(14), *g_eex = P(15);
-  void *g_th = P(16), *g_st = P(17), *g_go = P(18), *g_sdf = P(19);
-  const int64_t g_stride = I(20);
-  const int32_t copies = (int32_t)I(21);
-  void *g_qc = P(22), *g_ow = P(23), *g_eps = P(24), *stream = P(25);
+  const void *dth = P(21), *g_dth = P(22), *g_eex = P(23);
+  void *g_th = P(24), *g_st = P(25), *g_go = P(26), *g_sdf = P(27);
+  const int64_t g_stride = I(28);
+  const int32_t copies = (int32_t)I(29);
+  void *g_qc = P(30), *g_ow = P(31), *g_eps = P(32), *stream = P(33);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_th, g_st, g_go, g_sdf, g_stride, copies,
                                             g_qc, g_ow, g_eps, stream));
@@ -150,11 +154,11 @@ static PyObject* py_eval_errors_backward(PyObject* self, PyObject* const* a, Py_
   NEED(PREFIX + 12, "eval_errors_backward");
   BOUND(f_eval_errors_backward);
   BUILD_PREFIX;
-  const void *g_eex = P(13), *g_usg = P(14), *g_ugp = P(15), *g_uobs = P(16);
-  void *g_th = P(17), *g_st = P(18), *g_go = P(19), *g_sdf = P(20);
-  const int64_t g_stride = I(21);
-  const int32_t copies = (int32_t)I(22);
-  void *g_eps = P(23), *stream = P(24);
+  const void *g_eex = P(21), *g_usg = P(22), *g_ugp = P(23), *g_uobs = P(24);
+  void *g_th = P(25), *g_st = P(26), *g_go = P(27), *g_sdf = P(28);
+  const int64_t g_stride = I(29);
+  const int32_t copies = (int32_t)I(30);
+  void *g_eps = P(31), *stream = P(32);
   if (bad) return NULL;
   return PyLong_FromLong(f_eval_errors_backward(h, batch, th, start, goal, sdfp, &covs, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf, g_stride,
                                                 copies, g_eps, stream));
@@ -165,30 +169,30 @@ static PyObject* py_gn_solve_traced(PyObject* self, PyObject* const* a, Py_ssize
   NEED(PREFIX + 10, "gn_solve_traced");
   BOUND(f_gn_solve_traced);
   BUILD_PREFIX;
-  const int32_t max_iters = (int32_t)I(13);
-  const double tol = PyFloat_AsDouble(a[14]);
+  const int32_t max_iters = (int32_t)I(21);
+  const double tol = PyFloat_AsDouble(a[22]);
   if (tol == -1.0 && PyErr_Occurred()) return NULL;
-  void *th_out = P(15), *iters = P(16), *eh = P(17), *eeh = P(18), *ef = P(19), *info = P(20), *hist = P(21), *stream = P(22);
+  void *th_out = P(23), *iters = P(24), *eh = P(25), *eeh = P(26), *ef = P(27), *info = P(28), *hist = P(29), *stream = P(30);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_solve_traced(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info,
                                            (double*)hist, stream));
 }
 
-/* gn_solve_backward(handle, batch, start, goal, sdf_data, sdf_rows, sdf_cols, sdf_batch_stride, max_iters, th_hist, th_out, iters, g_th_out,
+/* gn_solve_backward(handle, batch, start, goal, sdf_data, sdf_rows, sdf_cols, sdf_batch_stride, sdf_layout, sdf_grad_mode, sdf_grad_indices, max_iters, th_hist, th_out, iters, g_th_out,
  *                   g_th_init, g_start, g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, stream) */
 static PyObject* py_gn_solve_backward(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
-  NEED(20, "gn_solve_backward");
+  NEED(23, "gn_solve_backward");
   BOUND(f_gn_solve_backward);
   const DgpHandle* h = (const DgpHandle*)P(0);
   const int32_t batch = (int32_t)I(1);
   const void *start = P(2), *goal = P(3);
-  DgpSdf sdf = {P(4), (int32_t)I(5), (int32_t)I(6), I(7)};
-  const int32_t max_iters = (int32_t)I(8);
-  const void *hist = P(9), *th_out = P(10), *iters = P(11), *g_out = P(12);
-  void *g_th = P(13), *g_st = P(14), *g_go = P(15), *g_sdf = P(16);
-  const int64_t g_stride = I(17);
-  const int32_t copies = (int32_t)I(18);
-  void* stream = P(19);
+  DgpSdf sdf = {P(4), (int32_t)I(5), (int32_t)I(6), I(7), (int32_t)I(8), (int32_t)I(9), (int64_t*)P(10)};
+  const int32_t max_iters = (int32_t)I(11);
+  const void *hist = P(12), *th_out = P(13), *iters = P(14), *g_out = P(15);
+  void *g_th = P(16), *g_st = P(17), *g_go = P(18), *g_sdf = P(19);
+  const int64_t g_stride = I(20);
+  const int32_t copies = (int32_t)I(21);
+  void* stream = P(22);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_solve_backward(h, batch, start, goal, sdf.data ? &sdf : NULL, max_iters, (const double*)hist, th_out, (const int32_t*)iters,
                                              g_out, g_th, g_st, g_go, g_sdf, g_stride, copies, stream));
@@ -199,7 +203,7 @@ static PyObject* py_gn_step_errors(PyObject* self, PyObject* const* a, Py_ssize_
   NEED(PREFIX + 8, "gn_step_errors");
   BOUND(f_gn_step_errors);
   BUILD_PREFIX;
-  void *dth = P(13), *err = P(14), *eex = P(15), *info = P(16), *usg = P(17), *ugp = P(18), *uobs = P(19), *stream = P(20);
+  void *dth = P(21), *err = P(22), *eex = P(23), *info = P(24), *usg = P(25), *ugp = P(26), *uobs = P(27), *stream = P(28);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_errors(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, usg, ugp, uobs, stream));
 }
@@ -210,24 +214,41 @@ static PyObject* py_gn_step_errors_backward(PyObject* self, PyObject* const* a, 
   NEED(PREFIX + 17, "gn_step_errors_backward");
   BOUND(f_gn_step_errors_backward);
   BUILD_PREFIX;
-  const void *dth = P(13), *g_dth = P(14), *g_eex = P(15), *g_usg = P(16), *g_ugp = P(17), *g_uobs = P(18);
-  void *g_th = P(19), *g_st = P(20), *g_go = P(21), *g_sdf = P(22);
-  const int64_t g_stride = I(23);
-  const int32_t copies = (int32_t)I(24);
-  void *g_qc = P(25), *g_ow = P(26), *g_eps = P(27), *ws = P(28), *stream = P(29);
+  const void *dth = P(21), *g_dth = P(22), *g_eex = P(23), *g_usg = P(24), *g_ugp = P(25), *g_uobs = P(26);
+  void *g_th = P(27), *g_st = P(28), *g_go = P(29), *g_sdf = P(30);
+  const int64_t g_stride = I(31);
+  const int32_t copies = (int32_t)I(32);
+  void *g_qc = P(33), *g_ow = P(34), *g_eps = P(35), *ws = P(36), *stream = P(37);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_errors_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf,
                                                    g_stride, copies, g_qc, g_ow, g_eps, ws, stream));
 }
 
+/* sum_partial_grids(partial, partial_dtype, copies, elems, scale, out, out_dtype, stream) */
+static PyObject* py_sum_partial_grids(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(8, "sum_partial_grids");
+  BOUND(f_sum_partial_grids);
+  const void* part = P(0);
+  const int32_t pdt = (int32_t)I(1), copies = (int32_t)I(2);
+  const int64_t elems = I(3);
+  const double scale = PyFloat_AsDouble(a[4]);
+  if (scale == -1.0 && PyErr_Occurred()) return NULL;
+  void* out = P(5);
+  const int32_t odt = (int32_t)I(6);
+  void* stream = P(7);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_sum_partial_grids(part, pdt, copies, elems, scale, out, odt, stream));
+}
+
 static PyMethodDef methods[] = {
     {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL,
-     "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward, gn_solve_traced, gn_solve_backward, gn_step_errors, gn_step_errors_backward): "
+     "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward, gn_solve_traced, gn_solve_backward, gn_step_errors, gn_step_errors_backward, sum_partial_grids): "
      "addresses of the C-ABI entry points"},
     {"gn_solve_traced", (PyCFunction)(void (*)(void))py_gn_solve_traced, METH_FASTCALL, "dgp_gn_solve_traced"},
     {"gn_solve_backward", (PyCFunction)(void (*)(void))py_gn_solve_backward, METH_FASTCALL, "dgp_gn_solve_backward"},
     {"gn_step_errors", (PyCFunction)(void (*)(void))py_gn_step_errors, METH_FASTCALL, "dgp_gn_step_errors"},
     {"gn_step_errors_backward", (PyCFunction)(void (*)(void))py_gn_step_errors_backward, METH_FASTCALL, "dgp_gn_step_errors_backward"},
+    {"sum_partial_grids", (PyCFunction)(void (*)(void))py_sum_partial_grids, METH_FASTCALL, "dgp_sum_partial_grids"},
     {"gn_step", (PyCFunction)(void (*)(void))py_gn_step, METH_FASTCALL, "dgp_gn_step"},
     {"gn_solve", (PyCFunction)(void (*)(void))py_gn_solve, METH_FASTCALL, "dgp_gn_solve"},
     {"eval_errors", (PyCFunction)(void (*)(void))py_eval_errors, METH_FASTCALL, "dgp_eval_errors"},

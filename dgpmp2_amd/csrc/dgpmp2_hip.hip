@@ -29,9 +29,40 @@ hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dg
   return table[h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
 }
 
+// dgp_sum_partial_grids: out[e] = scale * sum_c partial[c][e] -- the partial copies of a shared grid's gradient (dgp_gn_step_backward's g_sdf_copies) summed and cast in
+// ONE pass at memory speed (torch's sum(0) of a (16, H W) tensor picks a reduction that takes 45 us for 8 MB on MI355X).  One element per lane and trip, the
+// copies walked by every lane: consecutive lanes read consecutive elements of each copy.
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) sum_partial_grids_kernel(const TI* __restrict__ in, int copies, int64_t elems, double scale, TO* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < elems; e += (int64_t)gridDim.x * 256) {
+    double acc = 0.0;
+    for (int c = 0; c < copies; ++c) acc += (double)in[(int64_t)c * elems + e];
+    out[e] = (TO)(acc * scale);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dgp_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t copies, int64_t elems, double scale, void* out, int32_t out_dtype, void* stream) {
+  if (!partial || !out) return fail(DGP_EINVAL, "dgp_sum_partial_grids: null partial or out");
+  if (copies < 1 || copies > 64 || elems < 1) return fail(DGP_EINVAL, "dgp_sum_partial_grids: copies must be in 1..64 and elems positive");
+  if ((partial_dtype != DGP_F32 && partial_dtype != DGP_F64) || (out_dtype != DGP_F32 && out_dtype != DGP_F64)) return fail(DGP_EINVAL, "dgp_sum_partial_grids: dtypes must be DGP_F32 / DGP_F64");
+  const int64_t blocks64 = (elems + 255) / 256;
+  const dim3 grid((unsigned)(blocks64 > 4096 ? 4096 : blocks64)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (partial_dtype == DGP_F64) {
+    if (out_dtype == DGP_F64) hipLaunchKernelGGL((sum_partial_grids_kernel<double, double>), grid, block, 0, s, (const double*)partial, copies, elems, scale, (double*)out);
+    else hipLaunchKernelGGL((sum_partial_grids_kernel<double, float>), grid, block, 0, s, (const double*)partial, copies, elems, scale, (float*)out);
+  } else {
+    if (out_dtype == DGP_F64) hipLaunchKernelGGL((sum_partial_grids_kernel<float, double>), grid, block, 0, s, (const float*)partial, copies, elems, scale, (double*)out);
+    else hipLaunchKernelGGL((sum_partial_grids_kernel<float, float>), grid, block, 0, s, (const float*)partial, copies, elems, scale, (float*)out);
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_sum_partial_grids launch failed: %s", hipGetErrorString(e));
+  return DGP_OK;
+}
 
 int dgp_abi_version(void) { return DGP_ABI_VERSION; }
 const char* dgp_last_error(void) { return dgp_host::err_buf(); }

@@ -36,8 +36,16 @@ struct GnGradParams {
   const double* th_hist;             // (max_iters,B,n,d) fp64: th_k of every iteration the forward loop ran (dgp_gn_solve's th_hist)
   const void* th_final;              // (B,n,d): th_out of the forward loop
   const int32_t* iters;              // (B): iterations each trajectory ran
-  int32_t chain_iters, pad_;         // rows of th_hist (max_iters of the forward call)
+  int32_t chain_iters;               // rows of th_hist (max_iters of the forward call)
+  // round 5 -- how the grid gradient is delivered (DgpSdf::grad_mode): GSDF_DENSE: g_sdf = grids of the I/O type, accumulated with atomics;
+  // GSDF_DENSE_F64: the same with FP64 grids whatever the I/O type (the partial copies of a shared grid: the sum over trajectories no longer depends
+  // on the order of fp32 atomics); GSDF_SPARSE: no atomics, no zero-filled grid -- g_sdf = (passes, B, n, 4) tap VALUES and g_sdf_idx = the (4, nnz) int64
+  // COO indices (b, 0, y, x) of a torch.sparse_coo_tensor of the grid tensor's shape (per-sample grids: the dense gradient is O(B H W) bytes of zeros)
+  int32_t g_sdf_mode;
+  int32_t g_sdf_passes, g_sdf_pass0; // GSDF_SPARSE: tap blocks the caller's arrays hold (1; max_iters for the chain kernels; 2 for dgp_gn_step_errors_backward) and the block this launch's first pass writes
+  int64_t* g_sdf_idx;
 };
+enum { GSDF_DENSE = 0, GSDF_DENSE_F64 = 1, GSDF_SPARSE = 2 };
 
 // ---------------------------------------------------------------------------------------------------
 // Scatter-add of the SDF gradient.  An atomic instruction costs the memory pipeline one pass per DISTINCT cache line among
@@ -61,13 +69,16 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
   typedef TapEntry<IO> E;
   const int lane = cx.lane();
   const bool local = gp.g_sdf_copies >= kMaxXcds;
-  IO* base = (IO*)gp.g_sdf;
+  const bool wide = sizeof(IO) == 4 && gp.g_sdf_mode == GSDF_DENSE_F64;      // wave-uniform: fp64 grids behind fp32 I/O
+  int64_t first = 0;
   if (gp.g_sdf_copies > 1) {
     const int xcc = cx.xcc_id();
     const int per_xcd = gp.g_sdf_copies / kMaxXcds;
     const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? (xcc % kMaxXcds) + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;      // (XCC_ID is a 4-bit field: never index past the copies)
-    base += (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
+    first = (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
   }
+  IO* base = (IO*)gp.g_sdf + first;
+  double* base64 = (double*)gp.g_sdf + first;
   E* l = (E*)cx.lds();
 #pragma unroll
   for (int k = 0; k < C; ++k)
@@ -83,10 +94,43 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
         const E e = l[h * 64 + lane];
         const int src = h * 32 + (lane >> 1);                                  // the lane whose state this tap belongs to
         const int64_t bs = (int64_t)cx.wave() * TPW + (src / LPT);             // ... and its trajectory (per-sample grids)
-        if (e.idx >= 0) cx.atomic_add(base + bs * gp.g_sdf_bstride + e.idx, e.val, local);
+        if (e.idx >= 0) {
+          if (wide) cx.atomic_add(base64 + bs * gp.g_sdf_bstride + e.idx, (double)e.val, local);
+          else cx.atomic_add(base + bs * gp.g_sdf_bstride + e.idx, e.val, local);
+        }
       }
       cx.lds_sync();
     }
+}
+
+// GSDF_SPARSE: the taps of the lane's C states as COO entries, position q = ((pass B + b) n + g) 4 + t of the value array and of each of the four index rows
+// (b, 0, y, x).  Every entry of an existing state is written (value 0 where the hinge is inactive or the trajectory sat the pass out: explicit zeros are legal in
+// an uncoalesced COO tensor; so are the duplicates of neighbouring states that share a pixel), nothing else: no atomics, no zero fill, no O(B H W) buffer.
+// A lane's C states are 4 C consecutive entries: 16 C bytes of fp32 values and 32 C bytes per index row, written as 16-byte vectors.
+template <int C, typename IO, typename Taps>
+DGP_HD void sdf_emit_sparse(const GnParams& p, const GnGradParams& gp, int64_t b, int g0, bool traj_ok, int pass, int64_t nnz, const Taps& taps,
+                            const int32_t (&tap_i)[C][4], const IO (&tap_v)[C][4]) {
+  typedef long long i64x2 __attribute__((vector_size(16)));
+  struct __attribute__((aligned(16))) V4 { IO v[4]; };
+  IO* vals = (IO*)gp.g_sdf;
+  int64_t* idx = gp.g_sdf_idx;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = g0 + k;
+    if (!(traj_ok && g < p.n)) continue;
+    const int64_t q = (((int64_t)pass * p.B + b) * p.n + g) * 4;
+    const bool on = tap_i[k][0] >= 0;
+    V4 v;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v.v[t] = on ? tap_v[k][t] : (IO)0;
+    *(V4*)(vals + q) = v;
+    const long long y1 = taps.oa[k].y1, y2 = taps.oa[k].y2, x1 = taps.oa[k].x1, x2 = taps.oa[k].x2;
+    i64x2* r0 = (i64x2*)(idx + q); i64x2* r1 = (i64x2*)(idx + nnz + q); i64x2* r2 = (i64x2*)(idx + 2 * nnz + q); i64x2* r3 = (i64x2*)(idx + 3 * nnz + q);
+    const i64x2 bb = {(long long)b, (long long)b}, zz = {0, 0};
+    r0[0] = bb; r0[1] = bb; r1[0] = zz; r1[1] = zz;
+    r2[0] = i64x2{y1, y1}; r2[1] = i64x2{y2, y2};                                  // taps (x1,y1), (x2,y1), (x1,y2), (x2,y2)
+    r3[0] = i64x2{x1, x2}; r3[1] = i64x2{x1, x2};
+  }
 }
 
 // LDS parking level of the adjoint solve's Woodbury elimination (gn_woodbury.h, PARK): the chain kernels also hold the running cotangent in LDS and
@@ -624,7 +668,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #endif                    // (a wavefront issues its LDS instructions in order: nothing to wait for on the device)
     }
   }
-  if (gp.g_sdf) sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);      // wave-uniform
+  if (gp.g_sdf) {                                                           // wave-uniform
+    if (gp.g_sdf_mode == GSDF_SPARSE) sdf_emit_sparse<C, IO>(p, gp, b, g0, traj_ok, gp.g_sdf_pass0 + it, (int64_t)gp.g_sdf_passes * p.B * p.n * 4, taps, tap_i, tap_v);
+    else sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);
+  }
   }  // passes (one unless CHAIN)
   if constexpr (CHAIN) {
     // gradient w.r.t. the INITIAL trajectory, and the start / goal means' gradients summed over the passes

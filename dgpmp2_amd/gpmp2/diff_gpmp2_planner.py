@@ -20,7 +20,7 @@ import time
 import torch
 import torch.nn as nn
 
-from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC, _GNSolve
+from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC, _GNSolve, _NO_COVS, _expand_base
 from ..utils.planner_utils import check_convergence
 
 
@@ -307,6 +307,7 @@ class DiffGPMP2Planner(nn.Module):
     idx = th_initb.get_device()
     m = max_iters
     if with_graph:
+      if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)      # (a shared grid's gradient comes back unexpanded: no B-fold sum in autograd)
       ts = (th_initb, startb, goalb, sdfb)
       slots = tuple([i for i in range(4) if ts[i] is not None and ts[i].requires_grad])
       box = []
@@ -323,7 +324,7 @@ class DiffGPMP2Planner(nn.Module):
       eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
       iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts in the last B elements' storage
       info = torch.empty(B, dtype=torch.int32, device=dev)
-      _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
+      _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), *sd[:7], *_NO_COVS,
               max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
     pl.last_info = info
     pl._last = (st, go, None, None, None)

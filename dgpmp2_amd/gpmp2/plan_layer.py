@@ -60,7 +60,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
 
 _SDF_GRAD_COPIES = 16     # MI355X has 8 XCDs, each with its own L2: two partial grids per XCD (XCD-local atomics, summed afterwards)
 _ALL_STATIC = (True, True, True)
-_NO_COVS = (_capi.DGP_QC_STATIC, None, None, None)       # (qc_mode, qc_inv, obs_w, eps) as the trampoline takes them
+_NO_COVS = (_capi.DGP_QC_STATIC, None, None, None, 0, 0, None, None, None)       # the nine fields of DgpCovs as the trampoline takes them
 
 # current device / current raw stream as plain ints: torch.cuda.current_stream() builds a Stream object (1.2 us), the private getters
 # are what it calls underneath (0.1 us each); fall back to the public API where a torch build lacks them
@@ -139,8 +139,7 @@ class _GNStep(torch.autograd.Function):
     # iteration's; the planning loop without an autograd graph reuses one buffer per (batch, device, stream), see _info_buffer
     info = layer._info_buffer(B, dev, stream, thc)
     if own_info or layer.check_spd: info = torch.empty_like(info)
-    _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
+    _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
     layer.__dict__['last_info'] = info      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
@@ -197,23 +196,30 @@ class _GNStep(torch.autograd.Function):
     g_th = torch.empty_like(th) if need[2] else None
     g_st = _grad_like(start, stc) if need[3] else None
     g_go = _grad_like(goal, goc) if need[4] else None
-    shared = sd[3] == 0
-    g_sdf, copies, g_stride = None, 1, 0
-    if need[5]:
-      H, W = sd[1], sd[2]
-      copies = _SDF_GRAD_COPIES if shared else 1  # shared grid: two partial grids per XCD (XCD-local atomics), summed below
-      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
-      g_stride = 0 if shared else H * W
+    gs = _SdfGrad(layer, th, sdf, sd) if need[5] else _NO_SDF_GRAD
     g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
     g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
     g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
-    _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf), g_stride, copies,
+    _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
+            *cv[:9], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr, gs.stride, gs.copies,
             _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _raw_stream(dev))
-    if g_sdf is not None:
-      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
     return (None, None, None, None, None) + tuple(grads[i] for i in slots)
+
+
+def _expand_base(t):
+  """sdfb as autograd should see it.  A shared grid usually arrives as `grid.expand(B, 1, H, W)` of a (1, 1, H, W) tensor: differentiating w.r.t. the
+  expanded view makes autograd's ExpandBackward sum B slices of whatever the node returns -- 4096 x 65536 elements, 45 us on MI355X, for a sum the
+  backward kernel has already formed.  When `t` is exactly such a view the node takes the view's BASE as its differentiable input (same storage, same
+  launch) and returns the (1, 1, H, W) gradient itself.  Anything else (a view of a view, a differently strided base) is returned unchanged and gets B
+  equal shares (see _SdfGrad.finish)."""
+  if t is None or t.dim() != 4 or t.shape[0] <= 1 or t.stride(0) != 0 or not t._is_view(): return t
+  b = t._base
+  if (b is not None and b.dim() == 4 and b.shape[0] == 1 and b.shape[1:] == t.shape[1:] and b.stride()[1:] == t.stride()[1:] and b.data_ptr() == t.data_ptr()
+      and b.dtype is t.dtype and b.requires_grad == t.requires_grad):
+    return b
+  return t
 
 
 def _check_versions(tensors, versions):
@@ -241,19 +247,95 @@ def _grad_out(g, ref):
 _GNStep._backward_once = staticmethod(once_differentiable(_GNStep._backward_impl))
 
 
-def _finish_sdf_grad(g, sdf, shared):
-  """Partial SDF-gradient grids of a backward launch -> the gradient in the layout autograd expects for `sdf`."""
-  if shared:
-    g = g.sum(0, keepdim=True)
-  if sdf.shape[1] != 1:       # only channel 0 is read (obstacle_cost.py:35): the other channels get a zero gradient
-    full = g.new_zeros((g.shape[0],) + tuple(sdf.shape[1:]))
-    full[:, 0:1] = g
-    g = full
-  if shared and sdf.shape[0] != 1:
-    # the kernel already accumulated all B trajectories into the one shared grid; autograd's expand-backward will sum
-    # the B slices of whatever is returned here, so hand it B equal shares
-    g = (g / sdf.shape[0]).expand(sdf.shape)
-  return g if g.dtype is sdf.dtype else g.to(sdf.dtype)
+class _SdfGrad(object):
+  """Destination of dL/d(sdfb) for one backward launch, and its way back into autograd.
+
+  shared grid (sdfb expand()ed / a single grid): `_SDF_GRAD_COPIES` PARTIAL grids, one set per XCD (XCD-local atomics), in FLOAT64 whatever the I/O type
+      (DGP_GSDF_DENSE_F64): the sum over thousands of trajectories is formed in double and cast once, so the fp32 result no longer depends on the order in
+      which the atomics landed; summed over the copies here.
+  per-sample grids (the reference's API shape, sdfb (B,1,H,W) with `sdf_b.requires_grad_(True)`, learning/train_planner.py:267): the reference's gradient is a
+      dense (B,1,H,W) tensor -- 1 GiB of zeros around 4 MB of taps at B = 4096, 256 x 256.  `layer.sdf_grad`:
+        'dense'  that tensor (zero-filled here, atomics in the kernel; the reference's layout);
+        'sparse' a torch.sparse_coo_tensor of sdfb's shape holding the 4 n B taps (DGP_GSDF_SPARSE: no zero fill, no atomics; uncoalesced -- explicit zeros and
+                 the duplicates of neighbouring states included; .to_dense() / .coalesce() give the reference's tensor).  AccumulateGrad takes a sparse gradient
+                 for a dense leaf (sdfb.grad is then sparse, and sums with dense or sparse gradients from other nodes);
+        'auto'   (default) sparse when sdfb is a LEAF tensor, the trajectory has at most 256 states and the dense gradient would be larger than both
+                 _SPARSE_MIN_DENSE_BYTES and twice the sparse one; dense otherwise (a non-leaf's producer may not accept sparse gradients)."""
+
+  __slots__ = ('g', 'idx', 'ptr', 'stride', 'copies', 'mode', 'shared', 'shape', 'pc', 'dev')
+
+  def __init__(self, layer, th, sdf, sd, passes=1, zero_fill=False):
+    B, n = th.shape[0], th.shape[1]
+    H, W = sd[1], sd[2]
+    self.shared = sd[3] == 0
+    self.idx = None
+    self.pc, self.dev = layer._pc, th.get_device()
+    if self.shared:
+      self.copies, self.stride = _SDF_GRAD_COPIES, 0
+      self.mode = _capi.DGP_GSDF_DENSE_F64 if n <= 256 else _capi.DGP_GSDF_DENSE
+      self.g = torch.zeros((self.copies, 1, H, W), dtype=torch.float64 if self.mode == _capi.DGP_GSDF_DENSE_F64 else th.dtype, device=th.device)
+    else:
+      self.copies, self.stride = 1, H * W
+      want = layer.sdf_grad
+      nnz = passes * B * n * 4
+      sparse = False
+      if want != 'dense' and n <= 256:
+        dense_bytes, sparse_bytes = B * H * W * th.element_size(), nnz * (32 + th.element_size())
+        sparse = want == 'sparse' or (sdf.is_leaf and dense_bytes > _SPARSE_MIN_DENSE_BYTES and dense_bytes > 2 * sparse_bytes)
+      if sparse:
+        self.mode = _capi.DGP_GSDF_SPARSE
+        mk = torch.zeros if zero_fill else torch.empty
+        self.g = mk((nnz,), dtype=th.dtype, device=th.device)
+        self.idx = mk((4, nnz), dtype=torch.int64, device=th.device)
+        self.shape = (B,) + tuple(sdf.shape[1:])
+      else:
+        self.mode = _capi.DGP_GSDF_DENSE
+        self.g = th.new_zeros((B, 1, H, W))
+    self.ptr = self.g.data_ptr()
+
+  def sd(self, sd):
+    """The seven DgpSdf fields of the launch: the grid as marshalled for the forward + how its gradient is delivered."""
+    return sd[:5] + (self.mode, None if self.idx is None else self.idx.data_ptr())
+
+  def finish(self, sdf):
+    """The launch's output -> the gradient in the layout autograd expects for `sdf`."""
+    g = self.g
+    if self.mode == _capi.DGP_GSDF_SPARSE:
+      if g.dtype is not sdf.dtype: g = g.to(sdf.dtype)
+      return torch.sparse_coo_tensor(self.idx, g, self.shape, check_invariants=False)      # (channel index 0: only channel 0 is read, obstacle_cost.py:35)
+    if self.shared:
+      # the copies summed (in double), scaled and cast in one launch; an expand()ed sdfb gets B equal shares: the kernel already accumulated all B
+      # trajectories into the one grid, and autograd's expand-backward will sum the B slices of whatever is returned here
+      many = sdf.shape[0] != 1
+      out = torch.empty((1, 1) + tuple(g.shape[2:]), dtype=sdf.dtype if sdf.dtype in (torch.float32, torch.float64) else g.dtype, device=g.device)
+      _launch(self.dev, self.pc.sum_partial_grids, g.data_ptr(), _io_code(g.dtype), self.copies, g.shape[2] * g.shape[3], 1.0 / sdf.shape[0] if many else 1.0,
+              out.data_ptr(), _io_code(out.dtype), _raw_stream(self.dev))
+      g = out
+      if sdf.shape[1] != 1:
+        full = g.new_zeros((1,) + tuple(sdf.shape[1:]))
+        full[:, 0:1] = g
+        g = full
+      if many: g = g.expand(sdf.shape)
+      return g if g.dtype is sdf.dtype else g.to(sdf.dtype)
+    if sdf.shape[1] != 1:       # only channel 0 is read (obstacle_cost.py:35): the other channels get a zero gradient
+      full = g.new_zeros((g.shape[0],) + tuple(sdf.shape[1:]))
+      full[:, 0:1] = g
+      g = full
+    return g if g.dtype is sdf.dtype else g.to(sdf.dtype)
+
+
+class _NoSdfGrad(object):
+  ptr, stride, copies = None, 0, 1
+
+  @staticmethod
+  def sd(sd): return sd[:7]
+
+  @staticmethod
+  def finish(sdf): return None
+
+
+_NO_SDF_GRAD = _NoSdfGrad()
+_SPARSE_MIN_DENSE_BYTES = 16 << 20      # 'auto': below this a zero-filled dense gradient costs a few microseconds and keeps the reference's layout
 
 
 class _GNStepErrors(torch.autograd.Function):
@@ -279,8 +361,7 @@ class _GNStepErrors(torch.autograd.Function):
     stream = _raw_stream(dev)
     info = layer._info_buffer(B, dev, stream, thc)
     if own_info or layer.check_spd: info = torch.empty_like(info)
-    _launch(dev, layer._pc.gn_step_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), usg.data_ptr(), ugp.data_ptr(),
+    _launch(dev, layer._pc.gn_step_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), usg.data_ptr(), ugp.data_ptr(),
             uobs.data_ptr(), stream)
     layer.__dict__['last_info'] = info
     if layer.check_spd and bool(info.any()):
@@ -327,22 +408,16 @@ class _GNStepErrors(torch.autograd.Function):
     g_th = torch.empty_like(th) if need[2] else None
     g_st = _grad_like(start, stc) if need[3] else None
     g_go = _grad_like(goal, goc) if need[4] else None
-    shared = sd[3] == 0
-    g_sdf, copies, g_stride = None, 1, 0
-    if need[5]:
-      H, W = sd[1], sd[2]
-      copies = _SDF_GRAD_COPIES if shared else 1
-      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
-      g_stride = 0 if shared else H * W
+    errs = g_usg is not None or g_ugp is not None or g_uobs is not None
+    gs = _SdfGrad(layer, th, sdf, sd, passes=2 if errs else 1) if need[5] else _NO_SDF_GRAD      # (with error cotangents the grid is read at th + dtheta and at th)
     g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
     g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
     g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
-    ws = torch.empty_like(th) if (g_usg is not None or g_ugp is not None or g_uobs is not None) else None      # dL/d(th + dtheta) between the two launches
-    _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
-            _ptr(g_go), _ptr(g_sdf), g_stride, copies, _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _ptr(ws), _raw_stream(dev))
-    if g_sdf is not None:
-      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    ws = torch.empty_like(th) if errs else None      # dL/d(th + dtheta) between the two launches
+    _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
+            *cv[:9], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
+            _ptr(g_go), gs.ptr, gs.stride, gs.copies, _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _ptr(ws), _raw_stream(dev))
+    g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
     return (None, None, None, None, None) + tuple(grads[i] for i in slots)
 
@@ -374,7 +449,7 @@ class _GNSolve(torch.autograd.Function):
     iters = buf[2 * B * m + B:].view(torch.int32)[:B]
     info = torch.empty(B, dtype=torch.int32, device=th.device)
     hist = torch.empty((m, B, n, d), dtype=torch.float64, device=th.device)      # th_k, fp64 whatever the I/O type (rows past iters[b] stay unwritten and unread)
-    _launch(dev, layer._pc.gn_solve_traced, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3], 0, None, None, None,
+    _launch(dev, layer._pc.gn_solve_traced, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *_NO_COVS,
             max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), hist.data_ptr(),
             _raw_stream(dev))
     box.append((buf, info))
@@ -405,18 +480,11 @@ class _GNSolve(torch.autograd.Function):
     g_th = torch.empty_like(th_out) if need[0] else None
     g_st = _grad_like(start, stc) if need[1] else None
     g_go = _grad_like(goal, goc) if need[2] else None
-    shared = sd[3] == 0
-    g_sdf, copies, g_stride = None, 1, 0
-    if need[3]:
-      H, W = sd[1], sd[2]
-      copies = _SDF_GRAD_COPIES if shared else 1
-      g_sdf = th_out.new_zeros((copies if shared else B, 1, H, W))
-      g_stride = 0 if shared else H * W
-    _launch(dev, layer._pc.gn_solve_backward, solver.h, B, stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3], ctx.max_iters,
-            ctx.hist.data_ptr(), th_out.data_ptr(), ctx.iters.data_ptr(), g_out.data_ptr(), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf), g_stride,
-            copies, _raw_stream(dev))
-    if g_sdf is not None:
-      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    gs = _SdfGrad(layer, th_out, sdf, sd, passes=ctx.max_iters, zero_fill=True) if need[3] else _NO_SDF_GRAD      # (a trajectory writes only the passes it ran)
+    _launch(dev, layer._pc.gn_solve_backward, solver.h, B, stc.data_ptr(), goc.data_ptr(), *gs.sd(sd), ctx.max_iters,
+            ctx.hist.data_ptr(), th_out.data_ptr(), ctx.iters.data_ptr(), g_out.data_ptr(), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr, gs.stride,
+            gs.copies, _raw_stream(dev))
+    g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf)
     return (None, None, None, None, None, None) + tuple(grads[i] for i in ctx.slots)
 
@@ -468,19 +536,12 @@ class _EvalErrors(torch.autograd.Function):
     g_th = torch.empty_like(th) if need[1] else None
     g_st = _grad_like(start, stc) if need[2] else None
     g_go = _grad_like(goal, goc) if need[3] else None
-    shared = sd[3] == 0
-    g_sdf, copies, g_stride = None, 1, 0
-    if sdf is not None and need[4]:
-      H, W = sd[1], sd[2]
-      copies = _SDF_GRAD_COPIES if shared else 1
-      g_sdf = th.new_zeros((copies if shared else B, 1, H, W))
-      g_stride = 0 if shared else H * W
+    gs = _SdfGrad(layer, th, sdf, sd) if (sdf is not None and need[4]) else _NO_SDF_GRAD
     g_eps = _grad_like(eps, th) if (need[5] and eps is not None) else None
-    _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), _ptr(g_sdf),
-            g_stride, copies, _ptr(g_eps), _raw_stream(dev))
-    if g_sdf is not None:
-      g_sdf = _finish_sdf_grad(g_sdf, sdf, shared)
+    _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
+            *cv[:9], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr,
+            gs.stride, gs.copies, _ptr(g_eps), _raw_stream(dev))
+    g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_eps, eps))
     return (None, None, None) + tuple(grads[i] for i in ctx.slots)
 
@@ -520,6 +581,7 @@ class PlanLayer(nn.Module):
     self.dynamics_mode = learn_params['dgpmp2']['dynamics_mode'] if learn_params is not None else None
     self._q_full = learn_params is not None and self.dynamics_mode == 'q_full'        # plan_layer.py:90
     self.check_spd = check_spd
+    self.sdf_grad = 'auto'             # how the gradient of PER-SAMPLE grids is returned: 'auto' | 'dense' | 'sparse' (see _SdfGrad)
     self.last_info = None
     self._last = None
     self._solvers = {}                 # torch dtype -> _capi.Solver
@@ -569,7 +631,7 @@ class PlanLayer(nn.Module):
     return t
 
   def _sdf_args(self, sdfb, dtype, B, dev):
-    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35) -> (address, H, W, batch stride in elements, keep-alive tensor); an
+    """sdfb (B,1,H,W) (only channel 0 is read, obstacle_cost.py:35) -> the seven DgpSdf fields (address, H, W, batch stride in elements, layout, 0, None) + a keep-alive tensor; an
     expand()ed / single grid is passed as shared (stride 0).  None: no grid (dgp_eval_errors without obstacle outputs only).
     A GN loop passes the same grid tensor every iteration, and slicing + checking it costs 5 us -- half a kernel -- so the result for
     the LAST tensor seen is cached, but ONLY in the zero-copy case: the kernel then reads sdfb's own storage, whatever was written to
@@ -594,8 +656,8 @@ class PlanLayer(nn.Module):
     t = t.detach()
     if t.dtype != dtype or not t.is_contiguous():
       t = t.to(dtype).contiguous()              # an owned copy: never cached (it would not see later writes to sdfb)
-      return (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), t)
-    res = (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), None)      # a view into sdfb: lives as long as sdfb does
+      return (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), _capi.DGP_SDF_ROWMAJOR, 0, None, t)
+    res = (t.data_ptr(), int(H), int(W), 0 if shared else int(t.stride(0)), _capi.DGP_SDF_ROWMAJOR, 0, None, None)      # a view into sdfb: lives as long as sdfb does
     me = weakref.ref(self)
 
     def _drop(_, me=me):                        # the tensor died: its address may be reused by another tensor object
@@ -605,7 +667,7 @@ class PlanLayer(nn.Module):
       self.__dict__['_sdf_cache'] = (weakref.ref(sdfb, _drop), sdfb.data_ptr(), sdfb.shape, sdfb.stride(), sdfb.dtype, B, dev, dtype, res)
     except TypeError:
       self.__dict__['_sdf_cache'] = None
-    return res[:4] + (t,)                       # (the caller's copy of the result keeps the view alive for the duration of the call)
+    return res[:7] + (t,)                       # (the caller's copy of the result keeps the view alive for the duration of the call)
 
   @staticmethod
   def static_flags(qc, ow, eps):
@@ -614,7 +676,7 @@ class PlanLayer(nn.Module):
     return (qc is None or '_dgp_static' in qc.__dict__, ow is None or '_dgp_static' in ow.__dict__, eps is None or '_dgp_static' in eps.__dict__)
 
   def _cov_args(self, qc, ow, eps, dtype, B, dev, static=(False, False, False), scalar_ok=False):
-    """Covariance tensors -> (qc_mode, qc_inv, obs_w, eps addresses, keep-alive list).  A static entry selects the constants of the
+    """Covariance tensors -> the nine DgpCovs fields (qc_mode, the qc_inv / obs_w / eps addresses, flags, row stride, three optional outputs) + a keep-alive list.  A static entry selects the constants of the
     handle (no per-state tensor is streamed)."""
     if static == _ALL_STATIC:
       return _NO_COVS_KEEP
@@ -645,7 +707,7 @@ class PlanLayer(nn.Module):
         qc_p = prep(qc, (n - 1) * (d * d if self._q_full else dof * dof), 'qc_inv_trajb')
     if ow is not None and not static[1]: ow_p = prep(ow, n * self.nlinks, 'obscov_inv_trajb')
     if eps is not None and not static[2]: ep_p = prep(eps, n * self.nlinks, 'eps_trajb')
-    return (mode, qc_p, ow_p, ep_p, keep)
+    return (mode, qc_p, ow_p, ep_p, 0, 0, None, None, None, keep)
 
   def _check_inputs(self, thb, startb, goalb):
     if not (thb.is_cuda and startb.is_cuda and goalb.is_cuda):
@@ -675,6 +737,7 @@ class PlanLayer(nn.Module):
       self.__dict__['_last'] = (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
                                 None if (eps_trajb is None or static[2]) else eps_trajb)
     if torch.is_grad_enabled():
+      if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
       ts = (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
       slots = tuple([i for i in range(7) if ts[i] is not None and ts[i].requires_grad])
       if slots:
@@ -699,6 +762,7 @@ class PlanLayer(nn.Module):
                                 None if (eps_trajb is None or static[2]) else eps_trajb)
     B = thb.shape[0]
     if torch.is_grad_enabled():
+      if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
       ts = (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
       slots = tuple([i for i in range(7) if ts[i] is not None and ts[i].requires_grad])
       if slots:
@@ -724,8 +788,7 @@ class PlanLayer(nn.Module):
     proto = self._err_protos.get((B, dtype, dev))
     if proto is None: proto = self._err_proto(B, dtype, dev, thc)
     outs = [torch.empty_like(proto) if w else None for w in (grid, grid, True, True, grid)]
-    _launch(dev, self._pc.eval_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), sd[0], sd[1], sd[2], sd[3],
-            cv[0], cv[1], cv[2], cv[3], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(outs[4]), _raw_stream(dev))
+    _launch(dev, self._pc.eval_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(outs[4]), _raw_stream(dev))
     return outs, thc, stc, goc, sd, cv
 
   def _eval(self, thb, sdfb, startb, goalb, qc, ow, eps):
@@ -754,6 +817,7 @@ class PlanLayer(nn.Module):
     """(err_ext, start_goal_error, gp_error, obs_error) at thb, each (B,1,1) (None where a grid is needed and sdfb is None), carrying
     the autograd graph the reference's plain torch ops would carry: w.r.t. thb, sdfb, the start / goal means and the current eps."""
     if torch.is_grad_enabled():
+      if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
       ts = (thb, st, go, sdfb, eps)
       slots = tuple([i for i in range(5) if ts[i] is not None and ts[i].requires_grad])
       if slots:
@@ -789,4 +853,4 @@ class PlanLayer(nn.Module):
     return o[1].reshape(thb.shape[0], 1), o[2], o[3]
 
 
-_NO_SDF = (None, 2, 2, 0, None)
+_NO_SDF = (None, 2, 2, 0, 0, 0, None, None)       # the seven fields of DgpSdf + the keep-alive slot

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DGP_ABI_VERSION 5
+#define DGP_ABI_VERSION 6
 
 /* status codes */
 #define DGP_OK              0
@@ -53,7 +53,8 @@ extern "C" {
 #define DGP_QC_PERSTATE 1   /* qc_inv (B, n-1, dof, dof): Q^-1 built as in gp_factor.py:65-73                       */
 #define DGP_QC_QFULL    2   /* qc_inv (B, n-1, d, d) is Q^-1 itself ('q_full', plan_layer.py:90)                    */
 #define DGP_QC_SCALAR   3   /* qc_inv (B, n-1): one scalar s_k per GP factor, Q_c^-1 = s_k * DgpConfig.Q_c_inv (diagonal) --      */
-                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] and their backward (g_qc_inv: the (B,n-1,dof,dof) gradient of the blocks s_k I), n <= 256 */
+                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] and their backward (g_qc_inv: the (B,n-1,dof,dof) gradient of the blocks s_k I;
+                               with DGP_COVS_SQUARED the (B,n-1) gradient of the raw scalars), n <= 256 */
 
 /* Constructor arguments of PlanLayer / DiffGPMP2Planner that the math depends on
  * (plan_layer.py:14-81).  All lengths in the reference's units. */
@@ -85,20 +86,58 @@ typedef struct DgpHandle DgpHandle;
 /* Signed-distance field argument: sdfb (B,1,H',W') of PlanLayer.forward (only sdfb[:,0] is read,
  * obstacle_cost.py:35).  batch_stride is in ELEMENTS between consecutive samples' grids; 0 means one
  * grid shared by the whole batch (an expand()ed tensor). */
+/* Memory layout of a grid (DgpSdf::layout).  ROWMAJOR is the reference's tensor.  TILED4: the same H' x W' values stored as 4 x 4 tiles,
+ * element (y, x) at offset ((y / 4) * ceil(W' / 4) + x / 4) * 16 + (y % 4) * 4 + (x % 4) of a grid of ceil(H'/4) * ceil(W'/4) * 16 elements (cells past
+ * the last row / column are padding, never read): the 2 x 2 footprint of a bilinear lookup then lies in ONE 64-byte (fp32) tile in 9 cases of 16 instead of
+ * in two rows 4 W' bytes apart -- what dgp_sdf_2d(..., out_layout) writes directly for per-sample grids (DESIGN.md section 3 "SDF"). */
+#define DGP_SDF_ROWMAJOR 0
+#define DGP_SDF_TILED4   1
+
+/* How the backward entry points deliver dL/d(sdf) (DgpSdf::grad_mode; the `g_sdf` argument is the destination):
+ *   DGP_GSDF_DENSE     g_sdf = grid(s) of the handle's io_dtype in the layout given by g_sdf_batch_stride / g_sdf_copies, accumulated with atomics
+ *                      (the caller zeroes them) -- the reference's dense sdf.grad;
+ *   DGP_GSDF_DENSE_F64 the same with grids of DOUBLES whatever io_dtype: the partial copies of a shared grid, summed (and cast) by the caller -- the
+ *                      accumulation over thousands of trajectories no longer depends on the order of fp32 atomics;
+ *   DGP_GSDF_SPARSE    no grid at all: g_sdf = (passes, B, n, 4) tap VALUES (io_dtype) and grad_indices = the (4, passes*B*n*4) int64 COO indices
+ *                      (b, 0, y, x) of a sparse tensor of sdfb's shape (torch.sparse_coo_tensor; explicit zeros and duplicates included; row-major
+ *                      (y, x) whatever `layout`).  passes = 1 (dgp_gn_step_backward, dgp_eval_errors_backward), 2 (dgp_gn_step_errors_backward with an
+ *                      unweighted-error cotangent: the taps at th + dtheta, then those at th) or max_iters (dgp_gn_solve_backward, whose caller
+ *                      ZERO-FILLS both arrays: passes a trajectory did not run stay untouched).  No atomics, no O(B H' W') zero fill: the dense
+ *                      gradient of B per-sample grids is 1 GiB of zeros at B = 4096, 256 x 256 around 4 MB of taps.  num_states <= 256.  */
+#define DGP_GSDF_DENSE     0
+#define DGP_GSDF_DENSE_F64 1
+#define DGP_GSDF_SPARSE    2
+
 typedef struct DgpSdf {
   const void* data;
   int32_t     rows;          /* H' */
   int32_t     cols;          /* W' >= 2; res = (x_lims[1]-x_lims[0])/W'  (obstacle_cost.py:34); a single-column grid
                                 is rejected with DGP_EUNSUPPORTED: the taps are fetched as column pairs */
   int64_t     batch_stride;
+  int32_t     layout;        /* DGP_SDF_*: layout of `data` (and of a dense g_sdf)                                                  */
+  int32_t     grad_mode;     /* DGP_GSDF_*: backward entry points only                                                              */
+  int64_t*    grad_indices;  /* DGP_GSDF_SPARSE: the (4, nnz) int64 index array, else ignored                                        */
 } DgpSdf;
 
 /* Per-call covariance inputs = the three trailing arguments of PlanLayer.forward. */
+/* DgpCovs::flags */
+#define DGP_COVS_SQUARED 1u  /* the per-state SCALARS (qc_inv under DGP_QC_SCALAR, obs_w, eps) are the learn module's RAW outputs and are squared
+                                inside the kernel (in io_dtype, as torch's v * v): diff_gpmp2_planner.py:247-290 for single-link robots in the modes
+                                'fix_dynamics' / 'diag_identity' is exactly that.  The backward entry points then write dL/d(raw) = 2 raw dL/d(raw^2)
+                                into g_qc_inv (B,n-1) / g_obs_w / g_eps with the same row stride.  dgp_gn_step[_errors] and their backward only. */
 typedef struct DgpCovs {
   int32_t     qc_mode;       /* DGP_QC_*                                                                 */
   const void* qc_inv;        /* see DGP_QC_*; NULL iff DGP_QC_STATIC                                     */
   const void* obs_w;         /* obscov_inv_trajb (B,n,1,1) or NULL = static 1/cost_sigma^2               */
   const void* eps;           /* eps_trajb (B,n,1,1) or NULL = static epsilon_dist                        */
+  uint32_t    flags;         /* DGP_COVS_*                                                               */
+  int32_t     pad_;
+  int64_t     row_stride;    /* elements between consecutive trajectories' rows of the SCALAR inputs (qc_inv under DGP_QC_SCALAR, obs_w, eps) and of
+                                their gradients; 0 = dense ((n-1) / n / n).  The three pointers may then address one (B, row_stride) matrix -- the
+                                learn module's output `out[:, 0, :]` sliced at [0, n-1), [n-1, 2n-1), [2n-1, 3n-1) (diff_gpmp2_planner.py:255-283)   */
+  void *sq_qc_inv, *sq_obs_w, *sq_eps;   /* DGP_COVS_SQUARED, dgp_gn_step[_errors], optional: the squared tensors in the reference's shapes -- q_k^2 I blocks
+                                (B,n-1,dof,dof), (B,n), (B,n), dense -- written by the step kernel: what DiffGPMP2Planner.step returns as qc_inv_curr,
+                                obscov_inv_curr, eps_curr (diff_gpmp2_planner.py:211)                     */
 } DgpCovs;
 
 int         dgp_abi_version(void);
@@ -179,6 +218,12 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch,
                          void* g_th, void* g_start, void* g_goal,
                          void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                          void* g_qc_inv, void* g_obs_w, void* g_eps, void* stream);
+
+/* The partial copies of a shared grid's gradient (g_sdf_copies above) -> the gradient: out[e] = scale * sum_c partial[c * elems + e], e < elems = H' W',
+ * one launch at memory speed; partial_dtype DGP_F32 / DGP_F64 (DGP_GSDF_DENSE_F64), out_dtype DGP_F32 / DGP_F64.  `scale`: 1, or 1 / B for a caller whose
+ * autograd will sum B equal shares of an expand()ed grid.  (torch.sum over the copies costs 45 us for 16 x 256 x 256 doubles on MI355X; this 3.) */
+int dgp_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t copies, int64_t elems, double scale,
+                          void* out, int32_t out_dtype, void* stream);
 
 /* Backward of dgp_eval_errors == torch autograd through PlanLayer.error_ext_batch (plan_layer.py:310-345) and the unweighted errors
  * gp_error / obs_error / start_goal_error (:374-388), which the reference's training loss differentiates

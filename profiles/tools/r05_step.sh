@@ -1,0 +1,28 @@
+#!/bin/bash
+# one development iteration on the GPU box: the every-kernel + parity + planner tests, then the training iteration with the grid gradient
+#   gpurun -- bash profiles/tools/r05_step.sh [pytest -k expression]
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05b
+rm -rf "$O"; mkdir -p "$O"
+cd "$R"
+K="${1:-}"
+if [ -n "$K" ]; then
+  (timeout 1800 python -m pytest tests -m gpu -q -x -k "$K" > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
+else
+  (timeout 1800 python -m pytest tests -m gpu -q -x > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
+fi
+tail -15 "$O/pytest_gpu.log"
+timeout 900 python profiles/tools/train_iteration.py 2> "$O/ti.err" | grep -a '^{' > "$O/train_iteration.json"
+tail -3 "$O/ti.err"
+python - <<PY
+import json
+d = json.load(open("$O/train_iteration.json"))
+for B in ('B4096', 'B32'):
+  for k in ('per_sample', 'shared'):
+    for t in ('no_sdf_grad', 'sdf_grad'):
+      e = d[B][k][t]
+      print(B, k, t, 'eager %.1f' % e['eager_us'], 'replay', e.get('hip_graph_replay_us'), e.get('grad_layout', ''), e.get('grad_bytes', ''), e.get('graph_error', ''))
+PY
+( U="python profiles/tools/ubench.py"; $U --what bwd,bwd_sdf16,bwd_sdf16w,bwd_sdf8w --covs perstate; $U --what bwd,bwd_sdf,bwd_sparse --covs perstate --sdf persample; $U --what bwd,bwd_sdf16,bwd_sdf16w; $U --what bwd,bwd_sdf,bwd_sparse --sdf persample ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
+cat "$O/ubench.jsonl"

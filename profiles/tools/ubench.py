@@ -108,12 +108,20 @@ def main():
       ge = torch.ones(B, device=dev, dtype=dt)
       gq = (torch.empty(B, n - 1, dof, dof, device=dev, dtype=dt) if a.covs == 'scalar' else torch.empty_like(keep[0])) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
       gp = torch.empty(B, n, device=dev, dtype=dt) if covs else None
-      copies = int(what[7:]) if what.startswith('bwd_sdf') and what[7:] else 1
-      gs = None
-      if what != 'bwd':
-        gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=dt)
+      # bwd_sdf[N]: dense grid gradient (N partial copies of a shared grid); bwd_sdf[N]w: the partial copies in float64 (DGP_GSDF_DENSE_F64); bwd_sparse: the taps as
+      # COO values + indices (DGP_GSDF_SPARSE, per-sample grids)
+      wide = what.startswith('bwd_sdf') and what.endswith('w')
+      num = what[7:-1] if wide else what[7:]
+      copies = int(num) if what.startswith('bwd_sdf') and num else 1
+      gs, sab = None, sa
+      if what == 'bwd_sparse':
+        gs = torch.empty(B * n * 4, device=dev, dtype=dt); gi = torch.empty((4, B * n * 4), device=dev, dtype=torch.int64)
+        sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, grad_mode=_capi.DGP_GSDF_SPARSE, grad_indices=gi.data_ptr())
+      elif what != 'bwd':
+        gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=torch.float64 if wide else dt)
+        if wide: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, grad_mode=_capi.DGP_GSDF_DENSE_F64)
       s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
-      f = lambda k: s.gn_step_backward(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
+      f = lambda k: s.gn_step_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
                                        P(gq), P(gw), P(gp), st, g_sdf_copies=copies)
     else:
       raise SystemExit('unknown --what ' + what)

@@ -322,6 +322,16 @@ int emul_gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* 
                                            g_goal, g_sdf, g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, workspace, EmulLaunch{h});
 }
 
+int emul_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t copies, int64_t elems, double scale, void* out, int32_t out_dtype, void*) {
+  if (!partial || !out || copies < 1 || copies > 64 || elems < 1) return DGP_EINVAL;
+  for (int64_t e = 0; e < elems; ++e) {
+    double acc = 0.0;
+    for (int c = 0; c < copies; ++c) acc += partial_dtype == DGP_F64 ? ((const double*)partial)[(int64_t)c * elems + e] : (double)((const float*)partial)[(int64_t)c * elems + e];
+    if (out_dtype == DGP_F64) ((double*)out)[e] = acc * scale; else ((float*)out)[e] = (float)(acc * scale);
+  }
+  return DGP_OK;
+}
+
 int emul_event_create(void** out) { if (out) *out = nullptr; return DGP_OK; }      // nothing to time on the host
 void emul_event_destroy(void*) {}
 int emul_event_elapsed_ms(void*, void*, float* ms) { if (ms) *ms = 0.0f; return DGP_OK; }

@@ -81,15 +81,15 @@ class Backend(object):
 
   def empty(self, shape, io=None, dtype=None, fill=None):
     dt = dtype if dtype is not None else self._np_dtype(io)
-    a = np.full(shape, np.nan if fill is None and dt != np.int32 else (fill if fill is not None else -1), dtype=dt)
+    a = np.full(shape, np.nan if fill is None and dt not in (np.int32, np.int64) else (fill if fill is not None else -1), dtype=dt)
     return self.to_dev(a, dtype=dt)
 
   def to_np(self, obj):
     if obj is None: return None
-    if self.kind == 'emul': return np.array(obj, dtype=np.float64 if obj.dtype != np.int32 else np.int32)
+    if self.kind == 'emul': return np.array(obj, dtype=np.float64 if obj.dtype not in (np.int32, np.int64) else obj.dtype)
     self.torch.cuda.synchronize()
     a = obj.cpu().numpy()
-    return a.astype(np.float64) if a.dtype != np.int32 else a
+    return a.astype(np.float64) if a.dtype not in (np.int32, np.int64) else a
 
   def stream(self):
     if self.kind == 'emul': return None
@@ -119,6 +119,41 @@ class Backend(object):
     _, eps_p = self.to_dev(eps, io)
     covs = solver.covs_arg(mode, qc_p, ow_p, eps_p)
     return solver, B, th_p, st_p, go_p, sdf_arg, covs
+
+  # -- destination of the grid gradient (DgpSdf::grad_mode) -----------------------------------------------
+  def _gsdf(self, sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n, passes=1):
+    """sdf_grad: 'dense' (grids of the I/O type), 'f64' (DGP_GSDF_DENSE_F64: double grids whatever the I/O type) or 'sparse' (DGP_GSDF_SPARSE: tap values +
+    COO indices; `passes` tap blocks, zero-filled as the chain kernels' caller must).  -> (state for _gsdf_out, g_sdf address, batch stride)"""
+    sdf = np.asarray(sdf)
+    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    if sdf_grad == 'sparse':
+      assert sdf_copies == 1 and stride != 0
+      nnz = passes * B * n * 4
+      vals, vals_p = self.empty((nnz,), io, fill=0.0)
+      idx, idx_p = self.empty((4, nnz), dtype=np.int64, fill=0)
+      sdf_arg.grad_mode = _capi.DGP_GSDF_SPARSE; sdf_arg.grad_indices = idx_p
+      return ('sparse', vals, idx, sdf.shape), vals_p, stride
+    shape = ((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape
+    if sdf_grad == 'f64':
+      g, g_p = self.empty(shape, dtype=np.float64, fill=0.0)
+      sdf_arg.grad_mode = _capi.DGP_GSDF_DENSE_F64
+    else:
+      g, g_p = self.empty(shape, io, fill=0.0)
+    return ('dense', g), g_p, stride
+
+  def _gsdf_out(self, st):
+    """-> the gradient as a float64 array: the grid(s) as written (partial copies unsummed), or the sparse taps scattered into a grid of sdfb's shape"""
+    if st is None: return None
+    if st[0] == 'dense': return self.to_np(st[1])
+    vals = self.to_np(st[1])
+    if self.kind == 'emul': idx = np.array(st[2])
+    else:
+      self.torch.cuda.synchronize(); idx = st[2].cpu().numpy()
+    shape = st[3]
+    assert idx[0].min() >= 0 and idx[0].max() < shape[0] and (idx[1] == 0).all() and idx[2].min() >= 0 and idx[2].max() < shape[2] and idx[3].min() >= 0 and idx[3].max() < shape[3]
+    out = np.zeros(shape, dtype=np.float64)
+    np.add.at(out, (idx[0], idx[1], idx[2], idx[3]), vals)
+    return out
 
   # -- entry points ------------------------------------------------------------------------------------
   def step(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
@@ -152,7 +187,7 @@ class Backend(object):
     return tuple(self.to_np(o[0]) for o in outs)
 
   def backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, qc=None, ow=None, eps=None, q_full=False, io='f64',
-               sdf_copies=1):
+               sdf_copies=1, sdf_grad='dense'):
     """-> dict of gradients: th, start, goal, sdf, qc, ow, eps (numpy fp64)"""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
     n = th.shape[1]
@@ -162,20 +197,18 @@ class Backend(object):
     gth, gth_p = self.empty(th.shape, io)
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
-    sdf = np.asarray(sdf)
-    gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+    gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n)
     qshape = None if qc is None else (np.asarray(qc).shape if np.asarray(qc).ndim != 2 else np.asarray(qc).shape + (p.dof, p.dof))      # DGP_QC_SCALAR: the gradient of the blocks s_k I
     gqc, gqc_p = self.empty(qshape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
-    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
     solver.gn_step_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, ge_p, gth_p, gst_p, ggo_p, gsdf_p, stride, gqc_p, gow_p,
                             gep_p, self.stream(), g_sdf_copies=sdf_copies)
-    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc),
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs), qc=self.to_np(gqc),
                 ow=self.to_np(gow), eps=self.to_np(gep))
 
   def eval_backward(self, p, th, start, goal, sdf, g_err_ext=None, g_unw_sg=None, g_unw_gp=None, g_unw_obs=None, eps=None, io='f64', sdf_copies=1,
-                    want_sdf=True):
+                    want_sdf=True, sdf_grad='dense'):
     """dgp_eval_errors_backward -> dict of gradients: th, start, goal, sdf, eps (numpy fp64).  sdf None: no grid (sg / gp cotangents only)."""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, None, None, eps, False)
     n = th.shape[1]
@@ -183,15 +216,13 @@ class Backend(object):
     gth, gth_p = self.empty(th.shape, io)
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
-    gsdf, gsdf_p, stride = None, None, 0
+    gs, gsdf_p, stride = None, None, 0
     if sdf is not None and want_sdf:
-      sdf = np.asarray(sdf)
-      gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
-      stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+      gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
     solver.eval_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride, gep_p,
                                 self.stream(), g_sdf_copies=sdf_copies)
-    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), eps=self.to_np(gep))
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs), eps=self.to_np(gep))
 
   # -- round 4: the fused-loop backward and the training iteration as single calls ---------------------------
   def solve_traced(self, p, th, start, goal, sdf, max_iters, tol_delta, io='f64'):
@@ -204,7 +235,7 @@ class Backend(object):
     solver.gn_solve_traced(B, th_p, st_p, go_p, sdf_arg, None, max_iters, tol_delta, tho_p, its_p, None, None, None, info_p, hist_p, self.stream())
     return self.to_np(tho), self.to_np(its), self.to_np(hist), self.to_np(info)
 
-  def solve_backward(self, p, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, io='f64', sdf_copies=1, want_sdf=True):
+  def solve_backward(self, p, start, goal, sdf, max_iters, th_hist, th_out, iters, g_th_out, io='f64', sdf_copies=1, want_sdf=True, sdf_grad='dense'):
     """dgp_gn_solve_backward -> dict of gradients: th (w.r.t. th_init), start, goal, sdf"""
     th_out = np.asarray(th_out)
     solver, B, tho_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th_out, start, goal, sdf, None, None, None, False)
@@ -215,13 +246,13 @@ class Backend(object):
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
     sdf = np.asarray(sdf)
-    gsdf, gsdf_p = (None, None)
-    if want_sdf:
-      gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+    gs, gsdf_p = (None, None)
     stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    if want_sdf:
+      gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, th_out.shape[1], passes=max_iters)
     solver.gn_solve_backward(B, st_p, go_p, sdf_arg, max_iters, hist_p, tho_p, its_p, g_p, gth_p, gst_p, ggo_p, gsdf_p, stride, self.stream(),
                              g_sdf_copies=sdf_copies)
-    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf))
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs))
 
   def step_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
     """dgp_gn_step_errors -> dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs (the last three at th + dtheta)"""
@@ -233,7 +264,7 @@ class Backend(object):
     return (self.to_np(dth), self.to_np(outs[0][0]), self.to_np(outs[1][0]), self.to_np(info)) + tuple(self.to_np(o[0]) for o in outs[2:])
 
   def step_errors_backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, qc=None, ow=None, eps=None,
-                           q_full=False, io='f64', sdf_copies=1):
+                           q_full=False, io='f64', sdf_copies=1, sdf_grad='dense'):
     """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps"""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
     n = th.shape[1]
@@ -243,14 +274,13 @@ class Backend(object):
     gth, gth_p = self.empty(th.shape, io)
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
-    sdf = np.asarray(sdf)
-    gsdf, gsdf_p = self.empty(((sdf_copies,) + sdf.shape[1:]) if sdf_copies > 1 else sdf.shape, io, fill=0.0)
+    errs = any(c is not None for c in (g_unw_sg, g_unw_gp, g_unw_obs))
+    gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n, passes=2 if errs else 1)
     gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
     ws, ws_p = self.empty(th.shape, io)
-    stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
     solver.gn_step_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride,
                                    gqc_p, gow_p, gep_p, ws_p, self.stream(), g_sdf_copies=sdf_copies)
-    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self.to_np(gsdf), qc=self.to_np(gqc), ow=self.to_np(gow),
+    return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs), qc=self.to_np(gqc), ow=self.to_np(gow),
                 eps=self.to_np(gep))

@@ -802,6 +802,71 @@ def case_step_errors(be, golden, io):
 ALL_CASES.append(case_step_errors)
 
 
+def case_sdf_gradient_delivery(be, golden, io):
+  """DgpSdf::grad_mode (round 5).  Per-sample grids: the taps as COO entries (DGP_GSDF_SPARSE: no zero-filled (B,1,H,W) grid, no atomics), scattered back
+  into a grid, equal the dense accumulation -- single step, the training iteration's two tap blocks, the fused loop's per-iteration blocks (early stoppers leave
+  theirs untouched) and dgp_eval_errors_backward.  Shared grid: FLOAT64 partial copies behind fp32 I/O (DGP_GSDF_DENSE_F64) sum to the fp64 run's gradient far
+  below what fp32 atomics in arbitrary order reach."""
+  g = golden('g7_errors')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  G = int(g['G'])
+  rs = np.random.RandomState(11)
+  base = O.circles_sdf(G, g['circles'])
+  sdf = np.stack([base + 0.05 * rs.randn(G, G) for _ in range(B)])[:, None]      # B distinct grids
+  th, st, go, sdf = rnd(g['th'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io)
+  qc, ow, eps = rnd(g['qc'], io), rnd(g['ow'].reshape(B, n), io), rnd(g['eps'].reshape(B, n), io)
+  cs, cg, co, ce = rnd(g['c_sg'], io).reshape(B), rnd(g['c_gp'], io).reshape(B), rnd(g['c_obs'], io).reshape(B), rnd(g['c_ee'], io).reshape(B)
+  gd = rnd(rs.randn(B, n, 4), io)
+  tol = 1e-12 if io == 'f64' else 2e-6      # (the same fp32 / fp64 summands; only the order of a pixel's few additions differs)
+  dth = be.step(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)[0]
+  d = be.backward(p, th, st, go, sdf, dth, gd, ce, qc=qc, ow=ow, eps=eps, io=io)
+  s = be.backward(p, th, st, go, sdf, dth, gd, ce, qc=qc, ow=ow, eps=eps, io=io, sdf_grad='sparse')
+  assert np.abs(d['sdf']).max() > 0 and s['sdf'].shape == d['sdf'].shape and rel_err(s['sdf'], d['sdf']) < tol
+  for k in ('th', 'start', 'goal', 'qc', 'ow', 'eps'): assert np.array_equal(s[k], d[k]), k
+  # static covariances (the Woodbury / static backward kernels)
+  dth0 = be.step(p, th, st, go, sdf, io=io)[0]
+  d0 = be.backward(p, th, st, go, sdf, dth0, gd, None, io=io)
+  s0 = be.backward(p, th, st, go, sdf, dth0, gd, None, io=io, sdf_grad='sparse')
+  assert rel_err(s0['sdf'], d0['sdf']) < tol and np.array_equal(s0['th'], d0['th'])
+  # the training iteration: taps at th + dtheta and at th
+  d2 = be.step_errors_backward(p, th, st, go, sdf, dth, gd, ce, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io)
+  s2 = be.step_errors_backward(p, th, st, go, sdf, dth, gd, ce, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io, sdf_grad='sparse')
+  assert rel_err(s2['sdf'], d2['sdf']) < tol and rel_err(s2['th'], d2['th']) < tol
+  s3 = be.step_errors_backward(p, th, st, go, sdf, dth, gd, ce, None, None, None, qc=qc, ow=ow, eps=eps, io=io, sdf_grad='sparse')      # no error cotangent: one block
+  assert rel_err(s3['sdf'], d['sdf']) < tol
+  # the errors' backward on its own
+  d4 = be.eval_backward(p, th, st, go, sdf, ce, cs, cg, co, eps=eps, io=io)
+  s4 = be.eval_backward(p, th, st, go, sdf, ce, cs, cg, co, eps=eps, io=io, sdf_grad='sparse')
+  assert rel_err(s4['sdf'], d4['sdf']) < tol
+  # the fused loop: one tap block per iteration (the g8 problem: trajectories that stop after 2, 8, 9, 9 iterations -- early stoppers leave their later blocks zero)
+  g8 = golden('g8_forward_grads')
+  B8, n8, G8 = g8['th0'].shape[0], g8['th0'].shape[1], int(g8['G'])
+  p8 = P2d(n8)
+  K8 = int(g8['max_iters'])
+  sdf8 = np.broadcast_to(O.circles_sdf(G8, g8['circles']), (B8, 1, G8, G8)).copy()
+  sdf8[int(g8['free_sample'])] = float(g8['free_value'])
+  th8, st8, go8, sdf8, gb8 = rnd(g8['th0'], io), rnd(g8['start'], io), rnd(g8['goal'], io), rnd(sdf8, io), rnd(g8['gbar'], io)
+  tho, its, hist, info = be.solve_traced(p8, th8, st8, go8, sdf8, K8, float(g8['tol_delta']), io=io)
+  assert its.min() < its.max()
+  d5 = be.solve_backward(p8, st8, go8, sdf8, K8, hist, tho, its, gb8, io=io)
+  s5 = be.solve_backward(p8, st8, go8, sdf8, K8, hist, tho, its, gb8, io=io, sdf_grad='sparse')
+  assert np.abs(d5['sdf']).max() > 0 and rel_err(s5['sdf'], d5['sdf']) < (1e-11 if io == 'f64' else 1e-5) and rel_err(s5['th'], d5['th']) < tol
+  # shared grid: double partial copies whatever the I/O type
+  sh = sdf[:1]
+  dthS = be.step(p, th, st, go, sh, qc=qc, ow=ow, eps=eps, io=io)[0]
+  ref = be.backward(p, th, st, go, sh, dthS, gd, ce, qc=qc, ow=ow, eps=eps, io=io)
+  w = be.backward(p, th, st, go, sh, dthS, gd, ce, qc=qc, ow=ow, eps=eps, io=io, sdf_copies=16, sdf_grad='f64')
+  assert w['sdf'].shape[0] == 16 and rel_err(w['sdf'].sum(0, keepdims=True), ref['sdf']) < (1e-11 if io == 'f64' else 2e-5)
+  if io == 'f32':
+    # the fp32 summands added in double: independent of the order -- two runs agree to the last bit of a double sum of a few hundred floats
+    w2 = be.backward(p, th, st, go, sh, dthS, gd, ce, qc=qc, ow=ow, eps=eps, io=io, sdf_copies=16, sdf_grad='f64')
+    assert rel_err(w2['sdf'].sum(0), w['sdf'].sum(0)) < 1e-13
+
+
+ALL_CASES.append(case_sdf_gradient_delivery)
+
+
 def case_long_trajectories(be, golden, io, configs=None):
   """n > 256 (gn_long.h: one trajectory per wavefront, ceil(n / 64) rows per lane in a loop, interior state parked in LDS): the reference
   accepts any total_time_step (plan_layer.py:30).  Every entry point -- step, the fused loop, the error evaluation, both backward kernels --
