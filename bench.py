@@ -492,6 +492,11 @@ def planner_api_backward_rate(device, reps=200):
     dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(thr, start, goal, None, sdfb, qc_s, ow_s, None)
     torch.autograd.grad((dth, sg, gp_, ob), (thr, lm_out), (g, cws, cw, cw))
 
+  def train_iteration_diag_identity_raw():      # round 5: the module output goes to the kernels as it is (DGP_COVS_SQUARED) -- what planner.step_with_errors() does in this mode
+    raw = planner.plan_layer.raw_covs(lm_out, 'diag_identity', False)
+    dth, _, _, sg, gp_, ob = planner.plan_layer.forward_raw(thr, start, goal, None, sdfb, raw, with_errors=True)[:6]
+    torch.autograd.grad((dth, sg, gp_, ob), (thr, lm_out), (g, cws, cw, cw))
+
   # planner.forward with the graph kept (examples/diff_gpmp2_2d_example.py:77): 10 GN iterations + the backward pass through all of them, two launches
   sdf_leaf = sdf.clone().requires_grad_(True)
   planner.optim_params['tol_delta'] = 0.0            # all 10 iterations, as the fused_forward block
@@ -529,9 +534,12 @@ def planner_api_backward_rate(device, reps=200):
   a, b = wall(static_fb), wall(learned_fb)
   t2, t1 = wall(train_iteration_two_calls), wall(train_iteration_fused)
   tdi = wall(train_iteration_diag_identity)
+  tdr = wall(train_iteration_diag_identity_raw)
+  gdr = None
   try:
     ga, gt1, gk = wall(graphed(static_fb)), wall(graphed(train_iteration_fused)), wall(graphed(tbptt_fb)) / 10.0
     gdi = wall(graphed(train_iteration_diag_identity)); gdl = wall(graphed(train_iteration_diag_identity_layer_only))
+    gdr = wall(graphed(train_iteration_diag_identity_raw))
   except Exception as e:      # noqa: BLE001  (measurement extra: a torch build without graph capture must not cost the bench line)
     print('bench: HIP-graph capture of the training iteration failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
     ga = gt1 = gk = gdi = gdl = None
@@ -545,9 +553,11 @@ def planner_api_backward_rate(device, reps=200):
                                        'tests/test_planner_api.py)'},
           'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1, 'step_with_errors_hip_graph_replay_us': gt1,
                                   'diag_identity_mode': {'step_with_errors_us': tdi, 'hip_graph_replay_us': gdi, 'layer_only_hip_graph_replay_us': gdl,
+                                                         'raw_module_output_us': tdr, 'raw_module_output_hip_graph_replay_us': gdr,
                                                          'note': "the reference's default learned mode: get_covariances(out, 'diag_identity') -> one scalar per GP factor -> DGP_QC_SCALAR "
                                                                  '(scaled-mask static kernels, forward and backward).  get_covariances and its backward -- a dozen small torch kernels: slices, q q^T, x I -- are inside the first two '
-                                                                 'figures and cost more than the solver; layer_only: the tagged blocks as leaves'},
+                                                                 'figures and cost more than the solver; layer_only: the tagged blocks as leaves; raw_module_output (round 5, what planner.step_with_errors() runs in this mode): the output vector '
+                                                                 'itself is the kernels\' covariance input (DGP_COVS_SQUARED: squared in-kernel, d/d out written by the backward kernel) -- covariance construction included'},
                                   'note': 'learned covariances (per-state qc_inv / obscov_inv / eps that require grad): step + unweighted errors at th + dtheta + '
                                           'backward of a loss on all four outputs w.r.t. all four inputs, wall per iteration -- PlanLayer.forward + '
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '
@@ -668,8 +678,12 @@ def main():
   if args.gpus > 1 and world != args.gpus:
     raise SystemExit('--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, args.gpus))
   assert torch.cuda.is_available(), 'bench.py needs a GPU (the product path has no CPU fallback)'
-  torch.cuda.set_device(local_rank)
-  device = torch.device('cuda', local_rank)
+  # DGP_BENCH_ONE_DEVICE=1 (with DGP_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): every rank on cuda:0 -- a world of N > 1 ranks on a ONE-GPU
+  # box, to execute the N > 1 branch (barriers, all-gather, max-over-ranks) end to end; a smoke configuration, its numbers mean nothing
+  one_device = os.environ.get('DGP_BENCH_ONE_DEVICE') == '1'
+  dev_index = 0 if one_device else local_rank
+  torch.cuda.set_device(dev_index)
+  device = torch.device('cuda', dev_index)
   dist = None
   # one process per GPU under torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment).  A world of ONE rank launched
   # that way (torchrun --nproc-per-node 1, or DGP_BENCH_FORCE_DIST=1) takes the same RCCL branch -- process group, barriers, the
@@ -680,7 +694,9 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    backend = os.environ.get('DGP_BENCH_BACKEND', 'nccl')      # ('nccl' IS RCCL on ROCm; 'gloo' only for the one-device smoke configuration above)
+    if backend == 'nccl': dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+    else: dist.init_process_group(backend, rank=rank, world_size=world)
 
   import __graft_entry__
   if rank == 0: __graft_entry__.build()
@@ -715,7 +731,7 @@ def main():
   sdf_ptr = sdf.data_ptr()
 
   def step(k):
-    rc = pc.gn_step(hnd, B, th_ptrs[k % GN_ITERS], sp, gp, sdf_ptr, GRID, GRID, 0, 0, 0, None, 0, None, None, None, 0, 0, None, None, None, dp, ep, xp, ip, raw_stream)
+    rc = pc.gn_step(hnd, B, th_ptrs[k % GN_ITERS], sp, gp, sdf_ptr, GRID, GRID, 0, 0, 0, None, 0, None, None, None, dp, ep, xp, ip, raw_stream)
     if rc: solver.api.check(rc)
 
   prewarm_s = prewarm(step)
@@ -741,17 +757,17 @@ def main():
   cur_stream = torch.cuda.current_stream()
   gathered = None
 
-  def region(ev=None):
+  def region(ev=None, steps=None, gather=True):
     """One timed region; `ev` = (begin, end) HIP events recorded around the launches (only in the extra span regions below: two event
-    records cost a 20-launch region ~13 us, profiles/r04_region_parts.txt)."""
+    records cost a 20-launch region ~13 us, profiles/r04_region_parts.txt).  steps / gather: the diagnostic regions of an N > 1 run (below)."""
     nonlocal gathered
     if dist is not None:
       torch.cuda.synchronize(); dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if ev: ev[0].record()
-    for k in range(K): step(k)
-    if dist is not None:      # collect the final trajectories -- the only collective of the path -- through the product's helper; it is stream-ordered
+    for k in range(K if steps is None else steps): step(k)
+    if dist is not None and gather:      # collect the final trajectories -- the only collective of the path -- through the product's helper; it is stream-ordered
       gathered = parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)      # behind the K launches and cannot complete before every rank has contributed
     if ev: ev[1].record()
     while not cur_stream.query(): pass              # spin until the stream has drained: synchronize() then returns at once, not after an interrupt wake-up
@@ -771,6 +787,16 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)        # every region: the slowest rank's clock
     walls = t.cpu().numpy()
   elapsed = float(np.median(walls))
+  # N > 1 diagnostics (so that a --steps 20 scaling run can be read: the all-gather + its wait are a constant of 25-55 us, 20 % of such a region and 0.1 % of a
+  # 5000-step one): the same regions WITHOUT the gather, and ONE long region (5000 steps + the gather), both max over ranks
+  steps_only = long_region = None
+  if dist is not None:
+    w0 = torch.tensor([region(gather=False) for _ in range(R)], dtype=torch.float64, device=device)
+    dist.all_reduce(w0, op=dist.ReduceOp.MAX)
+    steps_only = float(np.median(w0.cpu().numpy()))
+    w1 = torch.tensor([region(steps=5000)], dtype=torch.float64, device=device)
+    dist.all_reduce(w1, op=dist.ReduceOp.MAX)
+    long_region = float(w1.item())
   q = lambda v, f: float(np.percentile(v, f))
   regions = {'count': R, 'steps_per_region': K,
              'ms_per_step': {'min': float(walls.min()) * 1e3 / K, 'p25': q(walls, 25) * 1e3 / K, 'median': elapsed * 1e3 / K, 'p75': q(walls, 75) * 1e3 / K,
@@ -839,6 +865,12 @@ def main():
     }
     out['roofline']['kernel_isolated_avg_ms'] = kernel_ms                # per-launch begin / end events, launches dispatched one by one
     out['roofline']['region_span_ms_per_launch'] = region_span_ms      # events around one K-launch region / K (median region): start-up and gaps included
+    if steps_only is not None:
+      out['value_steps_only'] = world * args.steps / steps_only      # the same K-launch regions without the all-gather (median, max over ranks)
+      out['steps_per_s_at_5000'] = world * 5000 / long_region         # one region of 5000 launches + the all-gather: the fixed cost amortised
+      out['scaling_note'] = ('value = K / median region INCLUDING one all-gather of the final trajectories and the wait for it (region_fixed_us, a constant); '
+                             'value_steps_only = the same regions without it; steps_per_s_at_5000 = one 5000-launch region with it -- at --steps 20 the constant is '
+                             '~20 %% of a region, so per-N efficiency is better read from the last two')
     if region_fixed_us is not None:
       out['region_fixed_us'] = region_fixed_us
       out['region_fixed_note'] = ('one all-gather of the final trajectories + the wait for it, timed on its own (median of 20): the part of an N > 1 region '

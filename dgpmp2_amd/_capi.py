@@ -19,7 +19,6 @@ DGP_FLAG_NONHOLONOMIC, DGP_FLAG_VEL_LIMITS = 1, 2
 DGP_QC_STATIC, DGP_QC_PERSTATE, DGP_QC_QFULL, DGP_QC_SCALAR = 0, 1, 2, 3
 DGP_SDF_ROWMAJOR, DGP_SDF_TILED4 = 0, 1
 DGP_GSDF_DENSE, DGP_GSDF_DENSE_F64, DGP_GSDF_SPARSE = 0, 1, 2
-DGP_COVS_SQUARED = 1
 DGP_ABI_VERSION = 6
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -41,8 +40,7 @@ class DgpSdf(C.Structure):
 
 
 class DgpCovs(C.Structure):
-  _fields_ = [('qc_mode', C.c_int32), ('qc_inv', C.c_void_p), ('obs_w', C.c_void_p), ('eps', C.c_void_p), ('flags', C.c_uint32), ('pad_', C.c_int32),
-              ('row_stride', C.c_int64), ('sq_qc_inv', C.c_void_p), ('sq_obs_w', C.c_void_p), ('sq_eps', C.c_void_p)]
+  _fields_ = [('qc_mode', C.c_int32), ('qc_inv', C.c_void_p), ('obs_w', C.c_void_p), ('eps', C.c_void_p)]
 
 
 class DgpError(RuntimeError):
@@ -56,7 +54,7 @@ class CApi(object):
 
   SYMBOLS = ('abi_version', 'last_error', 'create', 'destroy', 'num_factor_rows', 'launch_shape', 'step_kernel_variant', 'gn_step', 'gn_solve',
              'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward', 'gn_step_errors',
-             'gn_step_errors_backward', 'sum_partial_grids', 'sdf_2d_workspace_bytes', 'sdf_2d', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
+             'gn_step_errors_backward', 'sum_partial_grids', 'square_covariances', 'square_covariances_backward', 'sdf_2d_workspace_bytes', 'sdf_2d', 'time_next_launch', 'event_create', 'event_destroy', 'event_elapsed_ms')
 
   def __init__(self, path, prefix='dgp_'):
     if not os.path.exists(path):
@@ -96,6 +94,10 @@ class CApi(object):
                                              i32, vp, vp, vp, vp, vp]
     self.sum_partial_grids = f('sum_partial_grids'); self.sum_partial_grids.restype = C.c_int
     self.sum_partial_grids.argtypes = [vp, i32, i32, i64, dbl, vp, i32, vp]
+    self.square_covariances = f('square_covariances'); self.square_covariances.restype = C.c_int
+    self.square_covariances.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    self.square_covariances_backward = f('square_covariances_backward'); self.square_covariances_backward.restype = C.c_int
+    self.square_covariances_backward.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     self.sdf_2d_workspace_bytes = f('sdf_2d_workspace_bytes'); self.sdf_2d_workspace_bytes.restype = C.c_size_t
     self.sdf_2d_workspace_bytes.argtypes = [i32, i32, i32, i32]
     self.sdf_2d = f('sdf_2d'); self.sdf_2d.restype = C.c_int
@@ -158,7 +160,7 @@ import sysconfig
 # never loaded by mistake
 PYCALL_PATH = os.path.join(_HERE, 'lib', '_dgp_pycall' + (sysconfig.get_config_var('EXT_SUFFIX') or '.so'))
 _PYCALL_ENTRIES = ('gn_step', 'gn_solve', 'eval_errors', 'gn_step_backward', 'eval_errors_backward', 'gn_solve_traced', 'gn_solve_backward',
-                   'gn_step_errors', 'gn_step_errors_backward', 'sum_partial_grids')
+                   'gn_step_errors', 'gn_step_errors_backward', 'sum_partial_grids', 'square_covariances', 'square_covariances_backward')
 
 
 def get_api():
@@ -171,7 +173,7 @@ def get_api():
 
 class CtypesPycall(object):
   """Drop-in for the trampoline module, on the plain ctypes binding: the same positional signatures (addresses as ints / None, the two
-  structs flattened into their seven + nine fields), 3-5 us slower per call.  Used when the trampoline has not been built or does not load
+  structs flattened into their seven + four fields), 3-5 us slower per call.  Used when the trampoline has not been built or does not load
   (no Python.h on the build host, another interpreter): the product path is then still the C-ABI, only the marshalling is slower."""
 
   def __init__(self, api):
@@ -183,10 +185,10 @@ class CtypesPycall(object):
 
   @staticmethod
   def _covs(a, i):
-    return C.byref(DgpCovs(int(a[i]), a[i + 1], a[i + 2], a[i + 3], int(a[i + 4]), 0, int(a[i + 5]), a[i + 6], a[i + 7], a[i + 8]))
+    return C.byref(DgpCovs(int(a[i]), a[i + 1], a[i + 2], a[i + 3]))
 
   def _prefixed(self, fn, a):
-    return fn(a[0], a[1], a[2], a[3], a[4], self._sdf(a, 5), self._covs(a, 12), *a[21:])
+    return fn(a[0], a[1], a[2], a[3], a[4], self._sdf(a, 5), self._covs(a, 12), *a[16:])
 
   def gn_step(self, *a): return self._prefixed(self.api.gn_step, a)
   def gn_solve(self, *a): return self._prefixed(self.api.gn_solve, a)
@@ -201,6 +203,8 @@ class CtypesPycall(object):
     return self.api.gn_solve_backward(a[0], a[1], a[2], a[3], self._sdf(a, 4), *a[11:])
 
   def sum_partial_grids(self, *a): return self.api.sum_partial_grids(*a)
+  def square_covariances(self, *a): return self.api.square_covariances(*a)
+  def square_covariances_backward(self, *a): return self.api.square_covariances_backward(*a)
 
 
 def get_pycall():
@@ -287,8 +291,8 @@ class Solver(object):
     return DgpSdf(ptr, int(rows), int(cols), int(batch_stride), int(layout), int(grad_mode), grad_indices)
 
   @staticmethod
-  def covs_arg(qc_mode=DGP_QC_STATIC, qc_inv=None, obs_w=None, eps=None, flags=0, row_stride=0, sq_qc_inv=None, sq_obs_w=None, sq_eps=None):
-    return DgpCovs(int(qc_mode), qc_inv, obs_w, eps, int(flags), 0, int(row_stride), sq_qc_inv, sq_obs_w, sq_eps)
+  def covs_arg(qc_mode=DGP_QC_STATIC, qc_inv=None, obs_w=None, eps=None):
+    return DgpCovs(int(qc_mode), qc_inv, obs_w, eps)
 
   def gn_step(self, batch, th, start, goal, sdf, covs, dtheta, err=None, err_ext=None, info=None, stream=None):
     self.api.check(self.api.gn_step(self.handle, batch, th, start, goal, C.byref(sdf), C.byref(covs) if covs is not None else None,

@@ -237,7 +237,6 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   p.vec_mu = (aligned16(start) && aligned16(goal)) ? 1 : 0;
   if (covs) {
     if (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);
-    if (covs->flags != 0 || covs->row_stride != 0) return fail(DGP_EUNSUPPORTED, "DgpCovs::flags / row_stride are not implemented");
     if (covs->qc_mode == DGP_QC_SCALAR && !scalar_qc_ok)
       return fail(DGP_EUNSUPPORTED, "qc_mode DGP_QC_SCALAR is implemented by dgp_gn_step[_errors] and their backward only (pass the (B,n-1,dof,dof) tensors elsewhere)");
     if (covs->qc_mode == DGP_QC_SCALAR && h->base.qc_diag == 0)
@@ -289,6 +288,7 @@ inline int fill_eval(const DgpHandle* h, int32_t batch, const void* th, const vo
 // fields of GnGradParams that only the round-4 entry points set
 inline void clear_extensions(dgp::GnGradParams& g) {
   g.accumulate = 0; g.g_th_new = nullptr; g.th_addend = nullptr; g.th_hist = nullptr; g.th_final = nullptr; g.iters = nullptr; g.chain_iters = 0; g.g_sdf_mode = dgp::GSDF_DENSE; g.g_sdf_idx = nullptr; g.g_sdf_passes = 1; g.g_sdf_pass0 = 0;
+  g.f_unw_sg = g.f_unw_gp = g.f_unw_obs = nullptr; g.f_addend = nullptr;
 }
 
 // the destination of dL/d(sdf): validation shared by the four backward entry points (call after clear_extensions)
@@ -343,7 +343,7 @@ inline int fill_eval_backward(const DgpHandle* h, int32_t batch, const void* th,
   const bool no_grid = !sdf || !sdf->data;
   if (no_grid && (g_err_ext || g_unw_obs || g_sdf))
     return fail(DGP_EINVAL, "sdf may be NULL only when g_err_ext, g_unw_obs and g_sdf (what reads / writes the grid) are NULL");
-  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr, 0u, 0, 0, nullptr, nullptr, nullptr};
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
   if (covs && (covs->qc_mode < DGP_QC_STATIC || covs->qc_mode > DGP_QC_SCALAR)) return fail(DGP_EINVAL, "bad qc_mode %d", covs->qc_mode);      // (whatever the mode: only eps is read)
   int rc = fill_call(h, batch, th, start, goal, sdf, &c, p, /*sdf_optional=*/true);
   if (rc != DGP_OK) return rc;
@@ -423,7 +423,7 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   rc = launch(dgp::MODE_STEP, p, (const dgp::GnGradParams*)nullptr);
   if (rc != DGP_OK || !errs) return rc;
   // the unweighted errors at th + dtheta: the error kernel with dtheta as addend, stream-ordered behind the step (only eps of the covariances enters them)
-  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr, 0u, 0, 0, nullptr, nullptr, nullptr};
+  DgpCovs c = {DGP_QC_STATIC, nullptr, nullptr, covs ? covs->eps : nullptr};
   rc = fill_eval(h, batch, th, start, goal, sdf, &c, nullptr, nullptr, unw_sg, unw_gp, unw_obs, p);
   if (rc != DGP_OK) return rc;
   p.dtheta = dtheta;               // MODE_EVAL: the addend (gn_lane.h)
@@ -439,13 +439,27 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
   dgp::GnParams p;
   dgp::GnGradParams g;
   const bool errs = g_unw_sg || g_unw_gp || g_unw_obs;
+  if (errs && !dtheta) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs dtheta when an unweighted-error cotangent is given");
+  if (errs && !is_long(h ? h->cfg.num_states : 0)) {
+    // ONE launch (round 5): the errors' backward at th + dtheta runs as a prologue of the step's backward kernel (gn_backward.h: unweighted_errors_prologue) and hands
+    // its trajectory gradient over in g_th itself (or in the workspace when g_th is not wanted)
+    void* buf = g_th ? g_th : workspace;
+    if (!buf) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs g_th or a (B,n,d) workspace when an unweighted-error cotangent is given");
+    int rc = fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
+                           g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
+    if (rc != DGP_OK) return rc;
+    g.f_unw_sg = g_unw_sg; g.f_unw_gp = g_unw_gp; g.f_unw_obs = g_unw_obs; g.f_addend = dtheta;
+    g.g_th_new = buf; g.accumulate = 1; g.g_sdf_passes = 2;
+    p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(buf)) ? 1 : 0;
+    return launch((int)kModeBackward, p, &g);
+  }
   if (errs) {
-    if (!workspace || !dtheta) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs dtheta and a (B,n,d) workspace when an unweighted-error cotangent is given");
+    // long trajectories (the loop kernels of gn_long.h): two launches, as in round 4
+    if (!workspace) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs a (B,n,d) workspace for num_states > 256");
     // launch 1: backward of the unweighted errors at th + dtheta -> workspace (gradient w.r.t. th + dtheta), start / goal / eps / grid shares
     int rc = fill_eval_backward(h, batch, th, start, goal, sdf, covs, nullptr, g_unw_sg, g_unw_gp, g_unw_obs, workspace, g_start, g_goal, g_sdf,
                                 g_sdf_batch_stride, g_sdf_copies, nullptr, p, g);
     if (rc != DGP_OK) return rc;
-    if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors_backward is not implemented for num_states > 256");
     g.g_eps = g_eps;                // (written by BOTH launches whatever the epsilon source: launch 2 adds to what this one stores)
     g.th_addend = dtheta;
     g.g_sdf_passes = 2; g.g_sdf_pass0 = 1;      // DGP_GSDF_SPARSE: the taps at th + dtheta are the second block
@@ -453,7 +467,7 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
     rc = launch((int)kModeBackward, p, &g);
     if (rc != DGP_OK) return rc;
   }
-  // launch 2 (the only one without error cotangents): backward of the step; with launch 1 in front, the workspace joins the dtheta cotangent and g_th,
+  // the step's backward (the only launch without error cotangents); behind launch 1 the workspace joins the dtheta cotangent and g_th,
   // and the small gradients are added to launch 1's
   int rc = fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
                          g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);

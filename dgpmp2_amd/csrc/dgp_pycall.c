@@ -36,6 +36,10 @@ typedef int (*gn_step_errors_backward_fn)(const DgpHandle*, int32_t, const void*
                                           const void*, const void*, const void*, const void*, const void*, void*, void*, void*, void*, int64_t, int32_t,
                                           void*, void*, void*, void*, void*);
 
+typedef int (*square_covs_fn)(const void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, void*, void*, void*, void*, void*);
+typedef int (*square_covs_bwd_fn)(const void*, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t, const void*, const void*, const void*, void*, void*);
+static square_covs_fn f_square_covs;
+static square_covs_bwd_fn f_square_covs_bwd;
 typedef int (*sum_partial_grids_fn)(const void*, int32_t, int32_t, int64_t, double, void*, int32_t, void*);
 static sum_partial_grids_fn f_sum_partial_grids;
 static gn_step_fn f_gn_step;
@@ -71,19 +75,19 @@ static inline int64_t as_i64(PyObject* o, int* bad) {
 #define I(i) as_i64(a[i], &bad)
 
 /* common prefix of every entry point: handle, batch, th, start, goal, the seven fields of DgpSdf (data, rows, cols, batch_stride, layout, grad_mode,
- * grad_indices), the nine of DgpCovs (qc_mode, qc_inv, obs_w, eps, flags, row_stride, sq_qc_inv, sq_obs_w, sq_eps) -- 21 arguments.
+ * grad_indices), the four of DgpCovs (qc_mode, qc_inv, obs_w, eps) -- 16 arguments.
  * sdf_data None/0 -> a NULL DgpSdf* (only dgp_eval_errors[_backward] accept that). */
-#define PREFIX 21
+#define PREFIX 16
 #define BUILD_PREFIX                                                                                        \
   const DgpHandle* h = (const DgpHandle*)P(0);                                                              \
   const int32_t batch = (int32_t)I(1);                                                                      \
   const void *th = P(2), *start = P(3), *goal = P(4);                                                       \
   DgpSdf sdf = {P(5), (int32_t)I(6), (int32_t)I(7), I(8), (int32_t)I(9), (int32_t)I(10), (int64_t*)P(11)};  \
-  DgpCovs covs = {(int32_t)I(12), P(13), P(14), P(15), (uint32_t)I(16), 0, I(17), P(18), P(19), P(20)};     \
+  DgpCovs covs = {(int32_t)I(12), P(13), P(14), P(15)};                                                     \
   const DgpSdf* sdfp = sdf.data ? &sdf : NULL
 
 static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
-  NEED(10, "bind");
+  NEED(12, "bind");
   f_gn_step = (gn_step_fn)P(0);
   f_gn_solve = (gn_solve_fn)P(1);
   f_eval_errors = (eval_errors_fn)P(2);
@@ -94,6 +98,8 @@ static PyObject* py_bind(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
   f_gn_step_errors = (gn_step_errors_fn)P(7);
   f_gn_step_errors_backward = (gn_step_errors_backward_fn)P(8);
   f_sum_partial_grids = (sum_partial_grids_fn)P(9);
+  f_square_covs = (square_covs_fn)P(10);
+  f_square_covs_bwd = (square_covs_bwd_fn)P(11);
   if (bad) return NULL;
   Py_RETURN_NONE;
 }
@@ -106,7 +112,7 @@ static PyObject* py_gn_step(PyObject* self, PyObject* const* a, Py_ssize_t nargs
   NEED(PREFIX + 5, "gn_step");
   BOUND(f_gn_step);
   BUILD_PREFIX;
-  void *dth = P(21), *err = P(22), *eex = P(23), *info = P(24), *stream = P(25);
+  void *dth = P(16), *err = P(17), *eex = P(18), *info = P(19), *stream = P(20);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, stream));
 }
@@ -116,10 +122,10 @@ static PyObject* py_gn_solve(PyObject* self, PyObject* const* a, Py_ssize_t narg
   NEED(PREFIX + 9, "gn_solve");
   BOUND(f_gn_solve);
   BUILD_PREFIX;
-  const int32_t max_iters = (int32_t)I(21);
-  const double tol = PyFloat_AsDouble(a[22]);
+  const int32_t max_iters = (int32_t)I(16);
+  const double tol = PyFloat_AsDouble(a[17]);
   if (tol == -1.0 && PyErr_Occurred()) return NULL;
-  void *th_out = P(23), *iters = P(24), *eh = P(25), *eeh = P(26), *ef = P(27), *info = P(28), *stream = P(29);
+  void *th_out = P(18), *iters = P(19), *eh = P(20), *eeh = P(21), *ef = P(22), *info = P(23), *stream = P(24);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_solve(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info, stream));
 }
@@ -129,7 +135,7 @@ static PyObject* py_eval_errors(PyObject* self, PyObject* const* a, Py_ssize_t n
   NEED(PREFIX + 6, "eval_errors");
   BOUND(f_eval_errors);
   BUILD_PREFIX;
-  void *err = P(21), *eex = P(22), *usg = P(23), *ugp = P(24), *uobs = P(25), *stream = P(26);
+  void *err = P(16), *eex = P(17), *usg = P(18), *ugp = P(19), *uobs = P(20), *stream = P(21);
   if (bad) return NULL;
   return PyLong_FromLong(f_eval_errors(h, batch, th, start, goal, sdfp, &covs, err, eex, usg, ugp, uobs, stream));
 }
@@ -139,11 +145,11 @@ static PyObject* py_gn_step_backward(PyObject* self, PyObject* const* a, Py_ssiz
   NEED(PREFIX + 13, "gn_step_backward");
   BOUND(f_gn_step_backward);
   BUILD_PREFIX;
-  const void *dth = P(21), *g_dth = P(22), *g_eex = P(23);
-  void *g_th = P(24), *g_st = P(25), *g_go = P(26), *g_sdf = P(27);
-  const int64_t g_stride = I(28);
-  const int32_t copies = (int32_t)I(29);
-  void *g_qc = P(30), *g_ow = P(31), *g_eps = P(32), *stream = P(33);
+  const void *dth = P(16), *g_dth = P(17), *g_eex = P(18);
+  void *g_th = P(19), *g_st = P(20), *g_go = P(21), *g_sdf = P(22);
+  const int64_t g_stride = I(23);
+  const int32_t copies = (int32_t)I(24);
+  void *g_qc = P(25), *g_ow = P(26), *g_eps = P(27), *stream = P(28);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_th, g_st, g_go, g_sdf, g_stride, copies,
                                             g_qc, g_ow, g_eps, stream));
@@ -154,11 +160,11 @@ static PyObject* py_eval_errors_backward(PyObject* self, PyObject* const* a, Py_
   NEED(PREFIX + 12, "eval_errors_backward");
   BOUND(f_eval_errors_backward);
   BUILD_PREFIX;
-  const void *g_eex = P(21), *g_usg = P(22), *g_ugp = P(23), *g_uobs = P(24);
-  void *g_th = P(25), *g_st = P(26), *g_go = P(27), *g_sdf = P(28);
-  const int64_t g_stride = I(29);
-  const int32_t copies = (int32_t)I(30);
-  void *g_eps = P(31), *stream = P(32);
+  const void *g_eex = P(16), *g_usg = P(17), *g_ugp = P(18), *g_uobs = P(19);
+  void *g_th = P(20), *g_st = P(21), *g_go = P(22), *g_sdf = P(23);
+  const int64_t g_stride = I(24);
+  const int32_t copies = (int32_t)I(25);
+  void *g_eps = P(26), *stream = P(27);
   if (bad) return NULL;
   return PyLong_FromLong(f_eval_errors_backward(h, batch, th, start, goal, sdfp, &covs, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf, g_stride,
                                                 copies, g_eps, stream));
@@ -169,10 +175,10 @@ static PyObject* py_gn_solve_traced(PyObject* self, PyObject* const* a, Py_ssize
   NEED(PREFIX + 10, "gn_solve_traced");
   BOUND(f_gn_solve_traced);
   BUILD_PREFIX;
-  const int32_t max_iters = (int32_t)I(21);
-  const double tol = PyFloat_AsDouble(a[22]);
+  const int32_t max_iters = (int32_t)I(16);
+  const double tol = PyFloat_AsDouble(a[17]);
   if (tol == -1.0 && PyErr_Occurred()) return NULL;
-  void *th_out = P(23), *iters = P(24), *eh = P(25), *eeh = P(26), *ef = P(27), *info = P(28), *hist = P(29), *stream = P(30);
+  void *th_out = P(18), *iters = P(19), *eh = P(20), *eeh = P(21), *ef = P(22), *info = P(23), *hist = P(24), *stream = P(25);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_solve_traced(h, batch, th, start, goal, sdfp, &covs, max_iters, tol, th_out, (int32_t*)iters, eh, eeh, ef, (int32_t*)info,
                                            (double*)hist, stream));
@@ -203,7 +209,7 @@ static PyObject* py_gn_step_errors(PyObject* self, PyObject* const* a, Py_ssize_
   NEED(PREFIX + 8, "gn_step_errors");
   BOUND(f_gn_step_errors);
   BUILD_PREFIX;
-  void *dth = P(21), *err = P(22), *eex = P(23), *info = P(24), *usg = P(25), *ugp = P(26), *uobs = P(27), *stream = P(28);
+  void *dth = P(16), *err = P(17), *eex = P(18), *info = P(19), *usg = P(20), *ugp = P(21), *uobs = P(22), *stream = P(23);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_errors(h, batch, th, start, goal, sdfp, &covs, dth, err, eex, (int32_t*)info, usg, ugp, uobs, stream));
 }
@@ -214,11 +220,11 @@ static PyObject* py_gn_step_errors_backward(PyObject* self, PyObject* const* a, 
   NEED(PREFIX + 17, "gn_step_errors_backward");
   BOUND(f_gn_step_errors_backward);
   BUILD_PREFIX;
-  const void *dth = P(21), *g_dth = P(22), *g_eex = P(23), *g_usg = P(24), *g_ugp = P(25), *g_uobs = P(26);
-  void *g_th = P(27), *g_st = P(28), *g_go = P(29), *g_sdf = P(30);
-  const int64_t g_stride = I(31);
-  const int32_t copies = (int32_t)I(32);
-  void *g_qc = P(33), *g_ow = P(34), *g_eps = P(35), *ws = P(36), *stream = P(37);
+  const void *dth = P(16), *g_dth = P(17), *g_eex = P(18), *g_usg = P(19), *g_ugp = P(20), *g_uobs = P(21);
+  void *g_th = P(22), *g_st = P(23), *g_go = P(24), *g_sdf = P(25);
+  const int64_t g_stride = I(26);
+  const int32_t copies = (int32_t)I(27);
+  void *g_qc = P(28), *g_ow = P(29), *g_eps = P(30), *ws = P(31), *stream = P(32);
   if (bad) return NULL;
   return PyLong_FromLong(f_gn_step_errors_backward(h, batch, th, start, goal, sdfp, &covs, dth, g_dth, g_eex, g_usg, g_ugp, g_uobs, g_th, g_st, g_go, g_sdf,
                                                    g_stride, copies, g_qc, g_ow, g_eps, ws, stream));
@@ -240,15 +246,40 @@ static PyObject* py_sum_partial_grids(PyObject* self, PyObject* const* a, Py_ssi
   return PyLong_FromLong(f_sum_partial_grids(part, pdt, copies, elems, scale, out, odt, stream));
 }
 
+/* square_covariances(raw, dtype, batch, width, n_gp, num_states, learn_eps, dof, sq_scalars, sq_qc_inv, sq_obs_w, sq_eps, stream) */
+static PyObject* py_square_covs(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(13, "square_covariances");
+  BOUND(f_square_covs);
+  const void* raw = P(0);
+  const int32_t dt = (int32_t)I(1), B = (int32_t)I(2), W = (int32_t)I(3), ngp = (int32_t)I(4), n = (int32_t)I(5), le = (int32_t)I(6), dof = (int32_t)I(7);
+  void *s = P(8), *blk = P(9), *ow = P(10), *ep = P(11), *stream = P(12);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_square_covs(raw, dt, B, W, ngp, n, le, dof, s, blk, ow, ep, stream));
+}
+
+/* square_covariances_backward(raw, dtype, batch, width, n_gp, num_states, learn_eps, dof, g_qc_inv, g_obs_w, g_eps, g_raw, stream) */
+static PyObject* py_square_covs_bwd(PyObject* self, PyObject* const* a, Py_ssize_t nargs) {
+  NEED(13, "square_covariances_backward");
+  BOUND(f_square_covs_bwd);
+  const void* raw = P(0);
+  const int32_t dt = (int32_t)I(1), B = (int32_t)I(2), W = (int32_t)I(3), ngp = (int32_t)I(4), n = (int32_t)I(5), le = (int32_t)I(6), dof = (int32_t)I(7);
+  const void *gq = P(8), *gw = P(9), *ge = P(10);
+  void *graw = P(11), *stream = P(12);
+  if (bad) return NULL;
+  return PyLong_FromLong(f_square_covs_bwd(raw, dt, B, W, ngp, n, le, dof, gq, gw, ge, graw, stream));
+}
+
 static PyMethodDef methods[] = {
     {"bind", (PyCFunction)(void (*)(void))py_bind, METH_FASTCALL,
-     "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward, gn_solve_traced, gn_solve_backward, gn_step_errors, gn_step_errors_backward, sum_partial_grids): "
+     "bind(gn_step, gn_solve, eval_errors, gn_step_backward, eval_errors_backward, gn_solve_traced, gn_solve_backward, gn_step_errors, gn_step_errors_backward, sum_partial_grids, square_covariances, square_covariances_backward): "
      "addresses of the C-ABI entry points"},
     {"gn_solve_traced", (PyCFunction)(void (*)(void))py_gn_solve_traced, METH_FASTCALL, "dgp_gn_solve_traced"},
     {"gn_solve_backward", (PyCFunction)(void (*)(void))py_gn_solve_backward, METH_FASTCALL, "dgp_gn_solve_backward"},
     {"gn_step_errors", (PyCFunction)(void (*)(void))py_gn_step_errors, METH_FASTCALL, "dgp_gn_step_errors"},
     {"gn_step_errors_backward", (PyCFunction)(void (*)(void))py_gn_step_errors_backward, METH_FASTCALL, "dgp_gn_step_errors_backward"},
     {"sum_partial_grids", (PyCFunction)(void (*)(void))py_sum_partial_grids, METH_FASTCALL, "dgp_sum_partial_grids"},
+    {"square_covariances", (PyCFunction)(void (*)(void))py_square_covs, METH_FASTCALL, "dgp_square_covariances"},
+    {"square_covariances_backward", (PyCFunction)(void (*)(void))py_square_covs_bwd, METH_FASTCALL, "dgp_square_covariances_backward"},
     {"gn_step", (PyCFunction)(void (*)(void))py_gn_step, METH_FASTCALL, "dgp_gn_step"},
     {"gn_solve", (PyCFunction)(void (*)(void))py_gn_solve, METH_FASTCALL, "dgp_gn_solve"},
     {"eval_errors", (PyCFunction)(void (*)(void))py_eval_errors, METH_FASTCALL, "dgp_eval_errors"},

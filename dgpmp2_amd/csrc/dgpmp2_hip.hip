@@ -41,9 +41,95 @@ __global__ void __launch_bounds__(256) sum_partial_grids_kernel(const TI* __rest
   }
 }
 
+// dgp_square_covariances[_backward]: one element of the module's output vector per lane and trip (rows of `width` values; consecutive lanes = consecutive columns)
+template <typename T>
+__global__ void __launch_bounds__(256) square_covs_kernel(const T* __restrict__ raw, int B, int W, int n_gp, int n, int learn_eps, int dof, T* __restrict__ s, T* __restrict__ blk,
+                                                          T* __restrict__ ow, T* __restrict__ ep) {
+  const int64_t total = (int64_t)B * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / W;
+    const int c = (int)(e - b * W);
+    const T v = raw[e];
+    const T q = v * v;                                 // in the I/O type, as torch's v * v
+    if (c < n_gp) {
+      if (s) s[b * n_gp + c] = q;
+      if (blk) {
+        T* o = blk + (b * n_gp + c) * dof * dof;
+        for (int i = 0; i < dof * dof; ++i) o[i] = (i % (dof + 1) == 0) ? q : (T)0;      // q * I, the 0 / 1 entries of the identity as exact values
+      }
+    } else if (c < n_gp + n) {
+      if (ow) ow[b * n + (c - n_gp)] = q;
+    } else if (learn_eps && c < n_gp + 2 * n) {
+      if (ep) ep[b * n + (c - n_gp - n)] = q;
+    }
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) square_covs_backward_kernel(const T* __restrict__ raw, int B, int W, int n_gp, int n, int learn_eps, int dof, const T* __restrict__ g_blk,
+                                                                   const T* __restrict__ g_ow, const T* __restrict__ g_ep, T* __restrict__ g_raw) {
+  const int64_t total = (int64_t)B * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / W;
+    const int c = (int)(e - b * W);
+    T g = (T)0;
+    if (c < n_gp) {
+      if (g_blk) {
+        const T* o = g_blk + (b * n_gp + c) * dof * dof;
+        for (int i = 0; i < dof; ++i) g += o[i * (dof + 1)];      // d (q I) / d q = I: the trace of the block's gradient
+      }
+    } else if (c < n_gp + n) {
+      if (g_ow) g = g_ow[b * n + (c - n_gp)];
+    } else if (learn_eps && c < n_gp + 2 * n) {
+      if (g_ep) g = g_ep[b * n + (c - n_gp - n)];
+    }
+    g_raw[e] = (T)2 * raw[e] * g;
+  }
+}
+
+int square_covs_check(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t n, int32_t learn_eps, int32_t dof) {
+  if (!raw) return fail(DGP_EINVAL, "dgp_square_covariances: null raw");
+  if (dtype != DGP_F32 && dtype != DGP_F64) return fail(DGP_EINVAL, "dgp_square_covariances: dtype %d", dtype);
+  if (batch < 1 || n < 2 || (n_gp != 0 && n_gp != n - 1) || (dof != 2 && dof != 3)) return fail(DGP_EINVAL, "dgp_square_covariances: batch >= 1, num_states >= 2, n_gp in {0, num_states - 1}, dof in {2, 3}");
+  if (width < n_gp + n * (learn_eps ? 2 : 1)) return fail(DGP_EINVAL, "dgp_square_covariances: width %d is less than the %d values the mode consumes", width, n_gp + n * (learn_eps ? 2 : 1));
+  return DGP_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int dgp_square_covariances(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t num_states, int32_t learn_eps, int32_t dof,
+                           void* sq_scalars, void* sq_qc_inv, void* sq_obs_w, void* sq_eps, void* stream) {
+  int rc = square_covs_check(raw, dtype, batch, width, n_gp, num_states, learn_eps, dof);
+  if (rc != DGP_OK) return rc;
+  const int64_t total = (int64_t)batch * width, blocks64 = (total + 255) / 256;
+  const dim3 grid((unsigned)(blocks64 > 4096 ? 4096 : blocks64)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DGP_F64) hipLaunchKernelGGL((square_covs_kernel<double>), grid, block, 0, s, (const double*)raw, batch, width, n_gp, num_states, learn_eps, dof, (double*)sq_scalars,
+                                           (double*)sq_qc_inv, (double*)sq_obs_w, (double*)sq_eps);
+  else hipLaunchKernelGGL((square_covs_kernel<float>), grid, block, 0, s, (const float*)raw, batch, width, n_gp, num_states, learn_eps, dof, (float*)sq_scalars, (float*)sq_qc_inv,
+                          (float*)sq_obs_w, (float*)sq_eps);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_square_covariances launch failed: %s", hipGetErrorString(e));
+  return DGP_OK;
+}
+
+int dgp_square_covariances_backward(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t num_states, int32_t learn_eps, int32_t dof,
+                                    const void* g_qc_inv, const void* g_obs_w, const void* g_eps, void* g_raw, void* stream) {
+  int rc = square_covs_check(raw, dtype, batch, width, n_gp, num_states, learn_eps, dof);
+  if (rc != DGP_OK) return rc;
+  if (!g_raw) return fail(DGP_EINVAL, "dgp_square_covariances_backward: null g_raw");
+  const int64_t total = (int64_t)batch * width, blocks64 = (total + 255) / 256;
+  const dim3 grid((unsigned)(blocks64 > 4096 ? 4096 : blocks64)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == DGP_F64) hipLaunchKernelGGL((square_covs_backward_kernel<double>), grid, block, 0, s, (const double*)raw, batch, width, n_gp, num_states, learn_eps, dof,
+                                           (const double*)g_qc_inv, (const double*)g_obs_w, (const double*)g_eps, (double*)g_raw);
+  else hipLaunchKernelGGL((square_covs_backward_kernel<float>), grid, block, 0, s, (const float*)raw, batch, width, n_gp, num_states, learn_eps, dof, (const float*)g_qc_inv,
+                          (const float*)g_obs_w, (const float*)g_eps, (float*)g_raw);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_square_covariances_backward launch failed: %s", hipGetErrorString(e));
+  return DGP_OK;
+}
 
 int dgp_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t copies, int64_t elems, double scale, void* out, int32_t out_dtype, void* stream) {
   if (!partial || !out) return fail(DGP_EINVAL, "dgp_sum_partial_grids: null partial or out");

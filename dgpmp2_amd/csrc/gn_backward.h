@@ -44,6 +44,10 @@ struct GnGradParams {
   int32_t g_sdf_mode;
   int32_t g_sdf_passes, g_sdf_pass0; // GSDF_SPARSE: tap blocks the caller's arrays hold (1; max_iters for the chain kernels; 2 for dgp_gn_step_errors_backward) and the block this launch's first pass writes
   int64_t* g_sdf_idx;
+  // round 5 -- dgp_gn_step_errors_backward as ONE launch: the backward of the unweighted errors at th + f_addend runs as a prologue of this kernel
+  // (unweighted_errors_prologue below) and leaves its trajectory gradient in g_th_new, its shares of g_start / g_goal / g_eps in place (accumulate = 1)
+  const void *f_unw_sg, *f_unw_gp, *f_unw_obs;   // (B) cotangents of the three unweighted errors, null = 0
+  const void* f_addend;                          // (B,n,d) dtheta of the forward pass; null: no prologue
 };
 enum { GSDF_DENSE = 0, GSDF_DENSE_F64 = 1, GSDF_SPARSE = 2 };
 
@@ -139,6 +143,124 @@ template <int DOF, bool CHAIN> struct BwdParks {
   static constexpr int value = WbParks<DOF, MODE_BACKWARD_SOLVE>::value == 0 ? 0 : (CHAIN ? 2 : WbParks<DOF, MODE_BACKWARD_SOLVE>::value);
 };
 
+// The backward of DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (plan_layer.py:374-388: start_goal_error = 1/2 |mu_s - x_0|^2 + 1/2 |mu_g - x_{n-1}|^2,
+// gp_error = mean over the n - 1 factors of 1/2 |e|^2, obs_error = mean over the n states of 1/2 c^2), run as a PROLOGUE of the step's backward kernel: what
+// round 4 launched as a kernel of its own in front of it (dgp_gn_step_errors_backward: +15 us of a 58 us replayed training iteration -- a second launch, the
+// general chain rule evaluated with lambda = 0, a 4 MB workspace written and read back by the next launch).  No solve, no covariance weights, only the three
+// cotangents: every lane hands the gradient rows of its states w.r.t. th + dtheta back in `gfold` (registers: the main program adds them to the dtheta cotangent in
+// front of the adjoint solve, after which they are dead) AND stores them to gp.g_th_new (the caller passes g_th itself: behind the solve and the chain rule, some
+// 15 us later, the main program reads ITS OWN rows back -- same lane, same addresses, program order: no fence, and nothing waits for the stores here), writes its
+// share of g_start / g_goal / g_eps in place (the main program accumulates onto them, lane-private too) and scatters its grid taps (tap block g_sdf_pass0 + 1 of a
+// sparse gradient).  Same formulas as the rows of gn_backward_lane_program with lambda = 0, ebar = 0.  (A first version ordered the stores before the main
+// program's loads with an agent-scope fence -- an L2 write-back per wavefront on gfx950: 57 instead of 36 us; with a workgroup-scope fence 31 us: the store
+// round trip in front of the main program's first loads.)
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
+DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp, Ctx& cx, const double (&th_rows)[C][2 * DOF], const double (&mu_s)[2 * DOF],
+                                       const double (&mu_g)[2 * DOF], double (&gfold)[C][2 * DOF]) {
+  constexpr int D = 2 * DOF;
+  constexpr int TPW = 64 / LPT;
+  const int lane = cx.lane();
+  const int j = lane_to_row<LPT>(lane & (LPT - 1));
+  const int64_t b = (int64_t)cx.wave() * TPW + (lane / LPT);
+  const int n = p.n;
+  const bool traj_ok = b < p.B;
+  const Nbr<LPT, 1, Ctx> nb(cx, j);
+  const int g0 = j * C;
+  const bool vec = p.vec_io != 0;
+  double x[C][D];
+  {
+    // (th rows and the means come from the main program, which has just loaded them: one load round trip instead of two)
+    double dq[C][D];
+    load_lane_rows<DOF, C, IO>(p, gp.f_addend, b, g0, traj_ok, vec, dq);
+#pragma unroll
+    for (int k = 0; k < C; ++k)
+#pragma unroll
+      for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)th_rows[k][a] + (IO)dq[k][a]);      // the sum in the I/O type, as torch forms th_curr_b + dthetab
+  }
+  const double gsg = (traj_ok && gp.f_unw_sg) ? ld<IO>(gp.f_unw_sg, b) : 0.0;
+  const double ggp = (traj_ok && gp.f_unw_gp) ? ld<IO>(gp.f_unw_gp, b) / (double)(n - 1) : 0.0;
+  const double gob = (traj_ok && gp.f_unw_obs) ? ld<IO>(gp.f_unw_obs, b) / (double)n : 0.0;
+  const bool has_grid = p.sdf != nullptr && (gp.f_unw_obs != nullptr || gp.g_sdf != nullptr);      // wave-uniform
+  LaneTaps<C, IO> taps;
+  if (has_grid) lane_obstacle_loads<DOF, C, IO>(p, b, g0, traj_ok, x, taps);
+  double x_prev[D], x_next[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) { x_prev[a] = nb.lo(x[C - 1][a]); x_next[a] = nb.hi(x[0][a]); }
+  const double dt = p.dt;
+  int32_t tap_i[C][4];
+  IO tap_v[C][4];
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { tap_i[k][t] = -1; tap_v[k][t] = (IO)0; }
+#pragma unroll
+    for (int a = 0; a < D; ++a) gfold[k][a] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = g0 + k;
+    if (!(traj_ok && g < n)) continue;
+    const double* xk = x[k];
+    const double* xm = (k == 0) ? x_prev : x[k > 0 ? k - 1 : 0];
+    const double* xp = (k == C - 1) ? x_next : x[k < C - 1 ? k + 1 : 0];
+    double gx[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) gx[a] = 0.0;
+    if (g == 0 || g == n - 1) {                       // 1/2 |mu - x|^2
+      const bool is_start = (g == 0);
+      void* gmu = is_start ? gp.g_start : gp.g_goal;
+#pragma unroll
+      for (int a = 0; a < D; ++a) {
+        const double t = gsg * ((is_start ? mu_s[a] : mu_g[a]) - xk[a]);
+        gx[a] -= t;
+        if (gmu) st<IO>(gmu, b * D + a, t);
+      }
+    }
+    if (g < n - 1) {                                  // 1/2 |x_{g+1} - Phi x_g|^2 / (n - 1): this row's share is -Phi^T e
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) {
+        const double ep = ggp * (xp[a] - (xk[a] + dt * xk[DOF + a])), ev = ggp * (xp[DOF + a] - xk[DOF + a]);
+        gx[a] -= ep;
+        gx[DOF + a] -= dt * ep + ev;
+      }
+    }
+    if (g > 0) {                                      // factor g-1 -> g: +e
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) {
+        gx[a] += ggp * (xk[a] - (xm[a] + dt * xm[DOF + a]));
+        gx[DOF + a] += ggp * (xk[DOF + a] - xm[DOF + a]);
+      }
+    }
+    double g_eps = 0.0;
+    if (has_grid) {                                   // 1/2 c^2 / n, c = eps + r - dist (hinge)
+      double c, hx, hy, d11, d21, d12, d22;
+      ObsTaps tp;
+      tap_values<C, IO>(taps, k, d11, d21, d12, d22);
+      obstacle_finish(p, taps.oa[k], d11, d21, d12, d22, taps.eps[k], c, hx, hy, &tp);
+      if (tp.act) {
+        const double ga = gob * c;
+        gx[0] -= ga * hx;
+        gx[1] -= ga * hy;
+        g_eps = ga;
+        if (gp.g_sdf) {
+          tap_i[k][0] = (int32_t)tp.i11; tap_v[k][0] = (IO)(-ga * (tp.wjc * tp.wja));
+          tap_i[k][1] = (int32_t)tp.i21; tap_v[k][1] = (IO)(-ga * (tp.wjd * tp.wja));
+          tap_i[k][2] = (int32_t)tp.i12; tap_v[k][2] = (IO)(-ga * (tp.wjc * tp.wjb));
+          tap_i[k][3] = (int32_t)tp.i22; tap_v[k][3] = (IO)(-ga * (tp.wjd * tp.wjb));
+        }
+      }
+    }
+    if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
+    st_row<IO, D>((void*)gp.g_th_new, b * n + g, vec, gx);
+#pragma unroll
+    for (int a = 0; a < D; ++a) gfold[k][a] = gx[a];
+  }
+  if (gp.g_sdf && has_grid) {
+    if (gp.g_sdf_mode == GSDF_SPARSE) sdf_emit_sparse<C, IO>(p, gp, b, g0, traj_ok, gp.g_sdf_pass0 + 1, (int64_t)gp.g_sdf_passes * p.B * p.n * 4, taps, tap_i, tap_v);
+    else sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);
+  }
+}
+
 // CHAIN = false: the backward of ONE Gauss-Newton step (dgp_gn_step_backward, dgp_eval_errors_backward).
 // CHAIN = true : the backward of the fused loop (dgp_gn_solve_backward): th_{k+1} = th_k + dtheta(th_k), k = 0 .. iters[b]-1, reversed inside the
 //   kernel -- the running cotangent g (gradient w.r.t. th_{k+1}) stays in registers, every pass re-assembles Lambda(th_k) from the forward loop's
@@ -164,6 +286,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   typename std::conditional<is_wb(QK), WbStaged, NoStage>::type wbv;
   const bool vec = p.vec_io != 0;
   double x[C][D], gbar[C][D], lam[C][D], mu_s[D], mu_g[D];
+  bool folded = false;
   // d = 4: a fully populated wavefront block whose length fills the shape moves its row tensors (th, the dtheta cotangent, dtheta in;
   // g_th out) as full cache lines through the LDS staging block, as the forward step does (load / store_rows_through_lds; the output
   // write-through) instead of 16 bytes per lane at a 64-byte stride.  Wave-uniform.
@@ -192,16 +315,33 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
+  if constexpr (!CHAIN) {
+    if (gp.f_addend) {             // wave-uniform: dgp_gn_step_errors_backward in one launch -- the errors' share of the dtheta cotangent arrives in gbar
+      unweighted_errors_prologue<DOF, LPT, C, IO>(p, gp, cx, x, mu_s, mu_g, gbar);
+      folded = true;
+    }
+  }
 #pragma unroll
   for (int k = 0; k < C; ++k)
 #pragma unroll
-    for (int a = 0; a < D; ++a) { gbar[k][a] = 0.0; lam[k][a] = 0.0; }
-  if (gp.g_dtheta) load_rows(gp.g_dtheta, gbar);
-  // dgp_gn_step_errors_backward: the gradient w.r.t. th + dtheta that the errors' backward left behind joins the dtheta cotangent
-  // (th + dtheta depends on dtheta with a unit Jacobian) and, further down, the trajectory gradient (and on th likewise).  Both uses re-read it
-  // from memory behind a wave-uniform branch: the plain step backward pays a scalar test, not sixteen registers
+    for (int a = 0; a < D; ++a) { if (!folded) gbar[k][a] = 0.0; lam[k][a] = 0.0; }
+  if (gp.g_dtheta) {
+    if (folded) {                  // (the prologue's rows are already in gbar)
+      double gd[C][D];
+      load_rows(gp.g_dtheta, gd);
+#pragma unroll
+      for (int k = 0; k < C; ++k)
+#pragma unroll
+        for (int a = 0; a < D; ++a) gbar[k][a] += gd[k][a];
+    } else {
+      load_rows(gp.g_dtheta, gbar);
+    }
+  }
+  // dgp_gn_step_errors_backward, two-launch form (long trajectories: gn_long.h; kept here for callers that pass g_th_new without f_addend): the gradient
+  // w.r.t. th + dtheta that the errors' backward left behind joins the dtheta cotangent (th + dtheta depends on dtheta with a unit Jacobian) and, further
+  // down, the trajectory gradient (and on th likewise).  Both uses re-read it from memory behind a wave-uniform branch
   if constexpr (!CHAIN) {
-    if (gp.g_th_new) {
+    if (gp.g_th_new && !folded) {
       double gnew[C][D];
       load_rows(gp.g_th_new, gnew);
 #pragma unroll

@@ -20,8 +20,11 @@ struct DevCtx {
   char* chain_;    // the chain backward kernels: lane-private slots of the running cotangent and the accumulated start / goal gradients (dgp::ChainSlots<C, d>), or null
   __device__ __forceinline__ char* chain_lds() const { return chain_; }
   __device__ __forceinline__ char* long_lds() const { return long_; }
-  // writes of this wavefront to global memory become visible to its own later loads (gn_long.h: MODE_SOLVE keeps the state in th_out)
-  __device__ __forceinline__ void mem_sync() const { __threadfence(); __syncthreads(); }
+  // writes of this wavefront to global memory become visible to its own later loads (gn_long.h: MODE_SOLVE keeps the state in th_out; gn_backward.h: the
+  // errors' prologue hands its trajectory gradient to the main program).  WORKGROUP scope (the fences inside __syncthreads; the workgroup is this one wavefront,
+  // its CU's vector L1 is write-through and shared by the whole workgroup): an agent-scope fence (__threadfence) writes back / invalidates the XCD's L2 on gfx950 --
+  // a thousand wavefronts doing that cost the single-launch training-iteration backward 20 us (measured: 57 instead of 36 us) for nothing.
+  __device__ __forceinline__ void mem_sync() const { __syncthreads(); }
   __device__ __forceinline__ char* lds() const { return lds_; }
   __device__ __forceinline__ char* stash() const { return stash_; }
   __device__ __forceinline__ char* wb_lds() const { return wb_; }

@@ -17,10 +17,11 @@ their output vector and the solver's covariance inputs, diff_gpmp2_planner.py:24
 """
 import time
 
+import numpy as np
 import torch
 import torch.nn as nn
 
-from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC, _GNSolve, _NO_COVS, _expand_base
+from .plan_layer import PlanLayer, _f, _launch, _raw_stream, _ALL_STATIC, _GNSolve, _NO_COVS, _expand_base, _RawCovs
 from ..utils.planner_utils import check_convergence
 
 
@@ -45,13 +46,36 @@ class _PerSampleHistory(object):
   def __getitem__(self, b):
     if isinstance(b, slice):
       return [self[i] for i in range(*b.indices(len(self)))]
-    return self._h[b, :self._k[b]].tolist()
+    return self._h[b, :int(self._k[b])].tolist()
 
   def __iter__(self):
     return (self[b] for b in range(len(self)))
 
   def __repr__(self):
     return 'PerSampleHistory(%d samples)' % len(self)
+
+
+class _LazyList(object):
+  """A per-sample result of forward() -- the reference returns python lists with one entry per sample (diff_gpmp2_planner.py:138-174) -- kept as the numpy array
+  that came back from the device: indexing, slicing, iteration, len(), ==, np.asarray() and tolist() behave like the list, which is only materialised when someone
+  asks for it (building four 4096-element lists costs more host time than the whole fused solve runs)."""
+
+  __slots__ = ('_a',)
+
+  def __init__(self, a): self._a = a
+  def __len__(self): return len(self._a)
+  def __getitem__(self, i):
+    r = self._a[i]
+    return r.tolist() if isinstance(i, slice) else r.item()
+  def __iter__(self): return iter(self._a.tolist())
+  def __array__(self, dtype=None, copy=None): return self._a if dtype is None else self._a.astype(dtype)
+  def tolist(self): return self._a.tolist()
+  def __eq__(self, o):
+    if isinstance(o, _LazyList): o = o._a.tolist()
+    return self._a.tolist() == (list(o) if isinstance(o, (list, tuple)) else o)
+  def __ne__(self, o): return not self.__eq__(o)
+  __hash__ = None
+  def __repr__(self): return repr(self._a.tolist())
 
 
 class _SquaredCovs(torch.autograd.Function):
@@ -73,8 +97,11 @@ class _SquaredCovs(torch.autograd.Function):
       res.append(s.view(B, n_gp, 1, 1) * torch.eye(dof, device=out.device, dtype=out.dtype))
       res.append(s)                                                    # (the scalars themselves, for the DGP_QC_SCALAR tag; not differentiable)
       ctx.mark_non_differentiable(s)
-    res.append(sq[:, n_gp:n_gp + n_obs].reshape(B, n_obs, 1, 1))
-    if learn_eps: res.append(sq[:, n_gp + n_obs:n_gp + 2 * n_obs].reshape(B, n_obs, 1, 1))
+    if learn_eps and out.shape[2] != n_gp + 2 * n_obs:      # the reference reshapes out[:, 0, n_gp + n_obs:] to (B, n, nl, 1) (:282) and raises on any other length
+      raise RuntimeError('get_covariances: the learn module emitted %d values, %d expected with learn_eps' % (out.shape[2], n_gp + 2 * n_obs))
+    # contiguous tensors (not strided views into `sq`): PlanLayer hands their addresses to the kernel as they are, and the gradient buffers take their shape
+    res.append(sq[:, n_gp:n_gp + n_obs].reshape(B, n_obs, 1, 1).contiguous())
+    if learn_eps: res.append(sq[:, n_gp + n_obs:n_gp + 2 * n_obs].reshape(B, n_obs, 1, 1).contiguous())
     return tuple(res)
 
   @staticmethod
@@ -210,8 +237,9 @@ class DiffGPMP2Planner(nn.Module):
                                        self._static_view(self.eps_traj, B, like))
     return v
 
-  def _predict(self, th_in, conv_out, hiddenb, im_in=None):
-    """Learned mode: run the user's modules and turn their output into covariances (diff_gpmp2_planner.py:183-199)."""
+  def _predict(self, th_in, conv_out, hiddenb, im_in=None, raw_ok=False):
+    """Learned mode: run the user's modules and turn their output into covariances (diff_gpmp2_planner.py:183-199).  raw_ok (step() / step_with_errors()): in the
+    modes whose tensors are plain squares of the module output the vector itself is handed on (-> (_RawCovs, None, None, hidden)) and squared inside the kernels."""
     if not self.fixed_conv:
       conv_out, _ = self.learn_module_conv(im_in)
     if self.model_type == 'feed_forward':
@@ -220,6 +248,9 @@ class DiffGPMP2Planner(nn.Module):
       out, hidden = self.learn_module_fcn(th_in, conv_out, hiddenb)
     B = th_in.shape[0]
     eps = None
+    if raw_ok and out.dtype is th_in.dtype:
+      raw = self.__dict__['_pl'].raw_covs(out, self.dynamics_mode, self.learn_eps)
+      if raw is not None: return raw, None, None, hidden
     if self.dynamics_mode == 'fix_dynamics':
       r = self.get_covariances(out, self.dynamics_mode, self.learn_eps)
       obscov, eps = (r if self.learn_eps else (r, None))
@@ -233,27 +264,35 @@ class DiffGPMP2Planner(nn.Module):
     return qc, obscov, eps, hidden
 
   # -- reference API --------------------------------------------------------------------------------------
-  def _step_covariances(self, th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb):
+  def _step_covariances(self, th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb, raw_ok=False):
     """The covariance inputs of one step (diff_gpmp2_planner.py:183-205): predicted by the learn modules, or the static ones."""
     if self.__dict__['_learned']:
       im_in = None
       if not self.fixed_conv:
         im_in = torch.cat((imb, sdfb), dim=1) if self.sdf_predict else imb
       th_in = torch.cat((th_currb, dtheta_currb), dim=-1) if self.use_dtheta else th_currb
-      return self._predict(th_in, conv_out, hiddenb, im_in)
+      return self._predict(th_in, conv_out, hiddenb, im_in, raw_ok)
     return self._static_covs(th_currb.shape[0], th_currb) + (None,)
 
   def step(self, th_currb, startb, goalb, imb, sdfb, conv_out=None, dtheta_currb=None, hiddenb=None):
     """One iteration of non-linear optimisation on a batch of environments (diff_gpmp2_planner.py:176-211).
     -> (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr)"""
     pl = self.__dict__['_pl']
+    hooks = pl._forward_hooks or pl._forward_pre_hooks or pl._backward_hooks or pl._backward_pre_hooks or _global_module_hooks()
     if self.__dict__['_learned']:
-      qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb)
+      qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb, raw_ok=not hooks)
+      if qc_inv_curr.__class__ is _RawCovs:
+        # 'diag_identity' / 'fix_dynamics': the module output goes to the kernels as it is (squared there; the backward kernel writes d/d out)
+        raw = qc_inv_curr
+        dthetab, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr = pl.forward_raw(th_currb, startb, goalb, imb, sdfb, raw)
+        if qc_inv_curr is None: qc_inv_curr = self._static_view(self.qc_inv_traj, th_currb.shape[0], th_currb)
+        if eps_curr is None: eps_curr = self._static_view(self.eps_traj, th_currb.shape[0], th_currb)
+        return dthetab, (hidden if hiddenb is not None else None), err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr
     else:
       hidden = None
       qc_inv_curr, obscov_inv_curr, eps_curr = self._static_covs(th_currb.shape[0], th_currb)
     # (nn.Module.__call__ costs ~2 us of hook bookkeeping per call; without hooks it does nothing but call forward())
-    if pl._forward_hooks or pl._forward_pre_hooks or pl._backward_hooks or pl._backward_pre_hooks or _global_module_hooks():
+    if hooks:
       dthetab, err_oldb, err_ext_oldb = pl(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
     else:
       dthetab, err_oldb, err_ext_oldb = pl.forward(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
@@ -266,9 +305,19 @@ class DiffGPMP2Planner(nn.Module):
     one C-ABI call forward, one backward (PlanLayer.forward_with_errors).  No counterpart in the reference: an addition for its outer loop,
         out, (err_sg, err_gp, err_obs) = planner.step_with_errors(th, start, goal, im, sdf, conv_out, dtheta)
     replacing  out = planner.step(...); err_sg, err_gp, err_obs = planner.unweighted_errors_batch(th + out[0], sdf)."""
-    qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb)
-    dthetab, err_oldb, err_ext_oldb, e_sg, e_gp, e_obs = self.__dict__['_pl'].forward_with_errors(th_currb, startb, goalb, imb, sdfb, qc_inv_curr,
-                                                                                                 obscov_inv_curr, eps_curr)
+    pl = self.__dict__['_pl']
+    if self.num_traj_states > 256 or pl._forward_hooks or pl._forward_pre_hooks or pl._backward_hooks or pl._backward_pre_hooks or _global_module_hooks():
+      # long trajectories (the fused entry points stop at 256 states) and registered module hooks: the two calls this method stands for
+      out = self.step(th_currb, startb, goalb, imb, sdfb, conv_out, dtheta_currb, hiddenb)
+      return out, self.unweighted_errors_batch(th_currb + out[0], sdfb)
+    qc_inv_curr, obscov_inv_curr, eps_curr, hidden = self._step_covariances(th_currb, imb, sdfb, conv_out, dtheta_currb, hiddenb, raw_ok=True)
+    if qc_inv_curr.__class__ is _RawCovs:
+      raw = qc_inv_curr
+      dthetab, err_oldb, err_ext_oldb, e_sg, e_gp, e_obs, qc_inv_curr, obscov_inv_curr, eps_curr = pl.forward_raw(th_currb, startb, goalb, imb, sdfb, raw, with_errors=True)
+      if qc_inv_curr is None: qc_inv_curr = self._static_view(self.qc_inv_traj, th_currb.shape[0], th_currb)
+      if eps_curr is None: eps_curr = self._static_view(self.eps_traj, th_currb.shape[0], th_currb)
+    else:
+      dthetab, err_oldb, err_ext_oldb, e_sg, e_gp, e_obs = pl.forward_with_errors(th_currb, startb, goalb, imb, sdfb, qc_inv_curr, obscov_inv_curr, eps_curr)
     hidden_newb = hidden if hiddenb is not None else None
     return (dthetab, hidden_newb, err_oldb, err_ext_oldb, qc_inv_curr, obscov_inv_curr, eps_curr), (e_sg, e_gp, e_obs)
 
@@ -285,16 +334,20 @@ class DiffGPMP2Planner(nn.Module):
     if self.learn_module_fcn is None and plan_time == float('inf'):
       if not needs_graph:
         return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t)
-      if self._chain_backward_available():
+      if self._chain_backward_available(B, max_iters):
         return self._forward_fused(th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t, with_graph=True)
     return self._forward_stepwise(th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t)
 
-  def _chain_backward_available(self):
+  fused_history_budget = 2 << 30      # bytes of fp64 trajectory history a differentiable fused forward() may hold until its graph is freed
+
+  def _chain_backward_available(self, B=1, max_iters=1):
     """dgp_gn_solve_backward covers static covariances with a diagonal Q_c_inv and trajectories of up to 256 states; anything else
-    differentiates through chained step() calls (_forward_stepwise)."""
+    differentiates through chained step() calls (_forward_stepwise).  So does a loop whose history -- (max_iters, B, n, d) doubles, allocated in
+    full whatever the iterations that run (the reference's YAML default is max_iters = 100) -- would exceed `fused_history_budget`: the stepwise
+    path keeps state for the iterations that ran and stops when every trajectory has converged."""
     q = self.plan_layer._qc_rows
     diag = all(q[i][j] == 0.0 for i in range(len(q)) for j in range(len(q)) if i != j)
-    return diag and self.num_traj_states <= 256
+    return diag and self.num_traj_states <= 256 and max_iters * B * self.num_traj_states * self.state_dim * 8 <= self.fused_history_budget
 
   def _forward_fused(self, th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t, with_graph=False):
     """The whole batch in ONE launch of the fused loop.  with_graph: th_currb carries the autograd graph of the loop (w.r.t. th_initb, startb,
@@ -318,28 +371,31 @@ class DiffGPMP2Planner(nn.Module):
       sd = pl._sdf_args(sdfb, dt, B, idx)
       th0, st, go = th_initb.detach().contiguous(), startb.detach().contiguous(), goalb.detach().contiguous()
       th_out = torch.empty_like(th0)
-      # the per-sample outputs share ONE device buffer -- err history | err_ext history | final error | iteration counts -- so that one fill (NaN: entries
+      # the per-sample outputs share ONE device buffer -- err history | err_ext history | final error | iteration counts | SPD flags -- so that one fill (NaN: entries
       # past a sample's last iteration stay untouched) and ONE device-to-host copy serve all four (each separate copy costs a synchronisation of its own)
-      buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dt, device=dev)
+      buf = torch.full((B * (2 * m + 3),), float('nan'), dtype=dt, device=dev)
       eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
-      iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts in the last B elements' storage
-      info = torch.empty(B, dtype=torch.int32, device=dev)
+      iters = buf[2 * B * m + B:].view(torch.int32)[:B]           # int32 counts and SPD flags in the storage of the last 2 B elements
+      info = buf[2 * B * m + 2 * B:].view(torch.int32)[:B]
       _launch(idx, pl._pc.gn_solve, solver.h, B, th0.data_ptr(), st.data_ptr(), go.data_ptr(), *sd[:7], *_NO_COVS,
               max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), _raw_stream(idx))
     pl.last_info = info
     pl._last = (st, go, None, None, None)
-    host = buf.cpu()                                # synchronises
-    # the copy above has synchronised, so the SPD flags of this launch can be looked at for the price of one more small copy: the
-    # reference raises from torch.cholesky at the first non-SPD system (plan_layer.py:226)
-    bad = int(info.count_nonzero())
-    if bad:
+    # ONE device-to-host copy of everything the reference API returns per sample -- error histories, final errors, iteration counts AND the SPD flags (they live
+    # in the tail of the same buffer) -- into pinned host memory (torch's caching host allocator: no page-locking per call), one stream synchronisation
+    host = torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+    host.copy_(buf, non_blocking=True)
+    torch.cuda.current_stream(idx).synchronize()
+    flags = host[2 * B * m + 2 * B:].view(torch.int32)[:B].numpy()
+    bad = int(np.count_nonzero(flags))
+    if bad:      # the reference raises from torch.cholesky at the first non-SPD system (plan_layer.py:226); here the flags ride along with the results: no extra copy
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories during forward() '
                          '(the reference raises from torch.cholesky here); per-trajectory flags: plan_layer.last_info' % (bad, B))
     eh_c, eeh_c = host[:B * m].view(B, m).numpy(), host[B * m:2 * B * m].view(B, m).numpy()
     ef_c = host[2 * B * m:2 * B * m + B].numpy()
-    jb = host[2 * B * m + B:].view(torch.int32)[:B].tolist()
+    jb = host[2 * B * m + B:].view(torch.int32)[:B].numpy()
     t = time.time() - start_t
-    return (th_out, None, eh_c[:, 0].tolist(), ef_c.tolist(), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), jb, [t] * B)
+    return (th_out, None, _LazyList(eh_c[:, 0]), _LazyList(ef_c), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), _LazyList(jb), [t] * B)
 
   def _forward_stepwise(self, th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t):
     """Differentiable / learned / time-limited variant: chained batched step() calls with a per-trajectory freeze once

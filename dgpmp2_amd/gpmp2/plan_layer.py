@@ -60,7 +60,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
 
 _SDF_GRAD_COPIES = 16     # MI355X has 8 XCDs, each with its own L2: two partial grids per XCD (XCD-local atomics, summed afterwards)
 _ALL_STATIC = (True, True, True)
-_NO_COVS = (_capi.DGP_QC_STATIC, None, None, None, 0, 0, None, None, None)       # the nine fields of DgpCovs as the trampoline takes them
+_NO_COVS = (_capi.DGP_QC_STATIC, None, None, None)       # the four fields of DgpCovs as the trampoline takes them
 
 # current device / current raw stream as plain ints: torch.cuda.current_stream() builds a Stream object (1.2 us), the private getters
 # are what it calls underneath (0.1 us each); fall back to the public API where a torch build lacks them
@@ -127,7 +127,8 @@ class _GNStep(torch.autograd.Function):
     if start.get_device() != dev or goal.get_device() != dev:
       _same_device(dev, startb=start, goalb=goal)
     sd = layer._sdf_args(sdf, dtype, B, dev)
-    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
+    if static.__class__ is _RawCovs: cv = static.cov_args(B, dtype, dev)      # (qc is the learn module's raw output vector, squared inside the kernel)
+    else: cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
     proto = layer._err_protos.get((B, dtype, dev))
@@ -139,7 +140,7 @@ class _GNStep(torch.autograd.Function):
     # iteration's; the planning loop without an autograd graph reuses one buffer per (batch, device, stream), see _info_buffer
     info = layer._info_buffer(B, dev, stream, thc)
     if own_info or layer.check_spd: info = torch.empty_like(info)
-    _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
+    _launch(dev, layer._pc.gn_step, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:4], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), stream)
     layer.__dict__['last_info'] = info      # (plain attribute: nn.Module.__setattr__ costs microseconds per call)
     if layer.check_spd and bool(info.any()):
       raise RuntimeError('dgpmp2_amd: A^T K A + delta I is not positive definite for %d of %d trajectories '
@@ -201,7 +202,7 @@ class _GNStep(torch.autograd.Function):
     g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
     g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
     _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
-            *cv[:9], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr, gs.stride, gs.copies,
+            *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr, gs.stride, gs.copies,
             _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _raw_stream(dev))
     g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
@@ -271,7 +272,9 @@ class _SdfGrad(object):
     self.idx = None
     self.pc, self.dev = layer._pc, th.get_device()
     if self.shared:
-      self.copies, self.stride = _SDF_GRAD_COPIES, 0
+      # partial copies: two per XCD for a batch that fills the chip; one set per XCD for a medium batch; a single grid (device-scope atomics) for a small one,
+      # whose few thousand taps do not contend -- zero-filling and summing sixteen 256 x 256 double grids costs more than such a backward kernel runs
+      self.copies, self.stride = (_SDF_GRAD_COPIES if B * n >= 65536 else (8 if B * n >= 8192 else 1)), 0
       self.mode = _capi.DGP_GSDF_DENSE_F64 if n <= 256 else _capi.DGP_GSDF_DENSE
       self.g = torch.zeros((self.copies, 1, H, W), dtype=torch.float64 if self.mode == _capi.DGP_GSDF_DENSE_F64 else th.dtype, device=th.device)
     else:
@@ -352,7 +355,8 @@ class _GNStepErrors(torch.autograd.Function):
     if start.get_device() != dev or goal.get_device() != dev:
       _same_device(dev, startb=start, goalb=goal)
     sd = layer._sdf_args(sdf, dtype, B, dev)
-    cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
+    if static.__class__ is _RawCovs: cv = static.cov_args(B, dtype, dev)
+    else: cv = _NO_COVS_KEEP if static == _ALL_STATIC else layer._cov_args(qc, ow, eps, dtype, B, dev, static, True)
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     dth = torch.empty_like(thc)
     proto = layer._err_protos.get((B, dtype, dev))
@@ -361,7 +365,7 @@ class _GNStepErrors(torch.autograd.Function):
     stream = _raw_stream(dev)
     info = layer._info_buffer(B, dev, stream, thc)
     if own_info or layer.check_spd: info = torch.empty_like(info)
-    _launch(dev, layer._pc.gn_step_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), usg.data_ptr(), ugp.data_ptr(),
+    _launch(dev, layer._pc.gn_step_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:4], dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), usg.data_ptr(), ugp.data_ptr(),
             uobs.data_ptr(), stream)
     layer.__dict__['last_info'] = info
     if layer.check_spd and bool(info.any()):
@@ -413,9 +417,11 @@ class _GNStepErrors(torch.autograd.Function):
     g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
     g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
     g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
-    ws = torch.empty_like(th) if errs else None      # dL/d(th + dtheta) between the two launches
+    # the errors' backward runs as a prologue of the step's backward kernel and hands dL/d(th + dtheta) over in g_th itself; a workspace is only needed
+    # when no trajectory gradient is wanted (or for the two-launch form of long trajectories)
+    ws = torch.empty_like(th) if (errs and (g_th is None or n > 256)) else None
     _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
-            *cv[:9], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
+            *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
             _ptr(g_go), gs.ptr, gs.stride, gs.copies, _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _ptr(ws), _raw_stream(dev))
     g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_qc, qc), _grad_out(g_ow, ow), _grad_out(g_eps, eps))
@@ -423,6 +429,129 @@ class _GNStepErrors(torch.autograd.Function):
 
 
 _GNStepErrors._backward_once = staticmethod(once_differentiable(_GNStepErrors._backward_impl))
+
+
+class _RawCovs(object):
+  """The learn module's output vector as the covariance input of a step: `out` (B, 1, W) contiguous, column blocks [0, n_gp) one raw scalar q_k per GP factor
+  ('diag_identity': Q_c^-1 = q_k^2 I; n_gp = 0: 'fix_dynamics', the static Q_c_inv), [n_gp, n_gp + n) the raw obstacle weights o_i (weight o_i^2), then --
+  learn_eps -- the raw epsilons (eps = e_i^2): exactly what get_covariances slices and squares for a single-link robot (diff_gpmp2_planner.py:247-290).  ONE small
+  launch (dgp_square_covariances) forms every tensor the step and its caller need -- the scalars q_k^2 the kernels take (DGP_QC_SCALAR), the blocks q_k^2 I the
+  reference returns, o_i^2, e_i^2 -- and one more (dgp_square_covariances_backward) turns the gradients the backward kernel writes into d/d out."""
+
+  __slots__ = ('out', 'n_gp', 'n', 'learn_eps', 'dof', 'scal', 'qc', 'ow', 'eps')
+
+  def __init__(self, out, n_gp, n, learn_eps, dof):
+    self.out, self.n_gp, self.n, self.learn_eps, self.dof = out, n_gp, n, learn_eps, dof
+    self.scal = self.qc = self.ow = self.eps = None
+
+  @property
+  def used(self): return self.n_gp + self.n * (2 if self.learn_eps else 1)
+
+  def square(self, pc, dev):
+    """the forward launch: fills scal (B, n-1), qc (B, n-1, dof, dof), ow (B, n, 1, 1), eps (B, n, 1, 1) (those the mode has)"""
+    out = self.out
+    B, n = out.shape[0], self.n
+    if self.n_gp:
+      self.scal = out.new_empty((B, self.n_gp))
+      self.qc = out.new_empty((B, self.n_gp, self.dof, self.dof))
+    self.ow = out.new_empty((B, n, 1, 1))
+    if self.learn_eps: self.eps = out.new_empty((B, n, 1, 1))
+    _launch(dev, pc.square_covariances, out.data_ptr(), _io_code(out.dtype), B, out.shape[2], self.n_gp, n, int(self.learn_eps), self.dof, _ptr(self.scal), _ptr(self.qc),
+            self.ow.data_ptr(), _ptr(self.eps), _raw_stream(dev))
+
+  def cov_args(self, B, dtype, dev):
+    return (_capi.DGP_QC_SCALAR if self.n_gp else _capi.DGP_QC_STATIC, _ptr(self.scal), self.ow.data_ptr(), _ptr(self.eps), (self.scal, self.ow, self.eps))
+
+
+class _GNStepRaw(torch.autograd.Function):
+  """_GNStep / _GNStepErrors with the learn module's OUTPUT VECTOR as the covariance input (planner.step() / step_with_errors() in the learned modes
+  'diag_identity' and 'fix_dynamics' of a single-link robot): the squares of diff_gpmp2_planner.py:247-290 are taken inside the kernels and the backward kernel
+  writes dL/d out -- none of get_covariances' slices, products and their backward (a dozen small torch kernels that cost as much as the solver under HIP-graph
+  replay) is left.  Outputs: dtheta, err_ext[, the three unweighted errors at th + dtheta], and the squared tensors step() returns (differentiable: a cotangent
+  on them, which the reference's loss does not produce -- its cov_loss is commented out, learning/train_planner.py:115 -- is chained by plain torch ops)."""
+
+  @staticmethod
+  def forward(ctx, layer, raw, with_errors, slots, ts, box, *diff):
+    th, start, goal, sdf, out = ts
+    raw.square(layer._pc, th.get_device())
+    if with_errors:
+      dth, err, eex, usg, ugp, uobs, (thc, stc, goc), args = _GNStepErrors.launch(layer, raw, th, start, goal, sdf, out, None, None, True)
+    else:
+      dth, err, eex, (thc, stc, goc), args = _GNStep.launch(layer, raw, th, start, goal, sdf, out, None, None, True)
+      usg = ugp = uobs = None
+    # (aliases as outputs: the node keeps raw.scal / ow / eps for its backward launch, and an OUTPUT held by its own node would be a reference cycle)
+    qc, ow, eps = (None if t is None else t.view(t.shape) for t in (raw.qc, raw.ow, raw.eps))
+    box.append((err,))
+    ctx.layer, ctx.slots, ctx.args, ctx.raw, ctx.with_errors = layer, slots, args, raw, with_errors
+    ctx.inputs = (thc, stc, goc, sdf, out, start, goal)
+    ctx.versions = (thc._version, stc._version, goc._version, -1 if sdf is None else sdf._version, out._version)
+    ctx.save_for_backward(dth)
+    ctx.set_materialize_grads(False)
+    res = (dth, eex) + ((usg, ugp, uobs) if with_errors else ()) + tuple(t for t in (qc, ow, eps) if t is not None)
+    return res
+
+  @staticmethod
+  def backward(ctx, *cots):
+    if torch.is_grad_enabled():
+      return _GNStepRaw._backward_once(ctx, *cots)
+    return _GNStepRaw._backward_impl(ctx, *cots)
+
+  @staticmethod
+  def _backward_impl(ctx, *cots):
+    layer, raw = ctx.layer, ctx.raw
+    dth, = ctx.saved_tensors
+    th, stc, goc, sdf, out, start, goal = ctx.inputs
+    _check_versions(ctx.inputs[:5], ctx.versions)
+    sd, cv = ctx.args
+    B, n, d = th.shape
+    dtype = th.dtype
+    solver = layer._solvers[dtype]
+    dev = th.get_device()
+    slots = ctx.slots
+    nig = ctx.needs_input_grad                    # (layer, raw, with_errors, slots, ts, box, *diff)
+    need = [False] * 5
+    for q, i in enumerate(slots): need[i] = nig[6 + q]
+    fix = lambda g: g if (g is None or (g.dtype is dtype and g.is_contiguous())) else g.contiguous().to(dtype)
+    k = 5 if ctx.with_errors else 2
+    g_dth, g_eex = fix(cots[0]), fix(cots[1])
+    g_usg, g_ugp, g_uobs = (fix(cots[2]), fix(cots[3]), fix(cots[4])) if ctx.with_errors else (None, None, None)
+    g_sq = list(cots[k:])                         # cotangents of the squared tensors (qc [if n_gp], ow, eps [if learn_eps]): normally all None
+    g_th = torch.empty_like(th) if need[0] else None
+    g_st = _grad_like(start, stc) if need[1] else None
+    g_go = _grad_like(goal, goc) if need[2] else None
+    errs = g_usg is not None or g_ugp is not None or g_uobs is not None
+    gs = _SdfGrad(layer, th, sdf, sd, passes=2 if errs else 1) if need[3] else _NO_SDF_GRAD
+    g_out = gq = gw = ge = None
+    if need[4]:
+      # the backward kernel writes the gradients of the squared tensors (the blocks' gradient under DGP_QC_SCALAR); one more small launch turns them into d/d out
+      if raw.n_gp: gq = torch.empty_like(raw.qc)
+      gw = torch.empty_like(raw.ow)
+      if raw.learn_eps: ge = torch.empty_like(raw.eps)
+    ws = torch.empty_like(th) if (errs and g_th is None) else None
+    if ctx.with_errors:
+      _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
+              *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
+              _ptr(g_go), gs.ptr, gs.stride, gs.copies, _ptr(gq), _ptr(gw), _ptr(ge), _ptr(ws), _raw_stream(dev))
+    else:
+      _launch(dev, layer._pc.gn_step_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
+              *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr, gs.stride, gs.copies,
+              _ptr(gq), _ptr(gw), _ptr(ge), _raw_stream(dev))
+    if need[4]:
+      # someone differentiated the squared tensors themselves (the reference's loss does not): their cotangents join the kernel's gradients
+      names = (['qc'] if raw.n_gp else []) + ['ow'] + (['eps'] if raw.learn_eps else [])
+      for name, g in zip(names, g_sq):
+        if g is None: continue
+        if name == 'qc': gq = gq + g.to(dtype)
+        elif name == 'ow': gw = gw + g.reshape(gw.shape).to(dtype)
+        else: ge = ge + g.reshape(ge.shape).to(dtype)
+      g_out = torch.empty_like(out)
+      _launch(dev, layer._pc.square_covariances_backward, out.data_ptr(), _io_code(dtype), B, out.shape[2], raw.n_gp, raw.n, int(raw.learn_eps), raw.dof,
+              _ptr(gq), _ptr(gw), _ptr(ge), g_out.data_ptr(), _raw_stream(dev))
+    grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), gs.finish(sdf), g_out)
+    return (None, None, None, None, None, None) + tuple(grads[i] for i in slots)
+
+
+_GNStepRaw._backward_once = staticmethod(once_differentiable(_GNStepRaw._backward_impl))
 
 
 class _GNSolve(torch.autograd.Function):
@@ -444,10 +573,10 @@ class _GNSolve(torch.autograd.Function):
     thc, stc, goc = th.contiguous(), start.contiguous(), goal.contiguous()
     th_out = torch.empty_like(thc)
     m = max_iters
-    buf = torch.full((B * (2 * m + 2),), float('nan'), dtype=dtype, device=th.device)
+    buf = torch.full((B * (2 * m + 3),), float('nan'), dtype=dtype, device=th.device)      # err history | err_ext history | final error | iteration counts | SPD flags: one copy to the host
     eh, eeh, ef = buf[:B * m], buf[B * m:2 * B * m], buf[2 * B * m:2 * B * m + B]
     iters = buf[2 * B * m + B:].view(torch.int32)[:B]
-    info = torch.empty(B, dtype=torch.int32, device=th.device)
+    info = buf[2 * B * m + 2 * B:].view(torch.int32)[:B]
     hist = torch.empty((m, B, n, d), dtype=torch.float64, device=th.device)      # th_k, fp64 whatever the I/O type (rows past iters[b] stay unwritten and unread)
     _launch(dev, layer._pc.gn_solve_traced, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *_NO_COVS,
             max_iters, tol_delta, th_out.data_ptr(), iters.data_ptr(), eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), info.data_ptr(), hist.data_ptr(),
@@ -539,7 +668,7 @@ class _EvalErrors(torch.autograd.Function):
     gs = _SdfGrad(layer, th, sdf, sd) if (sdf is not None and need[4]) else _NO_SDF_GRAD
     g_eps = _grad_like(eps, th) if (need[5] and eps is not None) else None
     _launch(dev, layer._pc.eval_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
-            *cv[:9], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr,
+            *cv[:4], _ptr(cot[0]), _ptr(cot[1]), _ptr(cot[2]), _ptr(cot[3]), _ptr(g_th), _ptr(g_st), _ptr(g_go), gs.ptr,
             gs.stride, gs.copies, _ptr(g_eps), _raw_stream(dev))
     g_sdf = gs.finish(sdf)
     grads = (g_th, _grad_out(g_st, start), _grad_out(g_go, goal), g_sdf, _grad_out(g_eps, eps))
@@ -676,7 +805,7 @@ class PlanLayer(nn.Module):
     return (qc is None or '_dgp_static' in qc.__dict__, ow is None or '_dgp_static' in ow.__dict__, eps is None or '_dgp_static' in eps.__dict__)
 
   def _cov_args(self, qc, ow, eps, dtype, B, dev, static=(False, False, False), scalar_ok=False):
-    """Covariance tensors -> the nine DgpCovs fields (qc_mode, the qc_inv / obs_w / eps addresses, flags, row stride, three optional outputs) + a keep-alive list.  A static entry selects the constants of the
+    """Covariance tensors -> the four DgpCovs fields (qc_mode, the qc_inv / obs_w / eps addresses) + a keep-alive list.  A static entry selects the constants of the
     handle (no per-state tensor is streamed)."""
     if static == _ALL_STATIC:
       return _NO_COVS_KEEP
@@ -707,7 +836,7 @@ class PlanLayer(nn.Module):
         qc_p = prep(qc, (n - 1) * (d * d if self._q_full else dof * dof), 'qc_inv_trajb')
     if ow is not None and not static[1]: ow_p = prep(ow, n * self.nlinks, 'obscov_inv_trajb')
     if eps is not None and not static[2]: ep_p = prep(eps, n * self.nlinks, 'eps_trajb')
-    return (mode, qc_p, ow_p, ep_p, 0, 0, None, None, None, keep)
+    return (mode, qc_p, ow_p, ep_p, keep)
 
   def _check_inputs(self, thb, startb, goalb):
     if not (thb.is_cuda and startb.is_cuda and goalb.is_cuda):
@@ -753,6 +882,11 @@ class PlanLayer(nn.Module):
     everything but err carries the graph (ONE autograd node, ONE backward call).  Equivalent to
         dth, err, eex = layer(thb, ...); sg, gp, ob = layer.unweighted_errors(thb + dth, sdfb)"""
     self._check_inputs(thb, startb, goalb)
+    B = thb.shape[0]
+    if self.num_traj_states > 256:      # the fused entry points stop at 256 states: the two calls this method stands for (the loop kernels of gn_long.h)
+      dth, err, eex = self.forward(thb, startb, goalb, imb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
+      sg, gp, ob = self.unweighted_errors(thb + dth, sdfb)
+      return dth, err, eex, sg, gp, ob
     static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
     if static == _ALL_STATIC:
       self.__dict__['_last'] = (startb, goalb, None, None, None)
@@ -760,7 +894,6 @@ class PlanLayer(nn.Module):
       det = lambda t, st: None if (t is None or st) else t.detach()
       self.__dict__['_last'] = (startb, goalb, det(qc_inv_trajb, static[0]), det(obscov_inv_trajb, static[1]),
                                 None if (eps_trajb is None or static[2]) else eps_trajb)
-    B = thb.shape[0]
     if torch.is_grad_enabled():
       if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
       ts = (thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
@@ -771,6 +904,56 @@ class PlanLayer(nn.Module):
         return dth, box[0], eex, usg.reshape(B, 1), ugp, uobs
     dth, err, eex, usg, ugp, uobs = _GNStepErrors.launch(self, static, thb, startb, goalb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)[:6]
     return dth, err, eex, usg.reshape(B, 1), ugp, uobs
+
+  def raw_covs(self, out, mode, learn_eps):
+    """The learn module's output `out` as a covariance input the kernels square themselves (_RawCovs), or None when this call cannot take that path: single-link
+    robot, dynamics_mode 'diag_identity' (with Q_c_inv = I in the configuration: q_k^2 I is then a scalar multiple of it) or 'fix_dynamics', out (B, 1, W) contiguous
+    with W at least what the mode consumes, at most 256 states."""
+    n = self.num_traj_states
+    if self.nlinks != 1 or n > 256 or self._q_full or out.dim() != 3 or out.shape[1] != 1 or not out.is_contiguous(): return None
+    if mode == 'diag_identity':
+      if not self._scalar_qc: return None
+      n_gp = n - 1
+    elif mode == 'fix_dynamics': n_gp = 0
+    else: return None
+    raw = _RawCovs(out, n_gp, n, bool(learn_eps), self.dof)
+    if learn_eps and raw.used != out.shape[2]: return None      # (the reference's reshape of the epsilon block would raise: keep its behaviour)
+    if raw.used > out.shape[2]: return None
+    return raw
+
+  def forward_raw(self, thb, startb, goalb, imb, sdfb, raw, with_errors=False):
+    """forward() / forward_with_errors() with the covariances given as the learn module's output vector (`raw` = self.raw_covs(out, mode, learn_eps)).
+    -> (dthetab, err, err_ext[, err_sg (B,1), err_gp, err_obs], qc_inv_trajb or None, obscov_inv_trajb, eps_trajb or None): the last three are what
+    get_covariances would have built (same values), carrying the graph to `out` like everything else."""
+    self._check_inputs(thb, startb, goalb)
+    out = raw.out
+    if out.dtype is not thb.dtype or out.get_device() != thb.get_device() or out.shape[0] != thb.shape[0]:
+      raise ValueError('the learn module output must share dtype, device and batch with thb')
+    B = thb.shape[0]
+    if torch.is_grad_enabled():
+      if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
+      ts = (thb, startb, goalb, sdfb, out)
+      slots = tuple([i for i in range(5) if ts[i] is not None and ts[i].requires_grad])
+      if slots:
+        box = []
+        res = _GNStepRaw.apply(self, raw, with_errors, slots, ts, box, *[ts[i] for i in slots])
+        err = box[0][0]
+        k = 5 if with_errors else 2
+        sq = list(res[k:])
+        qc = sq.pop(0) if raw.n_gp else None
+        ow = sq.pop(0)
+        eps = sq.pop(0) if raw.learn_eps else None
+        self.__dict__['_last'] = (startb, goalb, None if qc is None else qc.detach(), ow.detach(), eps)
+        if with_errors: return res[0], err, res[1], res[2].reshape(B, 1), res[3], res[4], qc, ow, eps
+        return res[0], err, res[1], qc, ow, eps
+    raw.square(self._pc, thb.get_device())
+    qc, ow, eps = raw.qc, raw.ow, raw.eps
+    self.__dict__['_last'] = (startb, goalb, qc, ow, eps)
+    if with_errors:
+      dth, err, eex, usg, ugp, uobs = _GNStepErrors.launch(self, raw, thb, startb, goalb, sdfb, out, None, None)[:6]
+      return dth, err, eex, usg.reshape(B, 1), ugp, uobs, qc, ow, eps
+    dth, err, eex = _GNStep.launch(self, raw, thb, startb, goalb, sdfb, out, None, None)[:3]
+    return dth, err, eex, qc, ow, eps
 
   def _eval_launch(self, thb, sdfb, startb, goalb, qc, ow, eps):
     """One dgp_eval_errors launch -> ([err, err_ext, start_goal_error, gp_error, obs_error] (None where a grid is needed and sdfb is
@@ -788,7 +971,7 @@ class PlanLayer(nn.Module):
     proto = self._err_protos.get((B, dtype, dev))
     if proto is None: proto = self._err_proto(B, dtype, dev, thc)
     outs = [torch.empty_like(proto) if w else None for w in (grid, grid, True, True, grid)]
-    _launch(dev, self._pc.eval_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:9], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(outs[4]), _raw_stream(dev))
+    _launch(dev, self._pc.eval_errors, solver.h, B, thc.data_ptr(), stc.data_ptr(), goc.data_ptr(), *sd[:7], *cv[:4], _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(outs[4]), _raw_stream(dev))
     return outs, thc, stc, goc, sd, cv
 
   def _eval(self, thb, sdfb, startb, goalb, qc, ow, eps):

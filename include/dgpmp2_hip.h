@@ -53,8 +53,7 @@ extern "C" {
 #define DGP_QC_PERSTATE 1   /* qc_inv (B, n-1, dof, dof): Q^-1 built as in gp_factor.py:65-73                       */
 #define DGP_QC_QFULL    2   /* qc_inv (B, n-1, d, d) is Q^-1 itself ('q_full', plan_layer.py:90)                    */
 #define DGP_QC_SCALAR   3   /* qc_inv (B, n-1): one scalar s_k per GP factor, Q_c^-1 = s_k * DgpConfig.Q_c_inv (diagonal) --      */
-                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] and their backward (g_qc_inv: the (B,n-1,dof,dof) gradient of the blocks s_k I;
-                               with DGP_COVS_SQUARED the (B,n-1) gradient of the raw scalars), n <= 256 */
+                            /* 'diag_identity' (diff_gpmp2_planner.py:255-258: q_k^2 I with Q_c_inv = I); dgp_gn_step[_errors] and their backward (g_qc_inv: the (B,n-1,dof,dof) gradient of the blocks s_k I), n <= 256 */
 
 /* Constructor arguments of PlanLayer / DiffGPMP2Planner that the math depends on
  * (plan_layer.py:14-81).  All lengths in the reference's units. */
@@ -120,24 +119,11 @@ typedef struct DgpSdf {
 } DgpSdf;
 
 /* Per-call covariance inputs = the three trailing arguments of PlanLayer.forward. */
-/* DgpCovs::flags */
-#define DGP_COVS_SQUARED 1u  /* the per-state SCALARS (qc_inv under DGP_QC_SCALAR, obs_w, eps) are the learn module's RAW outputs and are squared
-                                inside the kernel (in io_dtype, as torch's v * v): diff_gpmp2_planner.py:247-290 for single-link robots in the modes
-                                'fix_dynamics' / 'diag_identity' is exactly that.  The backward entry points then write dL/d(raw) = 2 raw dL/d(raw^2)
-                                into g_qc_inv (B,n-1) / g_obs_w / g_eps with the same row stride.  dgp_gn_step[_errors] and their backward only. */
 typedef struct DgpCovs {
   int32_t     qc_mode;       /* DGP_QC_*                                                                 */
   const void* qc_inv;        /* see DGP_QC_*; NULL iff DGP_QC_STATIC                                     */
   const void* obs_w;         /* obscov_inv_trajb (B,n,1,1) or NULL = static 1/cost_sigma^2               */
   const void* eps;           /* eps_trajb (B,n,1,1) or NULL = static epsilon_dist                        */
-  uint32_t    flags;         /* DGP_COVS_*                                                               */
-  int32_t     pad_;
-  int64_t     row_stride;    /* elements between consecutive trajectories' rows of the SCALAR inputs (qc_inv under DGP_QC_SCALAR, obs_w, eps) and of
-                                their gradients; 0 = dense ((n-1) / n / n).  The three pointers may then address one (B, row_stride) matrix -- the
-                                learn module's output `out[:, 0, :]` sliced at [0, n-1), [n-1, 2n-1), [2n-1, 3n-1) (diff_gpmp2_planner.py:255-283)   */
-  void *sq_qc_inv, *sq_obs_w, *sq_eps;   /* DGP_COVS_SQUARED, dgp_gn_step[_errors], optional: the squared tensors in the reference's shapes -- q_k^2 I blocks
-                                (B,n-1,dof,dof), (B,n), (B,n), dense -- written by the step kernel: what DiffGPMP2Planner.step returns as qc_inv_curr,
-                                obscov_inv_curr, eps_curr (diff_gpmp2_planner.py:211)                     */
 } DgpCovs;
 
 int         dgp_abi_version(void);
@@ -290,6 +276,20 @@ int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch,
                                 void* g_th, void* g_start, void* g_goal,
                                 void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies,
                                 void* g_qc_inv, void* g_obs_w, void* g_eps, void* workspace, void* stream);
+
+/* DiffGPMP2Planner.get_covariances for a single-link robot in the modes whose tensors are plain squares of the learn module's output (diff_gpmp2_planner.py:247-290,
+ * 'diag_identity' and 'fix_dynamics', with or without learned epsilons) as ONE small launch each way -- the reference spends some twenty tiny torch kernels on the
+ * slices, outer products, broadcasts and their backward, which cost as much as the solver once a training iteration is replayed from a HIP graph.
+ * raw (B, width): the module's output vector out[:, 0, :], column blocks [0, n_gp) one scalar q_k per GP factor (n_gp = n - 1: 'diag_identity'; 0: 'fix_dynamics'),
+ * [n_gp, n_gp + n) the raw obstacle weights o_i, [n_gp + n, n_gp + 2 n) the raw epsilons e_i (learn_eps != 0).  Outputs, every one optional, dense, io dtype of `dtype`:
+ *   sq_scalars (B, n_gp) = q_k^2 (what DGP_QC_SCALAR takes), sq_qc_inv (B, n_gp, dof, dof) = q_k^2 I (the tensor the reference returns), sq_obs_w (B, n) = o_i^2,
+ *   sq_eps (B, n) = e_i^2 -- the squares formed in the I/O type, as torch's v * v. */
+int dgp_square_covariances(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t num_states, int32_t learn_eps, int32_t dof,
+                           void* sq_scalars, void* sq_qc_inv, void* sq_obs_w, void* sq_eps, void* stream);
+/* Its backward: g_raw (B, width) = 2 raw * [trace of g_qc_inv's dof x dof blocks (the gradient dgp_gn_step_backward writes under DGP_QC_SCALAR) | g_obs_w | g_eps],
+ * zero in columns the mode does not consume; any gradient input may be NULL (= 0). */
+int dgp_square_covariances_backward(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t num_states, int32_t learn_eps, int32_t dof,
+                                    const void* g_qc_inv, const void* g_obs_w, const void* g_eps, void* g_raw, void* stream);
 
 /* Signed distance fields of a batch of occupancy images on the GPU: utils/sdf_utils.py:6-21 (sdf_2d) for every image of the batch --
  *   im = image > 0.75 (free space), padded by `padlen` pixels of free space on every side (:13-15),

@@ -44,6 +44,8 @@ def main():
   jobs.append(base + [os.path.join(CSRC, 'dgpmp2_hip.hip'), '-o', os.path.join(d, 'abi.o')])
   d = os.path.join(work, 'long'); os.makedirs(d)
   jobs.append(base + [os.path.join(CSRC, 'gn_long_inst.hip'), '-o', os.path.join(d, 'long.o')])      # the long-trajectory kernels (small: always built)
+  d = os.path.join(work, 'edt'); os.makedirs(d)
+  jobs.append(base + [os.path.join(CSRC, 'sdf_edt.hip'), '-o', os.path.join(d, 'edt.o')])       # dgp_sdf_2d (the binding resolves every declared symbol)
   stub = os.path.join(work, 'stubs.hip')
   with open(stub, 'w') as f:
     f.write('#include "%s"\n' % os.path.join(CSRC, 'gn_device.h'))

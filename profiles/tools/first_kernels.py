@@ -14,7 +14,7 @@ s = _capi.Solver(solver_config(num_states=n, dof=2, io_dtype=torch.float32))
 pc = _capi.get_pycall()
 dth = torch.empty_like(th0); err = torch.empty(B, device=dev); eex = torch.empty(B, device=dev); info = torch.zeros(B, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-def step(): pc.gn_step(s.h, B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf.data_ptr(), G, G, 0, 0, 0, None, 0, None, None, None, 0, 0, None, None, None, dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), st)
+def step(): pc.gn_step(s.h, B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf.data_ptr(), G, G, 0, 0, 0, None, 0, None, None, None, dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr(), st)
 bench.prewarm(lambda k: step())
 K = 20
 timer = _capi.KernelTimer(K)

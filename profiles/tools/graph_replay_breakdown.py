@@ -56,3 +56,17 @@ for static in (False, True):
     dth = pl.forward(thr,start,goal,None,sdfb,qc,ow,ep)[0]
     return torch.autograd.grad(dth, leaves, g)
   print('static' if static else 'learned', 'graph replay us: step %.1f  step+errors %.1f  step+bwd %.1f  iteration %.1f' % (wall(graphed(step_only)), wall(graphed(fwd_only)), wall(graphed(it_step)), wall(graphed(it))))
+# round 5: the reference's default learned mode (diag_identity) end to end -- the module output through get_covariances (tagged blocks -> DGP_QC_SCALAR) and handed to the kernels raw (DGP_COVS_SQUARED)
+lm_out = torch.cat([torch.ones(B,1,n-1,device=dev,dtype=f32), torch.full((B,1,n),100.0,device=dev,dtype=f32)], dim=2).requires_grad_(True)
+thr = th.clone().requires_grad_(True)
+def it_di():
+  qc_s, ow_s = planner.get_covariances(lm_out, 'diag_identity')
+  dth,_,_,sg,gp_,ob = pl.forward_with_errors(thr,start,goal,None,sdfb,qc_s,ow_s,None)
+  return torch.autograd.grad((dth,sg,gp_,ob), (thr,lm_out), (g,cws,cw,cw))
+def it_raw():
+  raw = pl.raw_covs(lm_out, 'diag_identity', False)
+  dth,_,_,sg,gp_,ob = pl.forward_raw(thr,start,goal,None,sdfb,raw,with_errors=True)[:6]
+  return torch.autograd.grad((dth,sg,gp_,ob), (thr,lm_out), (g,cws,cw,cw))
+def fwd_raw():
+  with torch.no_grad(): pl.forward_raw(thr,start,goal,None,sdfb,pl.raw_covs(lm_out.detach(), 'diag_identity', False),with_errors=True)
+print('diag_identity graph replay us: iteration via get_covariances %.1f  iteration raw module output %.1f  forward raw %.1f   eager: %.1f / %.1f' % (wall(graphed(it_di)), wall(graphed(it_raw)), wall(graphed(fwd_raw)), wall(it_di), wall(it_raw)))

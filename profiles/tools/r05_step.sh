@@ -24,5 +24,13 @@ for B in ('B4096', 'B32'):
       e = d[B][k][t]
       print(B, k, t, 'eager %.1f' % e['eager_us'], 'replay', e.get('hip_graph_replay_us'), e.get('grad_layout', ''), e.get('grad_bytes', ''), e.get('graph_error', ''))
 PY
+timeout 600 python profiles/tools/graph_replay_breakdown.py 2>/dev/null | tee "$O/graph_replay.txt"
 ( U="python profiles/tools/ubench.py"; $U --what bwd,bwd_sdf16,bwd_sdf16w,bwd_sdf8w --covs perstate; $U --what bwd,bwd_sdf,bwd_sparse --covs perstate --sdf persample; $U --what bwd,bwd_sdf16,bwd_sdf16w; $U --what bwd,bwd_sdf,bwd_sparse --sdf persample ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
 cat "$O/ubench.jsonl"
+cd /tmp && export TMPDIR=/tmp
+for w in shared per_sample; do
+  timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace_$w" -o trace -- python "$R/profiles/tools/train_iteration.py" --profile $w > "$O/trace_$w.log" 2>&1
+  for db in $(find "$O/trace_$w" -name '*_results.db'); do python "$R/profiles/tools/summarize_rocpd.py" "$db" "rocprofv3 --kernel-trace --stats -- python profiles/tools/train_iteration.py --profile $w" > "$O/train_iteration_trace_$w.txt" 2>&1; done
+  rm -rf "$O/trace_$w"
+  cut -c1-150 "$O/train_iteration_trace_$w.txt" | awk -F'|' 'NR<=12 {print $1, "|", $2, "|", $4}'
+done

@@ -18,7 +18,7 @@ dth = torch.empty_like(th0); err = torch.empty(B, device=dev); eex = torch.empty
 pc, hnd = _capi.get_pycall(), solver.h
 st = torch.cuda.current_stream(); raw = st.cuda_stream
 a = (th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sdf.data_ptr(), dth.data_ptr(), err.data_ptr(), eex.data_ptr(), info.data_ptr())
-def step(k=0): pc.gn_step(hnd, B, a[0], a[1], a[2], a[3], 256, 256, 0, 0, 0, None, 0, None, None, None, 0, 0, None, None, None, a[4], a[5], a[6], a[7], raw)
+def step(k=0): pc.gn_step(hnd, B, a[0], a[1], a[2], a[3], 256, 256, 0, 0, 0, None, 0, None, None, None, a[4], a[5], a[6], a[7], raw)
 Bn.prewarm(step, 0.6)
 sync = torch.cuda.synchronize
 reps = int(os.environ.get('REPS', 200)); K = 20

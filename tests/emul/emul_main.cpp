@@ -205,6 +205,31 @@ void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g,
 }  // namespace
 
 // Same entry points as include/dgpmp2_hip.h with the prefix emul_, on HOST pointers (stream ignored).
+template <typename T>
+static void emul_square(const T* raw, int B, int W, int n_gp, int n, int le, int dof, T* s, T* blk, T* ow, T* ep) {
+  for (int64_t b = 0; b < B; ++b)
+    for (int c = 0; c < W; ++c) {
+      const T v = raw[b * W + c];
+      const T q = v * v;
+      if (c < n_gp) {
+        if (s) s[b * n_gp + c] = q;
+        if (blk) for (int i = 0; i < dof * dof; ++i) blk[(b * n_gp + c) * dof * dof + i] = (i % (dof + 1) == 0) ? q : (T)0;
+      } else if (c < n_gp + n) { if (ow) ow[b * n + (c - n_gp)] = q; }
+      else if (le && c < n_gp + 2 * n) { if (ep) ep[b * n + (c - n_gp - n)] = q; }
+    }
+}
+template <typename T>
+static void emul_square_bwd(const T* raw, int B, int W, int n_gp, int n, int le, int dof, const T* gb, const T* gw, const T* ge, T* graw) {
+  for (int64_t b = 0; b < B; ++b)
+    for (int c = 0; c < W; ++c) {
+      T g = (T)0;
+      if (c < n_gp) { if (gb) for (int i = 0; i < dof; ++i) g += gb[(b * n_gp + c) * dof * dof + i * (dof + 1)]; }
+      else if (c < n_gp + n) { if (gw) g = gw[b * n + (c - n_gp)]; }
+      else if (le && c < n_gp + 2 * n) { if (ge) g = ge[b * n + (c - n_gp - n)]; }
+      graw[b * W + c] = (T)2 * raw[b * W + c] * g;
+    }
+}
+
 extern "C" {
 
 int emul_abi_version(void) { return DGP_ABI_VERSION; }
@@ -329,6 +354,20 @@ int emul_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t c
     for (int c = 0; c < copies; ++c) acc += partial_dtype == DGP_F64 ? ((const double*)partial)[(int64_t)c * elems + e] : (double)((const float*)partial)[(int64_t)c * elems + e];
     if (out_dtype == DGP_F64) ((double*)out)[e] = acc * scale; else ((float*)out)[e] = (float)(acc * scale);
   }
+  return DGP_OK;
+}
+
+int emul_square_covariances(const void* raw, int32_t dtype, int32_t B, int32_t W, int32_t n_gp, int32_t n, int32_t le, int32_t dof, void* s, void* blk, void* ow, void* ep, void*) {
+  if (!raw || B < 1 || W < n_gp + n * (le ? 2 : 1)) return DGP_EINVAL;
+  if (dtype == DGP_F64) emul_square<double>((const double*)raw, B, W, n_gp, n, le, dof, (double*)s, (double*)blk, (double*)ow, (double*)ep);
+  else emul_square<float>((const float*)raw, B, W, n_gp, n, le, dof, (float*)s, (float*)blk, (float*)ow, (float*)ep);
+  return DGP_OK;
+}
+int emul_square_covariances_backward(const void* raw, int32_t dtype, int32_t B, int32_t W, int32_t n_gp, int32_t n, int32_t le, int32_t dof, const void* gb, const void* gw,
+                                     const void* ge, void* graw, void*) {
+  if (!raw || !graw || B < 1 || W < n_gp + n * (le ? 2 : 1)) return DGP_EINVAL;
+  if (dtype == DGP_F64) emul_square_bwd<double>((const double*)raw, B, W, n_gp, n, le, dof, (const double*)gb, (const double*)gw, (const double*)ge, (double*)graw);
+  else emul_square_bwd<float>((const float*)raw, B, W, n_gp, n, le, dof, (const float*)gb, (const float*)gw, (const float*)ge, (float*)graw);
   return DGP_OK;
 }
 

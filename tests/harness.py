@@ -96,7 +96,9 @@ class Backend(object):
     return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
 
   # -- argument marshalling -------------------------------------------------------------------------
-  def _common(self, p, io, th, start, goal, sdf, qc, ow, eps, q_full):
+  def _common(self, p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw=None):
+    """raw = (out (B, W), n_gp, learn_eps): the covariances as a learn module's output vector, squared inside the kernels (DGP_COVS_SQUARED, row stride W);
+    qc / ow / eps must then be None."""
     self._keep = []
     B = th.shape[0]
     solver = _capi.Solver(config_from_oracle(p, io), api=self.api)
@@ -114,6 +116,21 @@ class Backend(object):
       sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
     mode = _capi.DGP_QC_STATIC if qc is None else (_capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE)
     if qc is not None and np.asarray(qc).ndim == 2: mode = _capi.DGP_QC_SCALAR      # (B, n-1) scalars: Q_c^-1 = s_k Q_c_inv (dgp_gn_step only)
+    if raw is not None:
+      # dgp_square_covariances: the squares the step takes (scalars, weights, epsilons) from the raw output vector, one launch
+      assert qc is None and ow is None and eps is None
+      out, n_gp, learn_eps = raw
+      out = np.asarray(out)
+      W, n = out.shape[1], th.shape[1]
+      _, o_p = self.to_dev(out, io)
+      s_t, s_p = self.empty((B, n_gp), io) if n_gp else (None, None)
+      b_t, b_p = self.empty((B, n_gp, p.dof, p.dof), io) if n_gp else (None, None)
+      w_t, w_p = self.empty((B, n), io)
+      e_t, e_p = self.empty((B, n), io) if learn_eps else (None, None)
+      self.api.check(self.api.square_covariances(o_p, _capi.DGP_F64 if io == 'f64' else _capi.DGP_F32, B, W, n_gp, n, int(learn_eps), p.dof, s_p, b_p, w_p, e_p, self.stream()))
+      self._raw = (o_p, W, n_gp, n, int(learn_eps), p.dof, b_t)
+      covs = solver.covs_arg(_capi.DGP_QC_SCALAR if n_gp else _capi.DGP_QC_STATIC, s_p, w_p, e_p)
+      return solver, B, th_p, st_p, go_p, sdf_arg, covs
     _, qc_p = self.to_dev(qc, io)
     _, ow_p = self.to_dev(ow, io)
     _, eps_p = self.to_dev(eps, io)
@@ -156,9 +173,9 @@ class Backend(object):
     return out
 
   # -- entry points ------------------------------------------------------------------------------------
-  def step(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+  def step(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64', raw=None):
     """-> dtheta (B,n,d), err (B,), err_ext (B,), info (B,)"""
-    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw)
     dth, dth_p = self.empty(th.shape, io)
     err, err_p = self.empty((B,), io)
     eex, eex_p = self.empty((B,), io)
@@ -186,10 +203,23 @@ class Backend(object):
     solver.eval_errors(B, th_p, st_p, go_p, sdf_arg, covs, *[o[1] for o in outs], stream=self.stream())
     return tuple(self.to_np(o[0]) for o in outs)
 
+  def _raw_grad_bufs(self, B, io):
+    """gradient buffers of the squared tensors for a backward launch in raw mode -> (g_blocks, g_ow, g_eps) (array, address) pairs"""
+    o_p, W, n_gp, n, le, dof, _ = self._raw
+    return (self.empty((B, n_gp, dof, dof), io) if n_gp else (None, None), self.empty((B, n), io), self.empty((B, n), io) if le else (None, None))
+
+  def _raw_grad_out(self, B, io, bufs):
+    """dgp_square_covariances_backward: the gradients of the squared tensors -> d/d out (B, W)"""
+    o_p, W, n_gp, n, le, dof, _ = self._raw
+    g, g_p = self.empty((B, W), io)
+    self.api.check(self.api.square_covariances_backward(o_p, _capi.DGP_F64 if io == 'f64' else _capi.DGP_F32, B, W, n_gp, n, le, dof, bufs[0][1], bufs[1][1], bufs[2][1],
+                                                       g_p, self.stream()))
+    return self.to_np(g)
+
   def backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, qc=None, ow=None, eps=None, q_full=False, io='f64',
-               sdf_copies=1, sdf_grad='dense'):
-    """-> dict of gradients: th, start, goal, sdf, qc, ow, eps (numpy fp64)"""
-    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+               sdf_copies=1, sdf_grad='dense', raw=None):
+    """-> dict of gradients: th, start, goal, sdf, qc, ow, eps (numpy fp64); raw: `out` = the gradient of the raw output vector instead of qc / ow / eps"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw)
     n = th.shape[1]
     _, dth_p = self.to_dev(dtheta, io)
     _, gd_p = self.to_dev(g_dtheta, io)
@@ -202,10 +232,14 @@ class Backend(object):
     gqc, gqc_p = self.empty(qshape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
+    bufs = None
+    if raw is not None:
+      bufs = self._raw_grad_bufs(B, io)
+      gqc_p, gow_p, gep_p = bufs[0][1], bufs[1][1], bufs[2][1]
     solver.gn_step_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, ge_p, gth_p, gst_p, ggo_p, gsdf_p, stride, gqc_p, gow_p,
                             gep_p, self.stream(), g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs), qc=self.to_np(gqc),
-                ow=self.to_np(gow), eps=self.to_np(gep))
+                ow=self.to_np(gow), eps=self.to_np(gep), out=None if bufs is None else self._raw_grad_out(B, io, bufs))
 
   def eval_backward(self, p, th, start, goal, sdf, g_err_ext=None, g_unw_sg=None, g_unw_gp=None, g_unw_obs=None, eps=None, io='f64', sdf_copies=1,
                     want_sdf=True, sdf_grad='dense'):
@@ -254,9 +288,9 @@ class Backend(object):
                              g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs))
 
-  def step_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64'):
+  def step_errors(self, p, th, start, goal, sdf, qc=None, ow=None, eps=None, q_full=False, io='f64', raw=None):
     """dgp_gn_step_errors -> dtheta, err, err_ext, info, unw_sg, unw_gp, unw_obs (the last three at th + dtheta)"""
-    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw)
     dth, dth_p = self.empty(th.shape, io)
     outs = [self.empty((B,), io) for _ in range(5)]
     info, info_p = self.empty((B,), dtype=np.int32)
@@ -264,9 +298,9 @@ class Backend(object):
     return (self.to_np(dth), self.to_np(outs[0][0]), self.to_np(outs[1][0]), self.to_np(info)) + tuple(self.to_np(o[0]) for o in outs[2:])
 
   def step_errors_backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, qc=None, ow=None, eps=None,
-                           q_full=False, io='f64', sdf_copies=1, sdf_grad='dense'):
-    """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps"""
-    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full)
+                           q_full=False, io='f64', sdf_copies=1, sdf_grad='dense', raw=None):
+    """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps (raw: `out`)"""
+    solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw)
     n = th.shape[1]
     _, dth_p = self.to_dev(dtheta, io)
     _, gd_p = self.to_dev(g_dtheta, io)
@@ -276,11 +310,16 @@ class Backend(object):
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
     errs = any(c is not None for c in (g_unw_sg, g_unw_gp, g_unw_obs))
     gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n, passes=2 if errs else 1)
-    gqc, gqc_p = self.empty(np.asarray(qc).shape, io) if qc is not None else (None, None)
+    qshape = None if qc is None else (np.asarray(qc).shape if np.asarray(qc).ndim != 2 else np.asarray(qc).shape + (p.dof, p.dof))      # DGP_QC_SCALAR: the gradient of the blocks s_k I
+    gqc, gqc_p = self.empty(qshape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)
     gep, gep_p = self.empty((B, n), io) if eps is not None else (None, None)
     ws, ws_p = self.empty(th.shape, io)
+    bufs = None
+    if raw is not None:
+      bufs = self._raw_grad_bufs(B, io)
+      gqc_p, gow_p, gep_p = bufs[0][1], bufs[1][1], bufs[2][1]
     solver.gn_step_errors_backward(B, th_p, st_p, go_p, sdf_arg, covs, dth_p, gd_p, cot[0], cot[1], cot[2], cot[3], gth_p, gst_p, ggo_p, gsdf_p, stride,
                                    gqc_p, gow_p, gep_p, ws_p, self.stream(), g_sdf_copies=sdf_copies)
     return dict(th=self.to_np(gth), start=self.to_np(gst), goal=self.to_np(ggo), sdf=self._gsdf_out(gs), qc=self.to_np(gqc), ow=self.to_np(gow),
-                eps=self.to_np(gep))
+                eps=self.to_np(gep), out=None if bufs is None else self._raw_grad_out(B, io, bufs))

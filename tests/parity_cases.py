@@ -867,6 +867,65 @@ def case_sdf_gradient_delivery(be, golden, io):
 ALL_CASES.append(case_sdf_gradient_delivery)
 
 
+def case_raw_squared_covariances(be, golden, io):
+  """dgp_square_covariances / dgp_square_covariances_backward (round 5): the learn module's raw output vector as covariance input -- one scalar q_k per GP factor
+  ('diag_identity': q_k^2 I), raw obstacle weights o_i, raw epsilons e_i, squared by one small launch into the tensors the step takes (diff_gpmp2_planner.py:247-290 for
+  a single-link robot) -- against the same step with the squares formed by the caller (DGP_QC_SCALAR + per-state tensors): the forward bit for bit, the backward's
+  d/d out = 2 out d/d(out^2).  'fix_dynamics' (static Q_c_inv, n_gp = 0) with and without learned epsilons, trailing unused columns (zero gradient), and the training
+  iteration's single-launch backward."""
+  g = golden('g7_errors')
+  B, n = g['th'].shape[:2]
+  p = P2d(n)
+  G = int(g['G'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  th, st, go, sdf = rnd(g['th'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io)
+  rs = np.random.RandomState(17)
+  npdt = np.float64 if io == 'f64' else np.float32
+  gd = rnd(rs.randn(B, n, 4), io)
+  cs, cg, co, ce = rnd(g['c_sg'], io).reshape(B), rnd(g['c_gp'], io).reshape(B), rnd(g['c_obs'], io).reshape(B), rnd(g['c_ee'], io).reshape(B)
+  for n_gp, learn_eps, extra in ((n - 1, True, 0), (n - 1, False, 3), (0, True, 0), (0, False, 0)):
+    W = n_gp + n * (2 if learn_eps else 1) + extra
+    out = np.concatenate([rs.uniform(0.6, 1.4, (B, n_gp)) * rs.choice([-1.0, 1.0], (B, n_gp)),            # raw q_k (signs: only the square enters)
+                          rs.uniform(60.0, 140.0, (B, n)) * rs.choice([-1.0, 1.0], (B, n)),               # raw o_i (weights ~ 1e4)
+                          rs.uniform(0.4, 0.8, (B, n * (1 if learn_eps else 0) + extra))], 1)              # raw e_i (eps ~ 0.16 .. 0.64) [+ unused columns]
+    out = rnd(out, io)
+    sq = (out.astype(npdt) * out.astype(npdt)).astype(np.float64)                                          # the squares as torch forms them, in the I/O type
+    qc = sq[:, :n_gp] if n_gp else None
+    ow = sq[:, n_gp:n_gp + n]
+    eps = sq[:, n_gp + n:n_gp + 2 * n] if learn_eps else None
+    raw = (out, n_gp, learn_eps)
+    a = be.step(p, th, st, go, sdf, raw=raw, io=io)
+    b = be.step(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
+    for x, y in zip(a, b): assert np.array_equal(x, y)
+    assert np.all(a[3] == 0)
+    ra = be.backward(p, th, st, go, sdf, a[0], gd, ce, raw=raw, io=io)
+    rb = be.backward(p, th, st, go, sdf, a[0], gd, ce, qc=qc, ow=ow, eps=eps, io=io)
+    tol = 1e-13 if io == 'f64' else 3e-6
+    for k in ('th', 'start', 'goal'): assert np.array_equal(ra[k], rb[k]), k
+    assert rel_err(ra['sdf'], rb['sdf']) < (1e-12 if io == 'f64' else 2e-5)
+
+    def expect(r):
+      parts = []
+      if n_gp: parts.append(2.0 * out[:, :n_gp] * np.einsum('bkii->bk', r['qc']))                         # the blocks' gradient -> the scalar's: trace (Q_c_inv = I)
+      parts.append(2.0 * out[:, n_gp:n_gp + n] * r['ow'])
+      if learn_eps: parts.append(2.0 * out[:, n_gp + n:n_gp + 2 * n] * r['eps'])
+      return np.concatenate(parts, 1)
+    used = W - extra
+    assert np.all(ra['out'][:, used:] == 0.0)
+    assert rel_err(ra['out'][:, :used], expect(rb)) < tol, (n_gp, learn_eps, rel_err(ra['out'][:, :used], expect(rb)))
+    # the training iteration: forward and the single-launch backward
+    ea = be.step_errors(p, th, st, go, sdf, raw=raw, io=io)
+    eb = be.step_errors(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
+    for x, y in zip(ea, eb): assert np.array_equal(x, y)
+    fa = be.step_errors_backward(p, th, st, go, sdf, ea[0], gd, ce, cs, cg, co, raw=raw, io=io)
+    fb = be.step_errors_backward(p, th, st, go, sdf, ea[0], gd, ce, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io)
+    for k in ('th', 'start', 'goal'): assert np.array_equal(fa[k], fb[k]), k
+    assert rel_err(fa['out'][:, :used], expect(fb)) < tol, (n_gp, learn_eps, 'iteration', rel_err(fa['out'][:, :used], expect(fb)))
+
+
+ALL_CASES.append(case_raw_squared_covariances)
+
+
 def case_long_trajectories(be, golden, io, configs=None):
   """n > 256 (gn_long.h: one trajectory per wavefront, ceil(n / 64) rows per lane in a loop, interior state parked in LDS): the reference
   accepts any total_time_step (plan_layer.py:30).  Every entry point -- step, the fused loop, the error evaluation, both backward kernels --

@@ -112,10 +112,12 @@ def test_hip_every_scaled_kernel_vs_c_oracle(be, dof, io, monkeypatch):
         bad.append(('dof %d %s shape (%d,%d) n %d' % (dof, io, lpt, c, n), e, ee, ex))
       # ... and the 36 backward kernels of the same variant against the Kronecker kernels on the dense blocks (themselves pinned to the autograd oracle above)
       gb = PC.rnd(rs.randn(B, n, 2 * dof), io); ge = PC.rnd(rs.randn(B), io)
-      r1 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=s_, ow=ow, eps=eps, io=io)
-      r2 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=PC.rnd(dense, io), ow=ow, eps=eps, io=io)
+      # (fp32 I/O: the grid gradient accumulated in FLOAT64 grids, DGP_GSDF_DENSE_F64 -- what PlanLayer uses for a shared grid since round 5: the sum no longer depends on
+      #  the order the fp32 atomics land in, so it is compared like every other gradient -- rounds 3-4 skipped it)
+      gm = 'f64' if io == 'f32' else 'dense'
+      r1 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=s_, ow=ow, eps=eps, io=io, sdf_grad=gm)
+      r2 = be.backward(p, th, start, goal, sdf, dth, gb, ge, qc=PC.rnd(dense, io), ow=ow, eps=eps, io=io, sdf_grad=gm)
       for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
-        if key == 'sdf' and io == 'f32': continue      # accumulated in fp32 IN MEMORY by atomics, in an order that differs from launch to launch: not a code-generation signal (as in the stress run)
         # (the grid gradient is a sum of signed tap contributions accumulated by atomics: judged against the size of the summands, for which the trajectory gradient stands in)
         scale = max(np.abs(r2[key]).max(), np.abs(r2['th']).max() if key == 'sdf' else 0.0, (1e-300 if io == 'f64' else 1e-6 * np.abs(r2['th']).max()))
         eb = np.abs(r1[key] - r2[key]).max() / scale if np.all(np.isfinite(r1[key])) else np.inf
@@ -147,13 +149,12 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
       dth = be.step(p, th, start, goal, sdf, **kw)[0]
       gbar = PC.rnd(rs.randn(B, n, d), io); gext = PC.rnd(rs.randn(B), io)
       copies = 16 if (lpt + c) % 3 == 0 else 1
-      g_h = be.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, **kw)
+      g_h = be.backward(p, th, start, goal, sdf, PC.rnd(dth, io), gbar, gext, sdf_copies=copies, sdf_grad='f64' if io == 'f32' else 'dense', **kw)      # (fp32 I/O: float64 grids, see the scaled-kernel test)
       g_o = AT.step_gradients(p, th, start, goal, sdf, gbar, gext, qc=qc, ow=ow, eps=eps, q_full=q_full)
       tag = 'dof %d %s shape (%d,%d) n %d cov %s' % (dof, io, lpt, c, n, cov)
       if not PC.rel_err(dth, g_o['dtheta']) < PC.TOL[io]: bad.append((tag, 'dtheta', PC.rel_err(dth, g_o['dtheta'])))
       for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'):
         if g_h[key] is None: continue
-        if key == 'sdf' and io == 'f32': continue      # accumulated in fp32 in memory by atomics: order-dependent cancellation noise, not a code-generation signal
         a_ = g_h[key]
         if key == 'sdf' and copies > 1: a_ = a_.sum(0, keepdims=True)
         b_ = g_o[key].reshape(a_.shape)
@@ -193,19 +194,19 @@ def test_hip_every_chain_backward_kernel(be, dof, io, monkeypatch):
       if B > 1 and not (its.min() == 1 and its.max() > 1): bad.append((tag, 'iteration counts', its.tolist())); continue
       gbar = PC.rnd(rs.randn(B, n, 2 * dof), io)
       copies = 16 if (lpt + c) % 3 == 0 else 1
-      r = be.solve_backward(p, start, goal, sdf, K, hist, tho, its, gbar, io=io, sdf_copies=copies)
+      gm = 'f64' if io == 'f32' else 'dense'      # (fp32 I/O: float64 grids, see the scaled-kernel test)
+      r = be.solve_backward(p, start, goal, sdf, K, hist, tho, its, gbar, io=io, sdf_copies=copies, sdf_grad=gm)
       gcur = gbar.copy()
       acc = dict(start=np.zeros_like(start), goal=np.zeros_like(goal), sdf=np.zeros_like(sdf))
       for k in range(K - 1, -1, -1):
         on = its > k
         thk = np.where(on[:, None, None], np.nan_to_num(hist[k]), tho)
         nxt = np.where((its > k + 1)[:, None, None], np.nan_to_num(hist[min(k + 1, K - 1)]), tho)
-        one = be.backward(p, thk, start, goal, sdf, nxt - thk, gcur * on[:, None, None], None, io='f64' if io == 'f64' else io)
+        one = be.backward(p, thk, start, goal, sdf, nxt - thk, gcur * on[:, None, None], None, io='f64' if io == 'f64' else io, sdf_grad=gm)
         gcur = gcur + one['th'] * on[:, None, None]
         acc['start'] += one['start'] * on[:, None, None]; acc['goal'] += one['goal'] * on[:, None, None]; acc['sdf'] += one['sdf']
       for key, a_, b_ in (('th', r['th'], gcur), ('start', r['start'], acc['start']), ('goal', r['goal'], acc['goal']),
                           ('sdf', r['sdf'].sum(0, keepdims=True) if copies > 1 else r['sdf'], acc['sdf'])):
-        if key == 'sdf' and io == 'f32': continue
         if not np.all(np.isfinite(a_)): bad.append((tag, key, 'non-finite')); continue
         eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(gcur).max() if key == 'sdf' else 0.0, 1e-300)
         # f32 I/O: the hand-walked chain rounds th_k, dtheta_k and the running cotangent to fp32 between the launches, the chain kernel keeps them in fp64

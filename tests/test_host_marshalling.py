@@ -29,8 +29,9 @@ class FakePycall(object):
     return f
 
   def __getattr__(self, name):
-    n = {'gn_step': 26, 'gn_solve': 30, 'eval_errors': 27, 'gn_step_backward': 34, 'eval_errors_backward': 33, 'gn_solve_traced': 31,
-         'gn_solve_backward': 23, 'gn_step_errors': 29, 'gn_step_errors_backward': 38, 'sum_partial_grids': 8}[name]
+    n = {'gn_step': 21, 'gn_solve': 25, 'eval_errors': 22, 'gn_step_backward': 29, 'eval_errors_backward': 28, 'gn_solve_traced': 26,
+         'gn_solve_backward': 23, 'gn_step_errors': 24, 'gn_step_errors_backward': 33, 'sum_partial_grids': 8, 'square_covariances': 13,
+         'square_covariances_backward': 13}[name]
     return self._rec(name, n)
 
 
@@ -66,8 +67,8 @@ def test_forward_static_shared_grid_arguments(layer):
   h = layer._solvers[torch.float32].h
   assert a[0] == h and a[1] == 3 and a[2:5] == (th.data_ptr(), st.data_ptr(), go.data_ptr())
   assert a[5:12] == (sdf.data_ptr(), 8, 10, 0, _capi.DGP_SDF_ROWMAJOR, 0, None)  # shared grid: stride 0; the seven DgpSdf fields
-  assert a[12:21] == (_capi.DGP_QC_STATIC, None, None, None, 0, 0, None, None, None)      # the nine DgpCovs fields
-  assert a[21:25] == (dth.data_ptr(), err.data_ptr(), eex.data_ptr(), layer.last_info.data_ptr()) and a[25] == 77
+  assert a[12:16] == (_capi.DGP_QC_STATIC, None, None, None)                      # the four DgpCovs fields
+  assert a[16:20] == (dth.data_ptr(), err.data_ptr(), eex.data_ptr(), layer.last_info.data_ptr()) and a[20] == 77
   assert dth.shape == th.shape and err.shape == (3, 1, 1) and eex.shape == (3, 1, 1) and layer.last_info.dtype == torch.int32
   assert dth.grad_fn is None                                                     # nothing requires grad: no autograd node
 
@@ -140,11 +141,11 @@ def test_per_state_covariances_and_backward_arguments(layer):
   (dth.sum() + eex.sum()).backward()
   name, b = layer._pc.calls[-1]
   assert name == 'gn_step_backward'
-  assert b[:21] == a[:21]                                                         # same inputs as the forward launch (a small dense per-sample gradient: grad_mode DGP_GSDF_DENSE)
-  assert b[21] == dth.data_ptr() and b[22] is not None and b[23] is not None     # dtheta, both cotangents
-  assert b[24] is not None and b[25] is None and b[26] is None                   # g_th only (start / goal do not require grad)
-  assert b[27] is not None and b[28] == 80 and b[29] == 1                        # per-sample SDF gradient: stride H*W, one copy
-  assert b[30] is not None and b[31] is not None and b[32] is None and b[33] == 77   # g_qc, g_ow, no g_eps; stream
+  assert b[:16] == a[:16]                                                         # same inputs as the forward launch (a small dense per-sample gradient: grad_mode DGP_GSDF_DENSE)
+  assert b[16] == dth.data_ptr() and b[17] is not None and b[18] is not None     # dtheta, both cotangents
+  assert b[19] is not None and b[20] is None and b[21] is None                   # g_th only (start / goal do not require grad)
+  assert b[22] is not None and b[23] == 80 and b[24] == 1                        # per-sample SDF gradient: stride H*W, one copy
+  assert b[25] is not None and b[26] is not None and b[27] is None and b[28] == 77   # g_qc, g_ow, no g_eps; stream
   assert th.grad.shape == th.shape and sdfb.grad.shape == sdfb.shape and qc.grad.shape == qc.shape and ow.grad.shape == ow.shape
   assert eps.grad is None
 
@@ -157,12 +158,12 @@ def test_shared_grid_gradient_uses_partial_copies(layer):
   dth.sum().backward()
   name, b = layer._pc.calls[-1]
   name, b = layer._pc.calls[-2]                                                  # (the last call sums the partial copies)
-  assert name == 'gn_step_backward' and b[22] is not None and b[23] is None     # err_ext unused: no cotangent materialised
-  assert b[24] is None and b[27] is not None and b[28] == 0 and b[29] == PL._SDF_GRAD_COPIES
+  assert name == 'gn_step_backward' and b[17] is not None and b[18] is None     # err_ext unused: no cotangent materialised
+  assert b[19] is None and b[22] is not None and b[23] == 0 and b[24] == PL._SDF_GRAD_COPIES
   assert b[10] == _capi.DGP_GSDF_DENSE_F64 and b[11] is None                     # double partial grids whatever the I/O type
   name, c = layer._pc.calls[-1]
   # sdfb = sdf.expand(...) of a (1,1,H,W) tensor: the node differentiates w.r.t. the BASE (no B-fold sum in autograd's ExpandBackward): unscaled sum of the copies
-  assert name == 'sum_partial_grids' and c[0] == b[27] and c[1:5] == (_capi.DGP_F64, PL._SDF_GRAD_COPIES, 80, 1.0) and c[6] == _capi.DGP_F32 and c[7] == 77
+  assert name == 'sum_partial_grids' and c[0] == b[22] and c[1:5] == (_capi.DGP_F64, PL._SDF_GRAD_COPIES, 80, 1.0) and c[6] == _capi.DGP_F32 and c[7] == 77
   assert sdf.grad.shape == sdf.shape
   # an expanded view whose base is not a (1,1,H,W) tensor: B equal shares for autograd's expand-backward to sum
   flat = torch.randn(8, 10, requires_grad=True)
@@ -181,7 +182,7 @@ def test_per_sample_grid_gradient_as_sparse_taps(layer):
   dth, err, eex = layer(th, st, go, None, sdfb, None, None, None)
   dth.sum().backward()
   name, b = layer._pc.calls[-1]
-  assert name == 'gn_step_backward' and b[10] == _capi.DGP_GSDF_SPARSE and b[11] is not None and b[27] is not None and b[28] == 80 and b[29] == 1
+  assert name == 'gn_step_backward' and b[10] == _capi.DGP_GSDF_SPARSE and b[11] is not None and b[22] is not None and b[23] == 80 and b[24] == 1
   assert sdfb.grad.is_sparse and sdfb.grad.shape == sdfb.shape and sdfb.grad._nnz() == B * n * 4 and sdfb.grad._indices().data_ptr() == b[11]
   # 'auto' keeps the reference's dense layout for a small gradient ...
   layer.sdf_grad = 'auto'
@@ -215,16 +216,16 @@ def test_error_helpers_arguments(layer):
   layer(th, st, go, None, sdf, None, None, eps)
   e = layer.error_batch(th, sdf)
   name, a = layer._pc.calls[-1]
-  assert name == 'eval_errors' and a[15] == eps.data_ptr() and a[21] == e.data_ptr() and e.grad_fn is None
+  assert name == 'eval_errors' and a[15] == eps.data_ptr() and a[16] == e.data_ptr() and e.grad_fn is None
   g = layer.gp_error(th)
   name, a = layer._pc.calls[-1]
-  assert a[5] is None and a[21] is None and a[22] is None and a[25] is None and a[24] == g.data_ptr()    # no grid: none of the outputs that read it
+  assert a[5] is None and a[16] is None and a[17] is None and a[20] is None and a[19] == g.data_ptr()    # no grid: none of the outputs that read it
   sg, gp, ob = layer.unweighted_errors(th.clone().requires_grad_(True), sdf)
   assert sg.shape == (B, 1) and gp.shape == (B, 1, 1) and ob.requires_grad
   (sg.sum() + ob.sum()).backward()
   name, b = layer._pc.calls[-1]
-  assert name == 'eval_errors_backward' and b[21] is None and b[22] is not None and b[23] is None and b[24] is not None
-  assert b[25] is not None and b[28] is None and b[31] is not None              # g_th, no SDF gradient, g_eps (the current eps carries a graph)
+  assert name == 'eval_errors_backward' and b[16] is None and b[17] is not None and b[18] is None and b[19] is not None
+  assert b[20] is not None and b[23] is None and b[26] is not None              # g_th, no SDF gradient, g_eps (the current eps carries a graph)
   assert eps.grad is not None and eps.grad.shape == eps.shape
 
 
@@ -240,11 +241,12 @@ def test_input_validation(layer):
 
 def test_real_trampoline_argument_counts():
   pc = _capi.get_pycall()
-  for name, n in (('gn_step', 26), ('gn_solve', 30), ('eval_errors', 27), ('gn_step_backward', 34), ('eval_errors_backward', 33), ('sum_partial_grids', 8)):
+  for name, n in (('gn_step', 21), ('gn_solve', 25), ('eval_errors', 22), ('gn_step_backward', 29), ('eval_errors_backward', 28), ('sum_partial_grids', 8),
+                  ('square_covariances', 13), ('square_covariances_backward', 13)):
     with pytest.raises(TypeError):
       getattr(pc, name)(*([0] * (n - 1)))
   # a NULL handle comes back as the C-ABI's DGP_EINVAL, not as a crash
-  assert pc.gn_step(0, 1, 0, 0, 0, 0, 2, 2, 0, 0, 0, None, 0, None, None, None, 0, 0, None, None, None, 0, 0, 0, 0, 0) == _capi.DGP_EINVAL
+  assert pc.gn_step(0, 1, 0, 0, 0, 0, 2, 2, 0, 0, 0, None, 0, None, None, None, 0, 0, 0, 0, 0) == _capi.DGP_EINVAL
   assert b'null' in _capi.get_api().last_error()
 
 

@@ -44,6 +44,8 @@ def test_emul_step_errors(be, golden): PC.case_step_errors(be, golden, 'f64')
 def test_emul_step_errors_f32(be, golden): PC.case_step_errors(be, golden, 'f32')
 def test_emul_sdf_gradient_delivery(be, golden): PC.case_sdf_gradient_delivery(be, golden, 'f64')
 def test_emul_sdf_gradient_delivery_f32(be, golden): PC.case_sdf_gradient_delivery(be, golden, 'f32')
+def test_emul_raw_squared_covariances(be, golden): PC.case_raw_squared_covariances(be, golden, 'f64')
+def test_emul_raw_squared_covariances_f32(be, golden): PC.case_raw_squared_covariances(be, golden, 'f32')
 
 
 # ---- launch shapes: LPT lanes per trajectory x C states per lane (local block elimination + PCR over the lanes)

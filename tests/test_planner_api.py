@@ -717,6 +717,82 @@ def test_learned_covariance_modes(golden, mode, learn_eps):
   assert gw is not None and bool(torch.isfinite(gw).all()) and float(gw.abs().max()) > 0
 
 
+@pytest.mark.parametrize('mode,learn_eps,dtype', [('diag_identity', False, torch.float64), ('diag_identity', True, torch.float32), ('fix_dynamics', True, torch.float64),
+                                                  ('fix_dynamics', False, torch.float32)])
+def test_step_takes_the_module_output_raw_and_matches_get_covariances(golden, mode, learn_eps, dtype):
+  """planner.step() / step_with_errors() in 'diag_identity' / 'fix_dynamics' hand the learn module's output vector to the kernels (DGP_COVS_SQUARED: squared there,
+  d/d out written by the backward kernel) -- against the explicit route through get_covariances (diff_gpmp2_planner.py:247-290) + PlanLayer.forward: same update,
+  errors, returned covariance tensors and parameter gradients; a cotangent on the returned tensors themselves is chained too."""
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  from dgpmp2_amd.gpmp2 import plan_layer as PLm
+  g = golden('g2_system_n16')
+  B, n = 3, 16
+  gp, ob, pp, op, ev = ref_params(n)
+  n_gp = {'fix_dynamics': 0, 'diag_identity': n - 1}[mode]
+  out_dim = n_gp + n + (n if learn_eps else 0)
+  lp = {'model': {'type': 'feed_forward'}, 'dgpmp2': {'learn_eps': learn_eps, 'sdf_predict': False, 'dtheta_predict': False,
+                                                     'dynamics_mode': mode, 'fixed_conv': False}, 'data': {'im_size': 64}}
+  fcn = _FcnStub(out_dim).to(DEV).to(dtype)
+  with torch.no_grad():
+    fcn.w[n_gp:n_gp + n] *= 70.0                              # obstacle weights o^2 ~ 1e3 .. 1e4
+    if learn_eps: fcn.w[n_gp + n:] *= 0.6
+  planner = DiffGPMP2Planner(gp, ob, pp, op, ev, PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n), learn_params=lp,
+                             batch_size=B, use_cuda=True, learn_module_conv=_ConvStub(), learn_module_fcn=fcn)
+  pl = planner.plan_layer
+  G = int(g['G'])
+  sdf = T(O.circles_sdf(G, g['circles']), dtype)[None, None].expand(B, 1, G, G)
+  im = (sdf > 0).to(dtype)
+  th, st, go = T(g['th'], dtype), T(g['start'], dtype), T(g['goal'], dtype)
+  gd = torch.randn(B, n, 4, device=DEV, dtype=dtype, generator=torch.Generator(device=DEV).manual_seed(3))
+  tol = 1e-11 if dtype is torch.float64 else 2e-5
+
+  def loss(dth, eex, sg, gp_, ob_, qc, ow, eps, with_cov):
+    l = (dth * gd).sum() + 2.0 * eex.sum() + 3.0 * sg.sum() + 5.0 * gp_.sum() + 7.0 * ob_.sum()
+    if with_cov: l = l + 1e-6 * (ow * ow).sum() + (0.1 * (qc * qc).sum() if qc.requires_grad else 0.0) + (0.3 * eps.sum() if eps.requires_grad else 0.0)
+    return l
+
+  def explicit(with_cov):       # the reference's route: module output -> get_covariances -> tensors into the layer
+    thr = th.clone().requires_grad_(True)
+    conv_out, _ = planner.learn_module_conv(im)
+    out = fcn(thr, conv_out)
+    r = planner.get_covariances(out, mode, learn_eps)
+    if mode == 'fix_dynamics':
+      ow, eps = (r if learn_eps else (r, None)); qc = planner._static_view(planner.qc_inv_traj, B, thr)
+    else:
+      qc, ow = r[0], r[1]; eps = r[2] if learn_eps else None
+    if eps is None: eps = planner._static_view(planner.eps_traj, B, thr)
+    dth, err, eex, sg, gp_, ob_ = pl.forward_with_errors(thr, st, go, im, sdf, qc, ow, eps)
+    gw, gt = torch.autograd.grad(loss(dth, eex, sg, gp_, ob_, qc, ow, eps, with_cov), (fcn.w, thr))
+    return dth.detach(), err, eex.detach(), sg.detach(), ob_.detach(), qc.detach(), ow.detach(), eps.detach(), gw, gt
+
+  def raw(with_cov, fused):
+    thr = th.clone().requires_grad_(True)
+    if fused:
+      (dth, _, err, eex, qc, ow, eps), (sg, gp_, ob_) = planner.step_with_errors(thr, st, go, im, sdf)
+    else:
+      dth, _, err, eex, qc, ow, eps = planner.step(thr, st, go, im, sdf)
+      sg, gp_, ob_ = planner.unweighted_errors_batch(thr + dth, sdf)
+    gw, gt = torch.autograd.grad(loss(dth, eex, sg.reshape(B, 1), gp_, ob_, qc, ow, eps, with_cov), (fcn.w, thr))
+    return dth.detach(), err, eex.detach(), sg.detach().reshape(B, 1), ob_.detach(), qc.detach(), ow.detach(), eps.detach(), gw, gt
+
+  calls = []
+  orig = pl.forward_raw
+  pl.forward_raw = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+  for with_cov in (False, True):
+    e = explicit(with_cov)
+    for fused in (True, False):
+      r = raw(with_cov, fused)
+      for i, (a_, b_) in enumerate(zip(r, e)):
+        assert a_.shape == b_.shape or a_.numel() == b_.numel(), i
+        assert rel_err(a_.double().cpu().numpy().reshape(-1), b_.double().cpu().numpy().reshape(-1)) < (tol if i < 8 else 50 * tol), (with_cov, fused, i)
+  assert len(calls) == 4                                       # the raw route really ran
+  # without a graph: same numbers
+  with torch.no_grad():
+    d0 = planner.step(th, st, go, im, sdf)[0]
+  assert rel_err(d0.double().cpu().numpy(), e[0].double().cpu().numpy()) < tol
+
+
 def PC_P2d(n):
   return O.OracleParams(dof=2, total_time_step=n - 1)
 
