@@ -290,12 +290,12 @@ def extra_workloads(device, stream, reps=1500):
   B, n = B_PER_GPU, N_STATES
   out = {}
 
-  def run(tag, dof, G, cfg_kw, sdf=None, sdf_stride=0, covs=False, note=None, traffic_key=None):
+  def run(tag, dof, G, cfg_kw, sdf=None, sdf_stride=0, covs=False, note=None, traffic_key=None, layout=0):
     d = 2 * dof
     th0, start, goal, sdf_shared = make_inputs(B, n, G, device, seed=0, dof=dof)
     s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=torch.float32, **cfg_kw))
     grids = [sdf_shared] if sdf is None else sdf
-    sas = [s.sdf_arg(g_.data_ptr(), G, G, sdf_stride) for g_ in grids]
+    sas = [s.sdf_arg(g_.data_ptr(), G, G, sdf_stride, layout=layout) for g_ in grids]
     sa = sas[0]
     dth = torch.empty_like(th0); err = torch.empty(B, device=device); eex = torch.empty(B, device=device)
     info = torch.zeros(B, dtype=torch.int32, device=device)
@@ -331,6 +331,13 @@ def extra_workloads(device, stream, reps=1500):
   run('per_sample_sdf', 2, GRID, {}, sdf=ps, sdf_stride=GRID * GRID, traffic_key='per_sample_sdf',
       note='configs[1] with one 256x256 SDF PER trajectory (the reference API shape sdfb (B,1,H,W)): 1 GiB of grids per batch, six '
            'different batches of grids cycled so that the tap lines come from HBM, not from the 256 MiB Infinity Cache')
+  # the same six batches of grids stored as 4 x 4 tiles (DgpSdf::layout = DGP_SDF_TILED4; utils.sdf_utils.tile_sdf, or written directly by dgp_sdf_2d): the 2 x 2 footprint of a
+  # lookup in one 64-byte tile instead of two rows a kilobyte apart -- 29 instead of 70 distinct lines per trajectory
+  from dgpmp2_amd.utils.sdf_utils import tile_sdf
+  pt = [tile_sdf(g_) for g_ in ps]
+  run('per_sample_sdf_tiled', 2, GRID, {}, sdf=pt, sdf_stride=GRID * GRID, layout=_capi.DGP_SDF_TILED4, traffic_key='per_sample_sdf_tiled',
+      note='per_sample_sdf with the grids stored as 4 x 4 tiles (an API extension: utils.sdf_utils.tile_sdf(sdfb) / sdf_2d_batch(layout="tiled4") in place of sdfb)')
+  del pt
   # the regime a GN loop is in: step k+1 reads (nearly) the lines step k read -- ONE batch of grids, the trajectory inputs cycling
   run('per_sample_sdf_same_grids', 2, GRID, {}, sdf=ps[:1], sdf_stride=GRID * GRID,
       note='configs[1] with one 256x256 SDF per trajectory, the SAME 4096 grids every step (GN iteration k+1 on the grids of iteration k): '

@@ -101,7 +101,7 @@ class CApi(object):
     self.sdf_2d_workspace_bytes = f('sdf_2d_workspace_bytes'); self.sdf_2d_workspace_bytes.restype = C.c_size_t
     self.sdf_2d_workspace_bytes.argtypes = [i32, i32, i32, i32]
     self.sdf_2d = f('sdf_2d'); self.sdf_2d.restype = C.c_int
-    self.sdf_2d.argtypes = [vp, i32, i32, i32, i32, i32, dbl, vp, i32, vp, C.c_size_t, vp]
+    self.sdf_2d.argtypes = [vp, i32, i32, i32, i32, i32, dbl, vp, i32, i32, vp, C.c_size_t, vp]
     self.time_next_launch = f('time_next_launch'); self.time_next_launch.restype = C.c_int; self.time_next_launch.argtypes = [vp, vp]
     self.event_create = f('event_create'); self.event_create.restype = C.c_int; self.event_create.argtypes = [C.POINTER(vp)]
     self.event_destroy = f('event_destroy'); self.event_destroy.restype = None; self.event_destroy.argtypes = [vp]

@@ -72,10 +72,15 @@ inline bool shape_supported(int lpt, int c) { return (lpt == 16 || lpt == 32 || 
 // of the adjoint solve AND the covariance blocks alive into the chain rule -- (16,4) 98.3 us against (32,2) 65.6 us at B = 4096 (the forward step
 // is indifferent, 47.4 vs 46.4 us, and the fused loop prefers (16,4), 76.0 vs 83.2 us per iteration, so only the backward changes family).
 enum { FAM_STATIC = 0, FAM_GENERAL = 1, FAM_KRON_BWD = 2 };
-inline DgpShape choose_shape(const DgpHandle* h, int B, int family = FAM_STATIC) {
+// `tiled` (DgpSdf::layout = DGP_SDF_TILED4, and the step kernels with the errors epilogue): the twin translation units hold the shapes (16,4) and (32,4) only
+// (num_states <= 128, host-checked)
+inline bool tiled_shape_ok(int lpt, int c) { return c == 4 && (lpt == 16 || lpt == 32); }
+constexpr int kMaxStatesTiled = 128;
+inline DgpShape choose_shape(const DgpHandle* h, int B, int family = FAM_STATIC, bool tiled = false) {
   const bool general = family == FAM_GENERAL;
   if (is_long(h->cfg.num_states)) return DgpShape{64, (h->cfg.num_states + 63) / 64};      // gn_long.h: rows per lane reported as C
-  if (h->force_lpt) return DgpShape{h->force_lpt, h->force_c};
+  if (h->force_lpt && (!tiled || tiled_shape_ok(h->force_lpt, h->force_c))) return DgpShape{h->force_lpt, h->force_c};
+  if (tiled) return DgpShape{h->cfg.num_states <= 64 ? 16 : 32, 4};
   static const double T4[3][3] = {{1.5, 2.4, 4.9}, {2.9, 4.3, 6.6}, {5.7, 7.4, 10.6}};      // [LPT 16,32,64][C 1,2,4], us, d = 4
   static const double T6[3][3] = {{11.0, 14.2, 24.4}, {13.4, 17.1, 26.6}, {19.9, 26.1, 33.9}};  // d = 6
   static const double T6G[3][3] = {{11.0, 14.2, 67.2}, {13.4, 25.9, 70.1}, {23.5, 26.1, 89.0}};  // d = 6, general kernels: the C = 4 / (32,2) / (64,1) entries from the round-3 check (time / turns), the rest as T6
@@ -222,12 +227,12 @@ inline int fill_call(const DgpHandle* h, int32_t batch, const void* th, const vo
   if (sdf->rows < 1 || sdf->cols < 1) return fail(DGP_EINVAL, "sdf grid must be at least 1x1, got %dx%d", sdf->rows, sdf->cols);
   if (sdf->cols < 2) return fail(DGP_EUNSUPPORTED, "sdf grids with a single column are not implemented (the taps are fetched as column pairs)");
   if (sdf->batch_stride < 0) return fail(DGP_EINVAL, "negative sdf batch stride");
-  if ((int64_t)sdf->rows * sdf->cols >= ((int64_t)1 << 31)) return fail(DGP_EUNSUPPORTED, "sdf grid of %dx%d elements is too large", sdf->rows, sdf->cols);
-  if (sdf->layout != DGP_SDF_ROWMAJOR) return fail(DGP_EUNSUPPORTED, "DgpSdf::layout %d is not implemented", sdf->layout);
+  if (((int64_t)sdf->rows + 3) * ((int64_t)sdf->cols + 3) >= ((int64_t)1 << 31)) return fail(DGP_EUNSUPPORTED, "sdf grid of %dx%d elements is too large", sdf->rows, sdf->cols);
+  if (sdf->layout != DGP_SDF_ROWMAJOR && sdf->layout != DGP_SDF_TILED4) return fail(DGP_EINVAL, "bad DgpSdf::layout %d", sdf->layout);
   p = h->base;
   p.B = batch;
   p.th = th; p.start = start; p.goal = goal;
-  p.sdf = sdf->data; p.sdf_rows = sdf->rows; p.sdf_cols = sdf->cols; p.sdf_bstride = sdf->batch_stride;
+  p.sdf = sdf->data; p.sdf_rows = sdf->rows; p.sdf_cols = sdf->cols; p.sdf_bstride = sdf->batch_stride; p.sdf_layout = sdf->layout;
   // obstacle_cost.py:34 and sdf_utils.py:57-58, evaluated exactly as Python does (fp64)
   p.res = (h->cfg.x_lims[1] - h->cfg.x_lims[0]) / (double)sdf->cols;
   p.inv_res = 1.0 / p.res;
@@ -305,6 +310,7 @@ inline int fill_gsdf(const DgpHandle* h, const DgpSdf* sdf, void* g_sdf, int64_t
       if (!sdf->grad_indices) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs DgpSdf::grad_indices");
       if (g_sdf_copies != 1) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE takes no partial copies");
       if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_SPARSE is not implemented for num_states > 256");
+      if (sdf->layout != DGP_SDF_ROWMAJOR) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_SPARSE delivers row-major (y, x) indices: a tiled grid takes a dense (tiled) gradient");
       if ((reinterpret_cast<uintptr_t>(g_sdf) & 15u) || (reinterpret_cast<uintptr_t>(sdf->grad_indices) & 15u))
         return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs 16-byte aligned value / index arrays (vector stores)");
       g.g_sdf_idx = sdf->grad_indices;
@@ -385,7 +391,7 @@ inline int fill_solve_backward(const DgpHandle* h, int32_t batch, const void* st
 
 // ---- the round-4 entry points, generic over how a kernel is launched (HIP: dgpmp2_hip.hip; the test emulator: tests/emul) ------------------
 // `launch(mode, p, g)` -> DGP_OK or an error code; mode: dgp::MODE_* / 3 = backward / 4 = chain backward.
-enum { kModeBackward = 3, kModeChain = 4 };
+enum { kModeBackward = 3, kModeChain = 4, kModeStepErrs = 5 };      // kModeStepErrs: MODE_STEP on the twin kernels that carry the errors epilogue (gn_lane.h: DGP_STEP_ERRS)
 
 template <typename Launch>
 int gn_solve_traced(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf, const DgpCovs* covs,
@@ -420,6 +426,12 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   if (rc != DGP_OK) return rc;
   const bool errs = unw_sg || unw_gp || unw_obs;
   if (errs && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors is not implemented for num_states > 256");
+  // ONE launch where the step kernels with the errors epilogue exist (round 5): row-major grid, up to 128 states (the two four-states-per-lane shapes), the static /
+  // scaled / per-state Kronecker families; everything else: the error kernel stream-ordered behind the step, as in round 4
+  if (errs && p.sdf_layout == 0 && p.n <= kMaxStatesTiled && dgp::kernel_variant(p) != dgp::QK_GENERAL && !h->force_lpt) {
+    p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
+    return launch((int)kModeStepErrs, p, (const dgp::GnGradParams*)nullptr);
+  }
   rc = launch(dgp::MODE_STEP, p, (const dgp::GnGradParams*)nullptr);
   if (rc != DGP_OK || !errs) return rc;
   // the unweighted errors at th + dtheta: the error kernel with dtheta as addend, stream-ordered behind the step (only eps of the covariances enters them)

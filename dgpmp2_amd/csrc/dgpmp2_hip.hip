@@ -16,17 +16,39 @@ int drop_events(int rc) {
   return rc;
 }
 
+// status of a launch: hipErrorNotSupported is this file's own code for "tiled grid beyond what the tiled translation units hold" (see launch())
+int hip_rc(hipError_t e, const char* what) {
+  if (e == hipSuccess) return DGP_OK;
+  if (e == hipErrorNotSupported)
+    return fail(DGP_EUNSUPPORTED, "%s: tiled grids (DGP_SDF_TILED4) are implemented for num_states <= %d (launch shapes (16,4) and (32,4))", what, dgp_host::kMaxStatesTiled);
+  return fail(DGP_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
+}
+
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
+  const bool tiled = p.sdf_layout != 0 && p.sdf != nullptr;
+  if (tiled && p.n > dgp_host::kMaxStatesTiled) return hipErrorNotSupported;
+  if (mode == dgp_host::kModeStepErrs) {          // dgp_gn_step_errors as ONE launch: the step kernels with the errors epilogue (gn_inst.hip with -DDGP_STEP_ERRS=1; host-checked: available)
+    static const DgpLaunchFn etab[2][2][2] = {{{dgp_launch_2e_f32_g0, dgp_launch_2e_f32_g3}, {dgp_launch_2e_f64_g0, dgp_launch_2e_f64_g3}},
+                                             {{dgp_launch_3e_f32_g0, dgp_launch_3e_f32_g3}, {dgp_launch_3e_f64_g0, dgp_launch_3e_f64_g3}}};
+    const int grp = dgp_dev::launch_group(dgp::MODE_STEP, p);
+    if (tiled || (grp != dgp_dev::GROUP_STATIC && grp != dgp_dev::GROUP_KRON)) return hipErrorInvalidValue;
+    const DgpShape she = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(dgp::MODE_STEP, p), /*four states per lane=*/true);
+    return etab[h->cfg.dof - 2][h->cfg.io_dtype == DGP_F64 ? 1 : 0][grp == dgp_dev::GROUP_KRON ? 1 : 0](she, dgp::MODE_STEP, p, g, s);
+  }
   if (dgp_host::is_long(p.n)) return dgp_launch_long(h->cfg.dof, h->cfg.io_dtype == DGP_F64, mode, p, g, s);      // n > 256: gn_long.h
-  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p));
-  // [dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip)
-  static const DgpLaunchFn table[2][2][dgp_dev::NUM_GROUPS] = {
-      {{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3, dgp_launch_2_f32_g4},
-       {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2, dgp_launch_2_f64_g3, dgp_launch_2_f64_g4}},
-      {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2, dgp_launch_3_f32_g3, dgp_launch_3_f32_g4},
-       {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2, dgp_launch_3_f64_g3, dgp_launch_3_f64_g4}}};
+  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p), tiled);
+  // [tiled][dof - 2][io dtype][kernel group] -> the translation unit that holds the kernel (gn_inst.hip; the tiled units: the same kernels compiled with -DDGP_TL=1)
+  static const DgpLaunchFn table[2][2][2][dgp_dev::NUM_GROUPS] = {
+      {{{dgp_launch_2_f32_g0, dgp_launch_2_f32_g1, dgp_launch_2_f32_g2, dgp_launch_2_f32_g3, dgp_launch_2_f32_g4},
+        {dgp_launch_2_f64_g0, dgp_launch_2_f64_g1, dgp_launch_2_f64_g2, dgp_launch_2_f64_g3, dgp_launch_2_f64_g4}},
+       {{dgp_launch_3_f32_g0, dgp_launch_3_f32_g1, dgp_launch_3_f32_g2, dgp_launch_3_f32_g3, dgp_launch_3_f32_g4},
+        {dgp_launch_3_f64_g0, dgp_launch_3_f64_g1, dgp_launch_3_f64_g2, dgp_launch_3_f64_g3, dgp_launch_3_f64_g4}}},
+      {{{dgp_launch_2t_f32_g0, dgp_launch_2t_f32_g1, dgp_launch_2t_f32_g2, dgp_launch_2t_f32_g3, dgp_launch_2t_f32_g4},
+        {dgp_launch_2t_f64_g0, dgp_launch_2t_f64_g1, dgp_launch_2t_f64_g2, dgp_launch_2t_f64_g3, dgp_launch_2t_f64_g4}},
+       {{dgp_launch_3t_f32_g0, dgp_launch_3t_f32_g1, dgp_launch_3t_f32_g2, dgp_launch_3t_f32_g3, dgp_launch_3t_f32_g4},
+        {dgp_launch_3t_f64_g0, dgp_launch_3t_f64_g1, dgp_launch_3t_f64_g2, dgp_launch_3t_f64_g3, dgp_launch_3t_f64_g4}}}};
   const int f64 = h->cfg.io_dtype == DGP_F64 ? 1 : 0;
-  return table[h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
+  return table[tiled ? 1 : 0][h->cfg.dof - 2][f64][dgp_dev::launch_group(mode, p)](sh, mode, p, g, s);
 }
 
 // dgp_sum_partial_grids: out[e] = scale * sum_c partial[c][e] -- the partial copies of a shared grid's gradient (dgp_gn_step_backward's g_sdf_copies) summed and cast in
@@ -36,7 +58,13 @@ template <typename TI, typename TO>
 __global__ void __launch_bounds__(256) sum_partial_grids_kernel(const TI* __restrict__ in, int copies, int64_t elems, double scale, TO* __restrict__ out) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < elems; e += (int64_t)gridDim.x * 256) {
     double acc = 0.0;
-    for (int c = 0; c < copies; ++c) acc += (double)in[(int64_t)c * elems + e];
+    int c = 0;
+    for (; c + 4 <= copies; c += 4) {                  // four independent loads in flight per lane (a serial chain over 16 copies ran at 1.5 TB/s)
+      const double v0 = (double)in[(int64_t)c * elems + e], v1 = (double)in[(int64_t)(c + 1) * elems + e];
+      const double v2 = (double)in[(int64_t)(c + 2) * elems + e], v3 = (double)in[(int64_t)(c + 3) * elems + e];
+      acc += (v0 + v1) + (v2 + v3);
+    }
+    for (; c < copies; ++c) acc += (double)in[(int64_t)c * elems + e];
     out[e] = (TO)(acc * scale);
   }
 }
@@ -110,8 +138,7 @@ int dgp_square_covariances(const void* raw, int32_t dtype, int32_t batch, int32_
   else hipLaunchKernelGGL((square_covs_kernel<float>), grid, block, 0, s, (const float*)raw, batch, width, n_gp, num_states, learn_eps, dof, (float*)sq_scalars, (float*)sq_qc_inv,
                           (float*)sq_obs_w, (float*)sq_eps);
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_square_covariances launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_square_covariances");
 }
 
 int dgp_square_covariances_backward(const void* raw, int32_t dtype, int32_t batch, int32_t width, int32_t n_gp, int32_t num_states, int32_t learn_eps, int32_t dof,
@@ -127,8 +154,7 @@ int dgp_square_covariances_backward(const void* raw, int32_t dtype, int32_t batc
   else hipLaunchKernelGGL((square_covs_backward_kernel<float>), grid, block, 0, s, (const float*)raw, batch, width, n_gp, num_states, learn_eps, dof, (const float*)g_qc_inv,
                           (const float*)g_obs_w, (const float*)g_eps, (float*)g_raw);
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_square_covariances_backward launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_square_covariances_backward");
 }
 
 int dgp_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t copies, int64_t elems, double scale, void* out, int32_t out_dtype, void* stream) {
@@ -146,8 +172,7 @@ int dgp_sum_partial_grids(const void* partial, int32_t partial_dtype, int32_t co
     else hipLaunchKernelGGL((sum_partial_grids_kernel<float, float>), grid, block, 0, s, (const float*)partial, copies, elems, scale, (float*)out);
   }
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_sum_partial_grids launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_sum_partial_grids");
 }
 
 int dgp_abi_version(void) { return DGP_ABI_VERSION; }
@@ -182,8 +207,7 @@ int dgp_gn_step(const DgpHandle* h, int32_t batch, const void* th, const void* s
   int rc = dgp_host::fill_step(h, batch, th, start, goal, sdf, covs, dtheta, err, err_ext, info, p);
   if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_STEP, p, nullptr, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_gn_step");
 }
 
 int dgp_gn_solve(const DgpHandle* h, int32_t batch, const void* th_init, const void* start, const void* goal, const DgpSdf* sdf,
@@ -194,8 +218,7 @@ int dgp_gn_solve(const DgpHandle* h, int32_t batch, const void* th_init, const v
                                 errext_hist, err_final, info, p);
   if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_SOLVE, p, nullptr, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_solve launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_gn_solve");
 }
 
 int dgp_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
@@ -204,8 +227,7 @@ int dgp_eval_errors(const DgpHandle* h, int32_t batch, const void* th, const voi
   int rc = dgp_host::fill_eval(h, batch, th, start, goal, sdf, covs, err, err_ext, unw_sg, unw_gp, unw_obs, p);
   if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp::MODE_EVAL, p, nullptr, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_eval_errors launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_eval_errors");
 }
 
 int dgp_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
@@ -218,8 +240,7 @@ int dgp_gn_step_backward(const DgpHandle* h, int32_t batch, const void* th, cons
                                    g_sdf_batch_stride, g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
   if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_gn_step_backward launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_gn_step_backward");
 }
 
 int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th, const void* start, const void* goal, const DgpSdf* sdf,
@@ -232,8 +253,7 @@ int dgp_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th, 
                                         g_sdf, g_sdf_batch_stride, g_sdf_copies, g_eps, p, g);
   if (rc != DGP_OK) return drop_events(rc);
   hipError_t e = launch(h, dgp_dev::MODE_BACKWARD, p, &g, (hipStream_t)stream);
-  if (e != hipSuccess) return fail(DGP_EHIP, "dgp_eval_errors_backward launch failed: %s", hipGetErrorString(e));
-  return DGP_OK;
+  return hip_rc(e, "dgp_eval_errors_backward");
 }
 
 // The round-4 entry points: their host logic (validation, the two launches behind one call) is shared with the test emulator, dgp_host.h
@@ -241,9 +261,7 @@ namespace {
 struct HipLaunch {
   const DgpHandle* h; hipStream_t s; const char* what;
   int operator()(int mode, const dgp::GnParams& p, const dgp::GnGradParams* g) const {
-    hipError_t e = launch(h, mode, p, g, s);
-    if (e != hipSuccess) return fail(DGP_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
-    return DGP_OK;
+    return hip_rc(launch(h, mode, p, g, s), what);
   }
 };
 }  // namespace

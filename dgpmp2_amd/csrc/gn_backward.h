@@ -79,7 +79,7 @@ DGP_HD void sdf_scatter_pairs(const GnParams& p, const GnGradParams& gp, Ctx& cx
     const int xcc = cx.xcc_id();
     const int per_xcd = gp.g_sdf_copies / kMaxXcds;
     const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? (xcc % kMaxXcds) + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;      // (XCC_ID is a 4-bit field: never index past the copies)
-    first = (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
+    first = (int64_t)copy * grid_elems(p);
   }
   IO* base = (IO*)gp.g_sdf + first;
   double* base64 = (double*)gp.g_sdf + first;
@@ -155,8 +155,8 @@ template <int DOF, bool CHAIN> struct BwdParks {
 // program's loads with an agent-scope fence -- an L2 write-back per wavefront on gfx950: 57 instead of 36 us; with a workgroup-scope fence 31 us: the store
 // round trip in front of the main program's first loads.)
 template <int DOF, int LPT, int C, typename IO, typename Ctx>
-DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp, Ctx& cx, const double (&th_rows)[C][2 * DOF], const double (&mu_s)[2 * DOF],
-                                       const double (&mu_g)[2 * DOF], double (&gfold)[C][2 * DOF]) {
+DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp, Ctx& cx, const double (&th_rows)[C][2 * DOF], const double (&dq)[C][2 * DOF],
+                                       const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], double (&gfold)[C][2 * DOF]) {
   constexpr int D = 2 * DOF;
   constexpr int TPW = 64 / LPT;
   const int lane = cx.lane();
@@ -168,15 +168,11 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
   const int g0 = j * C;
   const bool vec = p.vec_io != 0;
   double x[C][D];
-  {
-    // (th rows and the means come from the main program, which has just loaded them: one load round trip instead of two)
-    double dq[C][D];
-    load_lane_rows<DOF, C, IO>(p, gp.f_addend, b, g0, traj_ok, vec, dq);
+  // (the th and dtheta rows and the means come from the main program, which loads them together with its own inputs: one memory round trip in front of the taps)
 #pragma unroll
-    for (int k = 0; k < C; ++k)
+  for (int k = 0; k < C; ++k)
 #pragma unroll
-      for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)th_rows[k][a] + (IO)dq[k][a]);      // the sum in the I/O type, as torch forms th_curr_b + dthetab
-  }
+    for (int a = 0; a < D; ++a) x[k][a] = (double)(IO)((IO)th_rows[k][a] + (IO)dq[k][a]);      // the sum in the I/O type, as torch forms th_curr_b + dthetab
   const double gsg = (traj_ok && gp.f_unw_sg) ? ld<IO>(gp.f_unw_sg, b) : 0.0;
   const double ggp = (traj_ok && gp.f_unw_gp) ? ld<IO>(gp.f_unw_gp, b) / (double)(n - 1) : 0.0;
   const double gob = (traj_ok && gp.f_unw_obs) ? ld<IO>(gp.f_unw_obs, b) / (double)n : 0.0;
@@ -315,9 +311,22 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
-  if constexpr (!CHAIN) {
+#ifndef DGP_BWD_FOLD
+#define DGP_BWD_FOLD 1             // 0: compile the prologue out (A/B builds, profiles/tools/devbuild.py: what its presence costs the plain step backward)
+#endif
+  if constexpr (!CHAIN && DGP_BWD_FOLD != 0) {
     if (gp.f_addend) {             // wave-uniform: dgp_gn_step_errors_backward in one launch -- the errors' share of the dtheta cotangent arrives in gbar
-      unweighted_errors_prologue<DOF, LPT, C, IO>(p, gp, cx, x, mu_s, mu_g, gbar);
+      double dq[C][D], gd[C][D];
+      load_rows(gp.f_addend, dq);
+      const bool have_gd = gp.g_dtheta != nullptr;
+      if (have_gd) load_rows(gp.g_dtheta, gd);      // (in flight under the prologue's arithmetic)
+      unweighted_errors_prologue<DOF, LPT, C, IO>(p, gp, cx, x, dq, mu_s, mu_g, gbar);
+      if (have_gd) {
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+#pragma unroll
+          for (int a = 0; a < D; ++a) gbar[k][a] += gd[k][a];
+      }
       folded = true;
     }
   }
@@ -325,18 +334,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   for (int k = 0; k < C; ++k)
 #pragma unroll
     for (int a = 0; a < D; ++a) { if (!folded) gbar[k][a] = 0.0; lam[k][a] = 0.0; }
-  if (gp.g_dtheta) {
-    if (folded) {                  // (the prologue's rows are already in gbar)
-      double gd[C][D];
-      load_rows(gp.g_dtheta, gd);
-#pragma unroll
-      for (int k = 0; k < C; ++k)
-#pragma unroll
-        for (int a = 0; a < D; ++a) gbar[k][a] += gd[k][a];
-    } else {
-      load_rows(gp.g_dtheta, gbar);
-    }
-  }
+  if (gp.g_dtheta && !folded) load_rows(gp.g_dtheta, gbar);
   // dgp_gn_step_errors_backward, two-launch form (long trajectories: gn_long.h; kept here for callers that pass g_th_new without f_addend): the gradient
   // w.r.t. th + dtheta that the errors' backward left behind joins the dtheta cotangent (th + dtheta depends on dtheta with a unit Jacobian) and, further
   // down, the trajectory gradient (and on th likewise).  Both uses re-read it from memory behind a wave-uniform branch

@@ -135,7 +135,9 @@ __device__ __forceinline__ const char* warm_kernarg_laundered() {
 #define DGP_LAUNDER_KERNARG(DOF, MODE, QK) ((MODE) == dgp::MODE_SOLVE && (dgp::is_wb(QK) || (QK) == dgp::QK_STATIC))
 #endif
 // QK: kernel variant by covariance representation, dgp::QK_* (static: the constant GP blocks are scalar operands; see gn_lane.h).
-template <int DOF, int LPT, int C, typename IO, int MODE, int QK>
+// TL: which twin of the source this translation unit is (DGP_TL: tiled grids; DGP_STEP_ERRS: step kernels with the errors epilogue; gn_lane.h) -- only there to give
+// the twin units' kernels their own symbols
+template <int DOF, int LPT, int C, typename IO, int MODE, int QK, int TL = DGP_TL + 2 * DGP_STEP_ERRS>
 __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) gn_kernel(const dgp::GnParams p_arg) {
   // (the Woodbury table behind the warmed lines is read with vector loads)
   constexpr bool kLaunder = DGP_LAUNDER_KERNARG(DOF, MODE, QK);
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(64, (WavesPerSimd<DOF, LPT, C, MODE>::value)) 
   dgp::gn_lane_program<DOF, LPT, C, IO, MODE, QK>(p, cx);
 }
 
-template <int DOF, int LPT, int C, typename IO, int QK, bool CHAIN = false>
+template <int DOF, int LPT, int C, typename IO, int QK, bool CHAIN = false, int TL = DGP_TL + 2 * DGP_STEP_ERRS>
 __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_arg, const dgp::GnGradParams g_arg) {
   // d = 4 static-covariance kernels: both argument structs read through the laundered pointer, as the fused loop does (static backward 15.0 -> 14.6 us;
   // the per-state kernel gets slower that way, 19.4 -> 19.7 us, and d = 6 was not measured: both keep the by-value reads)
@@ -216,8 +218,12 @@ __global__ void __launch_bounds__(64) gn_long_backward_kernel(const dgp::GnParam
   dgp::gn_long_backward_program<DOF, IO>(p, g, cx);
 }
 
-// every (LPT, C) of dgp_host::shape_supported
+// every (LPT, C) of dgp_host::shape_supported; the tiled units (DGP_TL == 1) hold the two shapes dgp_host::choose_shape picks for tiled grids
+#if DGP_TL == 1 || DGP_STEP_ERRS == 1
+#define DGP_FOR_EACH_SHAPE(X) X(16, 4) X(32, 4)
+#else
 #define DGP_FOR_EACH_SHAPE(X) X(16, 1) X(32, 1) X(64, 1) X(16, 2) X(32, 2) X(64, 2) X(16, 4) X(32, 4) X(64, 4)
+#endif
 
 // mode: dgp::MODE_* or MODE_BACKWARD
 enum { MODE_BACKWARD = 3, MODE_CHAIN = 4 };      // MODE_CHAIN: dgp_gn_solve_backward (the chain kernels, static covariances)
@@ -236,7 +242,9 @@ inline int launch_group(int mode, const dgp::GnParams& p) {
   return qk == dgp::QK_STATIC ? GROUP_STATIC : GROUP_GENERIC;
 }
 
-template <int DOF, typename IO, int GROUP>
+// (TL is part of the signature: the standard and the tiled unit of one (dof, io dtype, group) must not share ONE weak host instantiation of this template --
+//  the linker would keep either, and both launchers would then start the same kernels)
+template <int DOF, typename IO, int GROUP, int TL = DGP_TL + 2 * DGP_STEP_ERRS>
 hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const int tpw = 64 / sh.lpt;
   const dim3 grid((unsigned)((p.B + tpw - 1) / tpw)), block(64);
@@ -254,8 +262,15 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
   } while (0)
 #define DGP_LAUNCH_BWD(K)                                                           \
   do {                                                                              \
-    if (timed) hipExtLaunchKernelGGL(K, grid, block, 0, s, ev0, ev1, 0, p, *g);     \
-    else hipLaunchKernelGGL(K, grid, block, 0, s, p, *g);                           \
+    if constexpr (DGP_STEP_ERRS == 0) {                                             \
+      if (timed) hipExtLaunchKernelGGL(K, grid, block, 0, s, ev0, ev1, 0, p, *g);   \
+      else hipLaunchKernelGGL(K, grid, block, 0, s, p, *g);                         \
+    } else return hipErrorInvalidValue;                                             \
+  } while (0)
+  /* the step-errors twins hold MODE_STEP kernels only: every other launch is a discarded statement there (no instantiation) */
+#define DGP_LAUNCH_NOSTEP(K)                                                        \
+  do {                                                                              \
+    if constexpr (DGP_STEP_ERRS == 0) DGP_LAUNCH(K); else return hipErrorInvalidValue; \
   } while (0)
 #define DGP_CASE(L, CC)                                                                                                   \
   if (sh.lpt == L && sh.c == CC) {                                                                                         \
@@ -269,20 +284,20 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
         if (dgp::wb_applies(p, L, CC)) {                                                                                   \
           if (p.n == L * CC) {                                                                                             \
             if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WB>));               \
-            else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WB>));                                     \
+            else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WB>));                                     \
           } else {                                                                                                         \
             if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_WBR>));              \
-            else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WBR>));                                    \
+            else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_WBR>));                                    \
           }                                                                                                                \
           return hipGetLastError();                                                                                        \
         }                                                                                                                  \
       }                                                                                                                    \
       if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));                 \
-      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
+      else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
-      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));                \
-      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));         \
-      else DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                       \
+      if (mode == dgp::MODE_STEP) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));         \
+      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));  \
+      else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                \
     } else if constexpr (GROUP == GROUP_CHAIN) {                                                                           \
       if (!qstat) return hipErrorInvalidValue;                                                                             \
       if constexpr (CC == 4) {                                                                                             \
@@ -295,7 +310,7 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_STATIC, true>));                                          \
     } else if constexpr (GROUP == GROUP_KRON) {                                                                            \
       if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_KRON>));                   \
-      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));            \
+      else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_KRON>));     \
       else DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_KRON>));                                             \
     } else {                                                                                                               \
       if (dgp::kernel_variant(p) == dgp::QK_SCALED) {                                                                      \
@@ -317,6 +332,7 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
   DGP_FOR_EACH_SHAPE(DGP_CASE)
 #undef DGP_CASE
 #undef DGP_LAUNCH
+#undef DGP_LAUNCH_NOSTEP
 #undef DGP_LAUNCH_BWD
   return hipErrorInvalidValue;
 }
@@ -332,6 +348,10 @@ typedef hipError_t (*DgpLaunchFn)(DgpShape, int, const dgp::GnParams&, const dgp
   hipError_t dgp_launch_##d##_##t##_g3(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t); \
   hipError_t dgp_launch_##d##_##t##_g4(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t);
 DGP_DECL_INST(2, f32) DGP_DECL_INST(2, f64) DGP_DECL_INST(3, f32) DGP_DECL_INST(3, f64)
+// ... and their tiled twins (gn_inst.hip with -DDGP_TL=1): dgp_launch_<dof>t_<io>_g<group>
+DGP_DECL_INST(2t, f32) DGP_DECL_INST(2t, f64) DGP_DECL_INST(3t, f32) DGP_DECL_INST(3t, f64)
+// ... and the step-errors twins (gn_inst.hip with -DDGP_STEP_ERRS=1; groups 0 and 3 are built): dgp_launch_<dof>e_<io>_g<group>
+DGP_DECL_INST(2e, f32) DGP_DECL_INST(2e, f64) DGP_DECL_INST(3e, f32) DGP_DECL_INST(3e, f64)
 #undef DGP_DECL_INST
 // gn_long_inst.hip: the long-trajectory kernels of every (dof, io dtype); mode: dgp::MODE_* or dgp_dev::MODE_BACKWARD
 hipError_t dgp_launch_long(int dof, bool f64, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s);

@@ -128,7 +128,8 @@ struct GnParams {
   // Static covariances (qc_mode == QC_STATIC): the three constant blocks every GP factor contributes, precomputed on the
   // host from (dt, Q_c_inv) so that the kernels read them as scalar (SGPR) operands instead of holding them in vector
   // registers.  d = 2 dof; symmetric blocks packed like Sym<d>, u_fix row-major d x d.
-  int32_t qc_diag, pad2_;    // 1: Q_c_inv is diagonal -> the static (QSTAT) kernels apply; else static covariances run the generic ones
+  int32_t qc_diag;           // 1: Q_c_inv is diagonal -> the static (QSTAT) kernels apply; else static covariances run the generic ones
+  int32_t sdf_layout;        // DgpSdf::layout: 0 row-major, 1 4 x 4 tiles -- read by the host (which translation unit to launch) and by the emulator; see DGP_TL
   double q_fix[21];          // Q^-1                                   (gp_factor.py:65-73)
   double a_fix[21];          // Phi^T Q^-1 Phi                         (block (i,i) share of factor i -> i+1)
   double u_fix[36];          // U = -Phi^T Q^-1                        (block (i,i+1))
@@ -472,6 +473,39 @@ DGP_HD double div_M(const GnParams& p, double a) {
 DGP_HD int32_t imin32(int32_t a, int32_t b) { return a < b ? a : b; }
 DGP_HD int32_t imax32(int32_t a, int32_t b) { return a > b ? a : b; }
 
+// Grid layout the kernels of a translation unit are compiled for (DgpSdf::layout):
+//   DGP_TL 0  row-major grids only -- the standard kernels (every round-4 instantiation keeps its code: no layout test anywhere in the device code);
+//   DGP_TL 1  every grid is stored as 4 x 4 tiles -- the TILED translation units (gn_inst.hip with -DDGP_TL=1: the same kernels for the launch shapes with four
+//             states per lane, distinct symbols through the kernels' trailing template argument);
+//   DGP_TL 2  decided at run time from GnParams::sdf_layout -- the CPU wavefront emulator (tests/emul), one build for both layouts.
+// A run-time branch inside the standard kernels was measured first (profiles/r05_tiled_ab.txt): the untaken branch splits the block that schedules the tap loads
+// under the factor arithmetic and costs the ROW-MAJOR path 0.45 us per kernel (headline step 9.22 -> 9.68 us; 3 us on a training iteration) -- and with it hipcc
+// produced wrong 64-lane d = 6 step kernels.  Compiled apart, the standard kernels are byte-identical to the verified ones.
+#ifndef DGP_TL
+#define DGP_TL 0
+#endif
+// DGP_STEP_ERRS 1: the MODE_STEP kernels of this translation unit carry an EPILOGUE -- the unweighted errors at th + dtheta (dgp_gn_step_errors, one iteration of
+// learning/train_planner.py:311-327 in ONE launch instead of two) -- behind a test of GnParams::unw_*.  Compiled into twin units only (gn_inst.hip with
+// -DDGP_STEP_ERRS=1: the STEP kernels of the two four-states-per-lane shapes), like the tiled kernels: the standard kernels stay byte-identical.  The emulator: 1.
+#ifndef DGP_STEP_ERRS
+#define DGP_STEP_ERRS 0
+#endif
+DGP_HD bool grid_is_tiled(const GnParams& p) { return DGP_TL == 1 ? true : (DGP_TL == 2 ? p.sdf_layout != 0 : false); }
+// Elements of one grid: row-major H x W, or ceil(H / 4) x ceil(W / 4) tiles of 16 -- tile (y / 4, x / 4), row (y % 4), column (x % 4) inside it: the 2 x 2 footprint
+// of a bilinear lookup then lies in one 64-byte (fp32) tile in 9 cases of 16, where the row-major grid spreads it over two lines a row pitch apart (per-sample
+// grids: 70 distinct 128-byte lines per 64-state trajectory against 29, profiles/r05_tile_probe.txt)
+DGP_HD int64_t grid_elems(const GnParams& p) {
+  if (!grid_is_tiled(p)) return (int64_t)p.sdf_rows * p.sdf_cols;
+  return (int64_t)((p.sdf_rows + 3) >> 2) * ((p.sdf_cols + 3) >> 2) * 16;
+}
+// the four tap offsets (x1,y1), (x2,y1), (x1,y2), (x2,y2) of a lookup in a tiled grid
+DGP_HD void tiled_tap_offsets(const GnParams& p, const ObsAddr& o, int32_t& i11, int32_t& i21, int32_t& i12, int32_t& i22) {
+  const int32_t Wt = (p.sdf_cols + 3) >> 2;
+  const int32_t t1 = ((o.y1 >> 2) * Wt) << 4, t2 = ((o.y2 >> 2) * Wt) << 4, r1 = (o.y1 & 3) << 2, r2 = (o.y2 & 3) << 2;
+  const int32_t c1 = ((o.x1 >> 2) << 4) + (o.x1 & 3), c2 = ((o.x2 >> 2) << 4) + (o.x2 & 3);
+  i11 = t1 + r1 + c1; i21 = t1 + r1 + c2; i12 = t2 + r2 + c1; i22 = t2 + r2 + c2;
+}
+
 DGP_HD void obstacle_addr(const GnParams& p, double x, double y, ObsAddr& o) {
 #pragma clang fp contract(off)
   o.px = p.orig_px + div_res(p, x);                       // :61   orig + x / res
@@ -510,9 +544,15 @@ DGP_HD void obstacle_finish(const GnParams& p, const ObsAddr& o, double d11, dou
   hx = act ? (-1.0 * Jx) : 0.0;                           // :37
   hy = act ? (-1.0 * Jy) : 0.0;
   if (taps) {
-    const int64_t W = p.sdf_cols;
-    taps->i11 = (int64_t)o.y1 * W + o.x1; taps->i21 = (int64_t)o.y1 * W + o.x2;
-    taps->i12 = (int64_t)o.y2 * W + o.x1; taps->i22 = (int64_t)o.y2 * W + o.x2;
+    if (grid_is_tiled(p)) {
+      int32_t i11, i21, i12, i22;
+      tiled_tap_offsets(p, o, i11, i21, i12, i22);
+      taps->i11 = i11; taps->i21 = i21; taps->i12 = i12; taps->i22 = i22;
+    } else {
+      const int64_t W = p.sdf_cols;
+      taps->i11 = (int64_t)o.y1 * W + o.x1; taps->i21 = (int64_t)o.y1 * W + o.x2;
+      taps->i12 = (int64_t)o.y2 * W + o.x1; taps->i22 = (int64_t)o.y2 * W + o.x2;
+    }
     taps->wja = fy2 - py; taps->wjb = py - fy1; taps->wjc = fx2 - px; taps->wjd = px - fx1;
     taps->cross = d22 - d12 - d21 + d11;
     taps->act = act;
@@ -524,9 +564,17 @@ DGP_HD void obstacle_eval(const GnParams& p, const IO* grid, double x, double y,
                           double& hy, ObsTaps* taps = nullptr) {
   ObsAddr o;
   obstacle_addr(p, x, y, o);
-  const int64_t W = p.sdf_cols;
-  const double d11 = (double)grid[(int64_t)o.y1 * W + o.x1], d21 = (double)grid[(int64_t)o.y1 * W + o.x2];      // dx1y1, dx2y1 (:76-77)
-  const double d12 = (double)grid[(int64_t)o.y2 * W + o.x1], d22 = (double)grid[(int64_t)o.y2 * W + o.x2];      // dx1y2, dx2y2 (:78-79)
+  int64_t i11, i21, i12, i22;
+  if (grid_is_tiled(p)) {
+    int32_t a11, a21, a12, a22;
+    tiled_tap_offsets(p, o, a11, a21, a12, a22);
+    i11 = a11; i21 = a21; i12 = a12; i22 = a22;
+  } else {
+    const int64_t W = p.sdf_cols;
+    i11 = (int64_t)o.y1 * W + o.x1; i21 = (int64_t)o.y1 * W + o.x2; i12 = (int64_t)o.y2 * W + o.x1; i22 = (int64_t)o.y2 * W + o.x2;
+  }
+  const double d11 = (double)grid[i11], d21 = (double)grid[i21];      // dx1y1, dx2y1 (:76-77)
+  const double d12 = (double)grid[i12], d22 = (double)grid[i22];      // dx1y2, dx2y2 (:78-79)
   obstacle_finish(p, o, d11, d21, d12, d22, eps, cost, hx, hy, taps);
 }
 
@@ -1165,6 +1213,16 @@ DGP_HD void lane_obstacle_loads(const GnParams& p, int64_t b, int g0, bool traj_
   if (p.obs_w) {
 #pragma unroll
     for (int k = 0; k < C; ++k) t.ow[k] = ld<IO>(p.obs_w, (traj_ok && (g0 + k) < n) ? b * n + g0 + k : 0);
+  }
+  if (grid_is_tiled(p)) {            // (compile-time in the product's kernels, see DGP_TL) 4 x 4 tiles: the four taps as scalar loads -- a column pair may straddle two tiles
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      int32_t o11, o21, o12, o22;
+      tiled_tap_offsets(p, t.oa[k], o11, o21, o12, o22);
+      t.d11[k] = grid[o11]; t.d21[k] = grid[o21]; t.d12[k] = grid[o12]; t.d22[k] = grid[o22];
+      t.first1[k] = true; t.first2[k] = false;          // (tap_values(): d11 / d12 are the x1 taps, d21 / d22 the x2 taps)
+    }
+    return;
   }
 #pragma unroll
   for (int k = 0; k < C; ++k) {
@@ -2732,6 +2790,46 @@ DGP_HD void gn_eval_only(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj
   }
 }
 
+// The three UNWEIGHTED errors of DiffGPMP2Planner.unweighted_errors_batch at a trajectory (plan_layer.py:374-388: start_goal_error, gp_error's sum over the
+// factors, obs_error's sum over the states), per lane, summed over its C rows in the order eval_state accumulates them -- no covariance enters (only the current
+// epsilons): the step kernels' epilogue for the errors at th + dtheta (DGP_STEP_ERRS), which must not re-read per-state covariance blocks.
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
+DGP_HD void unweighted_errors_at(const GnParams& p, Ctx& cx, int64_t b, int j, bool traj_ok, const double (&x)[C][2 * DOF], const double (&mu_s)[2 * DOF],
+                                 const double (&mu_g)[2 * DOF], double& usg, double& ugp, double& uobs) {
+  constexpr int D = 2 * DOF;
+  const Nbr<LPT, 1, Ctx> nb(cx, j);
+  double x_next[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) x_next[a] = nb.hi(x[0][a]);
+  LaneFactors<C> lf;
+  if (p.sdf) lane_prefetch<DOF, C, IO>(p, b, j * C, traj_ok, x, lf);
+  usg = 0.0; ugp = 0.0; uobs = 0.0;
+  const int n = p.n;
+  const double dt = p.dt;
+#pragma unroll
+  for (int k = 0; k < C; ++k) {
+    const int g = j * C + k;
+    if (!(traj_ok && g < n)) continue;
+    const double* xk = x[k];
+    const double* xp = (k < C - 1) ? x[k < C - 1 ? k + 1 : 0] : x_next;
+    if (g == 0 || g == n - 1) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < D; ++a) { const double ea = ((g == 0) ? mu_s[a] : mu_g[a]) - xk[a]; s2 += ea * ea; }
+      usg += 0.5 * s2;
+    }
+    if (g < n - 1) {
+      double e[D], s2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < DOF; ++a) { e[a] = xp[a] - (xk[a] + dt * xk[DOF + a]); e[DOF + a] = xp[DOF + a] - xk[DOF + a]; }
+#pragma unroll
+      for (int a = 0; a < D; ++a) s2 += e[a] * e[a];
+      ugp += 0.5 * s2;
+    }
+    if (p.sdf) uobs += 0.5 * lf.oc[k] * lf.oc[k];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Row stores of a whole wavefront through LDS.  A lane owns C consecutive rows = one contiguous chunk of C*D elements, so
 // a direct store instruction writes 16 bytes at a C*D*sizeof(IO)-byte lane stride: 64 partially written cache lines per
@@ -3096,6 +3194,33 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
           if (traj_ok && g < n) st_row<IO, D>(p.dtheta, b * n + g, vec, dx[k]);
         }
       }
+#if DGP_STEP_ERRS
+      if (p.unw_sg || p.unw_gp || p.unw_obs) {      // wave-uniform: the training iteration's errors at th + dtheta, same launch
+        // th is read again (L2 hits: carried through the solve it would cost 2 C d registers), the sum formed in the I/O type from the STORED dtheta values,
+        // exactly as the separate error launch forms it from memory (torch: th_curr_b + dthetab)
+        double xe[C][D];
+        if (block_load) {
+          if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32 && MODE == MODE_STEP)
+            load_rows_through_lds<IO, C, D>(cx, p.th, (int64_t)cx.wave() * TPW * n * D, xe);
+        } else {
+          load_lane_rows<DOF, C, IO>(p, p.th, b, j * C, traj_ok, vec, xe);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k)
+#pragma unroll
+          for (int a = 0; a < D; ++a) xe[k][a] = (traj_ok && j * C + k < n) ? (double)(IO)((IO)xe[k][a] + (IO)dx[k][a]) : 0.0;
+        double usg, ugp, uobs, ms[D], mg[D];      // (the means re-read too: two rows less to carry through the solve)
+        ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, ms);
+        ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mg);
+        unweighted_errors_at<DOF, LPT, C, IO>(p, cx, b, j, traj_ok, xe, ms, mg, usg, ugp, uobs);
+        usg = group_sum_to_first<LPT>(cx, usg); ugp = group_sum_to_first<LPT>(cx, ugp); uobs = group_sum_to_first<LPT>(cx, uobs);
+        if (traj_ok && j == 0) {
+          if (p.unw_sg) st<IO>(p.unw_sg, b, usg);
+          if (p.unw_gp) st<IO>(p.unw_gp, b, ugp / (double)(n - 1));     // torch.mean over the n-1 factors
+          if (p.unw_obs) st<IO>(p.unw_obs, b, uobs / (double)n);
+        }
+      }
+#endif
     } else {
       double s2 = 0.0;
 #pragma unroll

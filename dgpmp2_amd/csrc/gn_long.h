@@ -466,7 +466,7 @@ DGP_HD void gn_long_backward_program(const GnParams& p, const GnGradParams& gp, 
       const int xcc = cx.xcc_id();
       const int per_xcd = gp.g_sdf_copies / kMaxXcds;
       const int copy = (per_xcd >= 1 && gp.g_sdf_copies % kMaxXcds == 0) ? (xcc % kMaxXcds) + kMaxXcds * ((cx.wave() / kMaxXcds) % per_xcd) : xcc % gp.g_sdf_copies;
-      gs_base += (int64_t)copy * ((int64_t)p.sdf_rows * p.sdf_cols);
+      gs_base += (int64_t)copy * grid_elems(p);
     }
     gs_base += b * gp.g_sdf_bstride;
   }

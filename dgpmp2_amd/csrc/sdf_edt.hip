@@ -42,6 +42,7 @@ struct EdtArgs {
   uint16_t* words;        // workspace: (B, Hp, Wp), per pixel: bit 15 = free space, bits 0-14 = vertical distance to the nearest pixel of the OTHER kind in its column
   uint32_t* flags;        // workspace: per image, bit 0: has an obstacle pixel, bit 1: has a free pixel
   int32_t B, rows, cols, pad, Hp, Wp;
+  int32_t layout;         // DgpSdf::layout of the output: 0 row-major, 1 4 x 4 tiles
   double res;
 };
 
@@ -127,7 +128,10 @@ __global__ void __launch_bounds__(256) edt_rows(const EdtArgs a) {
     if (PAD) { sq[x] = kFar; sq[2 * Wp + x] = kFar; sq[span + x] = kFar; sq[span + 2 * Wp + x] = kFar; }
   }
   __syncthreads();
-  O* out = (O*)a.out + ((int64_t)b * a.Hp + y) * Wp;
+  // row-major: this row of the (B, Hp, Wp) output; 4 x 4 tiles: row (y % 4) of the tiles (y / 4, .) of image b's ceil(Hp / 4) x ceil(Wp / 4) tile grid
+  const int Wt = (Wp + 3) >> 2;
+  O* out = a.layout == 0 ? (O*)a.out + ((int64_t)b * a.Hp + y) * Wp
+                         : (O*)a.out + (int64_t)b * ((a.Hp + 3) >> 2) * Wt * 16 + (int64_t)(y >> 2) * Wt * 16 + ((y & 3) << 2);
   for (int x = threadIdx.x; x < Wp; x += 256) {
     const bool free_px = sq[span + off + x] == 0;        // its own distance to the nearest free pixel is 0
     // a free pixel measures to the obstacles, an obstacle pixel to free space
@@ -173,7 +177,7 @@ __global__ void __launch_bounds__(256) edt_rows(const EdtArgs a) {
       }
     }
     const double dist = sqrt((double)best);
-    out[x] = (O)(free_px ? (dist - 0.0) * a.res : (0.0 - dist) * a.res);       // (im_dist - inv_im_dist) * res, sdf_utils.py:20
+    out[a.layout == 0 ? x : ((x >> 2) << 4) + (x & 3)] = (O)(free_px ? (dist - 0.0) * a.res : (0.0 - dist) * a.res);       // (im_dist - inv_im_dist) * res, sdf_utils.py:20
   }
 }
 
@@ -190,11 +194,12 @@ size_t dgp_sdf_2d_workspace_bytes(int32_t batch, int32_t rows, int32_t cols, int
 }
 
 int dgp_sdf_2d(const void* image, int32_t image_dtype, int32_t batch, int32_t rows, int32_t cols, int32_t padlen, double res,
-               void* sdf_out, int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+               void* sdf_out, int32_t out_dtype, int32_t out_layout, void* workspace, size_t workspace_bytes, void* stream) {
   if (!image || !sdf_out || !workspace) return fail(DGP_EINVAL, "dgp_sdf_2d: null image, output or workspace");
   if (batch <= 0 || rows <= 0 || cols <= 0 || padlen < 0) return fail(DGP_EINVAL, "dgp_sdf_2d: batch, rows, cols must be positive and padlen non-negative");
   if (image_dtype != DGP_F32 && image_dtype != DGP_F64 && image_dtype != DGP_U8) return fail(DGP_EINVAL, "dgp_sdf_2d: image_dtype %d", image_dtype);
   if (out_dtype != DGP_F32 && out_dtype != DGP_F64) return fail(DGP_EINVAL, "dgp_sdf_2d: out_dtype %d", out_dtype);
+  if (out_layout != DGP_SDF_ROWMAJOR && out_layout != DGP_SDF_TILED4) return fail(DGP_EINVAL, "dgp_sdf_2d: out_layout %d", out_layout);
   const int64_t Hp = (int64_t)rows + 2 * padlen, Wp = (int64_t)cols + 2 * padlen;
   if (Hp > kMaxDim || Wp > kMaxDim || batch > 65535) return fail(DGP_EUNSUPPORTED, "dgp_sdf_2d: padded image %lld x %lld (limit %d) or batch %d (limit 65535)", (long long)Hp, (long long)Wp, kMaxDim, batch);
   if (workspace_bytes < dgp_sdf_2d_workspace_bytes(batch, rows, cols, padlen)) return fail(DGP_EINVAL, "dgp_sdf_2d: workspace of %zu bytes, %zu needed", workspace_bytes, dgp_sdf_2d_workspace_bytes(batch, rows, cols, padlen));
@@ -204,7 +209,7 @@ int dgp_sdf_2d(const void* image, int32_t image_dtype, int32_t batch, int32_t ro
   a.image = image; a.out = sdf_out;
   a.flags = (uint32_t*)workspace;
   a.words = (uint16_t*)((char*)workspace + flags_bytes(batch));
-  a.B = batch; a.rows = rows; a.cols = cols; a.pad = padlen; a.Hp = (int32_t)Hp; a.Wp = (int32_t)Wp; a.res = res;
+  a.B = batch; a.rows = rows; a.cols = cols; a.pad = padlen; a.Hp = (int32_t)Hp; a.Wp = (int32_t)Wp; a.res = res; a.layout = out_layout;
   if (hipMemsetAsync(a.flags, 0, flags_bytes(batch), s) != hipSuccess) return fail(DGP_EHIP, "dgp_sdf_2d: hipMemsetAsync failed");
   const dim3 gc((unsigned)((Wp + 63) / 64), (unsigned)batch), gr((unsigned)Hp, (unsigned)batch);
   const bool strip = DGP_EDT_LDS_STRIP != 0 && Hp <= kColsLdsRows;

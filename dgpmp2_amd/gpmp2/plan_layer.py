@@ -58,7 +58,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
                            cost_sigma=cost_sigma, epsilon_dist=epsilon_dist, **kw)
 
 
-_SDF_GRAD_COPIES = 16     # MI355X has 8 XCDs, each with its own L2: two partial grids per XCD (XCD-local atomics, summed afterwards)
+_SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2: one FLOAT64 partial grid per XCD (XCD-local atomics; summed afterwards by dgp_sum_partial_grids).  (Two per XCD -- round 4's fp32 choice -- run the backward kernel no faster with double grids and double the zero fill and the sum: 27.7 vs 27.5 us, profiles/r05_ubench.txt)
 _ALL_STATIC = (True, True, True)
 _NO_COVS = (_capi.DGP_QC_STATIC, None, None, None)       # the four fields of DgpCovs as the trampoline takes them
 
@@ -215,10 +215,11 @@ def _expand_base(t):
   backward kernel has already formed.  When `t` is exactly such a view the node takes the view's BASE as its differentiable input (same storage, same
   launch) and returns the (1, 1, H, W) gradient itself.  Anything else (a view of a view, a differently strided base) is returned unchanged and gets B
   equal shares (see _SdfGrad.finish)."""
-  if t is None or t.dim() != 4 or t.shape[0] <= 1 or t.stride(0) != 0 or not t._is_view(): return t
+  if t is None or t.dim() not in (4, 6) or t.shape[0] <= 1 or t.stride(0) != 0 or not t._is_view(): return t
   b = t._base
-  if (b is not None and b.dim() == 4 and b.shape[0] == 1 and b.shape[1:] == t.shape[1:] and b.stride()[1:] == t.stride()[1:] and b.data_ptr() == t.data_ptr()
+  if (b is not None and b.dim() == t.dim() and b.shape[0] == 1 and b.shape[1:] == t.shape[1:] and b.stride()[1:] == t.stride()[1:] and b.data_ptr() == t.data_ptr()
       and b.dtype is t.dtype and b.requires_grad == t.requires_grad):
+    if '_dgp_hw' in t.__dict__: b.__dict__.setdefault('_dgp_hw', t.__dict__['_dgp_hw'])      # (a tiled grid's logical size travels with it)
     return b
   return t
 
@@ -271,18 +272,22 @@ class _SdfGrad(object):
     self.shared = sd[3] == 0
     self.idx = None
     self.pc, self.dev = layer._pc, th.get_device()
+    tiled = sd[4] != _capi.DGP_SDF_ROWMAJOR
+    # the grid of one gradient: (1, H, W), or the (1, Ht, Wt, 4, 4) tiles of a tiled sdfb (the gradient of a tiled tensor is tiled: dense only)
+    gshape = (1, (H + 3) // 4, (W + 3) // 4, 4, 4) if tiled else (1, H, W)
+    gelems = gshape[1] * gshape[2] * (16 if tiled else 1)
     if self.shared:
-      # partial copies: two per XCD for a batch that fills the chip; one set per XCD for a medium batch; a single grid (device-scope atomics) for a small one,
-      # whose few thousand taps do not contend -- zero-filling and summing sixteen 256 x 256 double grids costs more than such a backward kernel runs
-      self.copies, self.stride = (_SDF_GRAD_COPIES if B * n >= 65536 else (8 if B * n >= 8192 else 1)), 0
+      # partial copies: one per XCD; a single grid (device-scope atomics) for a small batch, whose few thousand taps do not contend -- zero-filling and summing
+      # eight 256 x 256 double grids costs more than such a backward kernel runs
+      self.copies, self.stride = (_SDF_GRAD_COPIES if B * n >= 8192 else 1), 0
       self.mode = _capi.DGP_GSDF_DENSE_F64 if n <= 256 else _capi.DGP_GSDF_DENSE
-      self.g = torch.zeros((self.copies, 1, H, W), dtype=torch.float64 if self.mode == _capi.DGP_GSDF_DENSE_F64 else th.dtype, device=th.device)
+      self.g = torch.zeros((self.copies,) + gshape, dtype=torch.float64 if self.mode == _capi.DGP_GSDF_DENSE_F64 else th.dtype, device=th.device)
     else:
-      self.copies, self.stride = 1, H * W
+      self.copies, self.stride = 1, gelems
       want = layer.sdf_grad
       nnz = passes * B * n * 4
       sparse = False
-      if want != 'dense' and n <= 256:
+      if want != 'dense' and n <= 256 and not tiled:
         dense_bytes, sparse_bytes = B * H * W * th.element_size(), nnz * (32 + th.element_size())
         sparse = want == 'sparse' or (sdf.is_leaf and dense_bytes > _SPARSE_MIN_DENSE_BYTES and dense_bytes > 2 * sparse_bytes)
       if sparse:
@@ -293,7 +298,7 @@ class _SdfGrad(object):
         self.shape = (B,) + tuple(sdf.shape[1:])
       else:
         self.mode = _capi.DGP_GSDF_DENSE
-        self.g = th.new_zeros((B, 1, H, W))
+        self.g = th.new_zeros((B,) + gshape)
     self.ptr = self.g.data_ptr()
 
   def sd(self, sd):
@@ -310,8 +315,8 @@ class _SdfGrad(object):
       # the copies summed (in double), scaled and cast in one launch; an expand()ed sdfb gets B equal shares: the kernel already accumulated all B
       # trajectories into the one grid, and autograd's expand-backward will sum the B slices of whatever is returned here
       many = sdf.shape[0] != 1
-      out = torch.empty((1, 1) + tuple(g.shape[2:]), dtype=sdf.dtype if sdf.dtype in (torch.float32, torch.float64) else g.dtype, device=g.device)
-      _launch(self.dev, self.pc.sum_partial_grids, g.data_ptr(), _io_code(g.dtype), self.copies, g.shape[2] * g.shape[3], 1.0 / sdf.shape[0] if many else 1.0,
+      out = torch.empty((1,) + tuple(g.shape[1:]), dtype=sdf.dtype if sdf.dtype in (torch.float32, torch.float64) else g.dtype, device=g.device)
+      _launch(self.dev, self.pc.sum_partial_grids, g.data_ptr(), _io_code(g.dtype), self.copies, g[0].numel(), 1.0 / sdf.shape[0] if many else 1.0,
               out.data_ptr(), _io_code(out.dtype), _raw_stream(self.dev))
       g = out
       if sdf.shape[1] != 1:
@@ -775,7 +780,8 @@ class PlanLayer(nn.Module):
       return c[8]
     _require_cuda(sdfb, 'sdfb')
     if sdfb.get_device() != dev: _same_device(dev, sdfb=sdfb)
-    if sdfb.dim() != 4: raise ValueError('sdfb must be (B,1,H,W)')
+    if sdfb.dim() == 6 and sdfb.shape[-2:] == (4, 4): return self._tiled_sdf_args(sdfb, dtype, B, dev)      # utils.sdf_utils.tile_sdf / sdf_2d_batch(layout='tiled4')
+    if sdfb.dim() != 4: raise ValueError('sdfb must be (B,1,H,W) (or the (B,1,H/4,W/4,4,4) tiles of utils.sdf_utils.tile_sdf)')
     H, W = sdfb.shape[-2], sdfb.shape[-1]
     shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
     if not shared and sdfb.shape[0] != B:       # a per-sample grid tensor with fewer grids than trajectories would be read out of bounds
@@ -797,6 +803,20 @@ class PlanLayer(nn.Module):
     except TypeError:
       self.__dict__['_sdf_cache'] = None
     return res[:7] + (t,)                       # (the caller's copy of the result keeps the view alive for the duration of the call)
+
+  def _tiled_sdf_args(self, sdfb, dtype, B, dev):
+    """A grid stored as 4 x 4 tiles, (B | 1, 1, Ht, Wt, 4, 4) contiguous per grid (utils.sdf_utils.tile_sdf): -> the DgpSdf fields with layout DGP_SDF_TILED4.  The
+    logical size comes from the tensor's `_dgp_hw` tag (4 Ht x 4 Wt without one).  Not cached: the checks are cheap next to a kernel on per-sample grids."""
+    if sdfb.shape[1] != 1: raise ValueError('tiled sdfb must be (B,1,Ht,Wt,4,4)')
+    Ht, Wt = int(sdfb.shape[2]), int(sdfb.shape[3])
+    H, W = sdfb.__dict__.get('_dgp_hw', (Ht * 4, Wt * 4))
+    if (H + 3) // 4 != Ht or (W + 3) // 4 != Wt: raise ValueError('tiled sdfb of %d x %d tiles does not hold a %d x %d grid' % (Ht, Wt, H, W))
+    shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
+    if not shared and sdfb.shape[0] != B:
+      raise ValueError('sdfb has %d grids for a batch of %d trajectories (expected %d, or 1 / an expand()ed view for a shared grid)' % (sdfb.shape[0], B, B))
+    t = (sdfb[0:1] if shared else sdfb).detach()
+    if t.dtype != dtype or not t.is_contiguous(): t = t.to(dtype).contiguous()
+    return (t.data_ptr(), int(H), int(W), 0 if shared else Ht * Wt * 16, _capi.DGP_SDF_TILED4, 0, None, t)
 
   @staticmethod
   def static_flags(qc, ow, eps):

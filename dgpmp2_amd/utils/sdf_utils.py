@@ -16,11 +16,38 @@ def sdf_2d(image, padlen=1, res=1.0):
   return (outside - inside) * res
 
 
-def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
+def tile_sdf(sdfb):
+  """(B, 1, H, W) signed distance fields -> the same values as 4 x 4 TILES, a (B, 1, ceil(H/4), ceil(W/4), 4, 4) tensor (padding cells zero) that every entry point of
+  the planner accepts in place of sdfb (DgpSdf::layout = DGP_SDF_TILED4; DESIGN.md section 3 "SDF").  With one grid per trajectory -- the reference's API shape,
+  1 GiB per batch of 4096 -- the bilinear taps of a trajectory then touch 29 instead of 70 cache lines: the GN kernels fetch half the bytes and run ~3 us sooner
+  (profiles/r05_tile_probe.txt).  The logical size (H, W) travels as the attribute `_dgp_hw` (it sets the resolution, obstacle_cost.py:34, and the clamping of the
+  lookup, sdf_utils.py:64-72).  sdf_2d_batch(..., layout='tiled4') writes this layout directly."""
+  import torch
+  if sdfb.dim() != 4 or sdfb.shape[1] != 1: raise ValueError('tile_sdf: (B, 1, H, W) expected, got %s' % (tuple(sdfb.shape),))
+  B, _, H, W = sdfb.shape
+  Ht, Wt = (H + 3) // 4, (W + 3) // 4
+  t = sdfb
+  if Ht * 4 != H or Wt * 4 != W: t = torch.nn.functional.pad(sdfb, (0, Wt * 4 - W, 0, Ht * 4 - H))
+  t = t.reshape(B, 1, Ht, 4, Wt, 4).permute(0, 1, 2, 4, 3, 5).contiguous()
+  t._dgp_hw = (int(H), int(W))
+  return t
+
+
+def untile_sdf(t, hw=None):
+  """The inverse of tile_sdf: (B, 1, Ht, Wt, 4, 4) tiles (a grid, or the gradient the planner returns for one) -> (B, 1, H, W); hw = the logical size when the tensor
+  does not carry `_dgp_hw` (a gradient does not)."""
+  B, C_, Ht, Wt = t.shape[:4]
+  H, W = hw if hw is not None else t.__dict__.get('_dgp_hw', (Ht * 4, Wt * 4))
+  return t.permute(0, 1, 2, 4, 3, 5).reshape(B, C_, Ht * 4, Wt * 4)[:, :, :H, :W]
+
+
+def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None, layout='rowmajor'):
   """sdf_2d for a whole batch of occupancy images on the GPU: ONE C-ABI call (dgp_sdf_2d, two launches of csrc/sdf_edt.hip) instead of
   two scipy distance transforms per image on the host.  images: CUDA tensor (B, H, W), (B, 1, H, W) or (H, W), float32 / float64 / uint8, free space
   > 0.75 as in sdf_2d; -> (B, H + 2 padlen, W + 2 padlen) (or without the batch axis for a 2-D input), float64 like the reference unless
-  `dtype` says float32.  The float64 result is bit-identical to sdf_2d's (tests/test_sdf_edt.py).  No CPU path: host arrays go through sdf_2d."""
+  `dtype` says float32.  The float64 result is bit-identical to sdf_2d's (tests/test_sdf_edt.py).  No CPU path: host arrays go through sdf_2d.
+  layout='tiled4': the fields as 4 x 4 tiles, (B, 1, ceil(H'/4), ceil(W'/4), 4, 4) with `_dgp_hw` = (H', W') -- exactly tile_sdf() of the row-major result, written
+  by the transform itself (no second pass over 1 GiB of grids)."""
   import torch
   from .. import _capi
   if not torch.is_tensor(images) or not images.is_cuda:
@@ -40,14 +67,21 @@ def sdf_2d_batch(images, padlen=1, res=1.0, dtype=None):
   im = im.contiguous()
   B, H, W = im.shape
   api = _capi.get_api()
+  if layout not in ('rowmajor', 'tiled4'): raise ValueError("sdf_2d_batch: layout must be 'rowmajor' or 'tiled4'")
+  tiled = layout == 'tiled4'
+  Hp, Wp = H + 2 * padlen, W + 2 * padlen
   with torch.cuda.device(im.device):
-    out = torch.empty((B, H + 2 * padlen, W + 2 * padlen), dtype=dtype, device=im.device)
+    if tiled: out = torch.zeros((B, 1, (Hp + 3) // 4, (Wp + 3) // 4, 4, 4), dtype=dtype, device=im.device) if (Hp % 4 or Wp % 4) else torch.empty((B, 1, Hp // 4, Wp // 4, 4, 4), dtype=dtype, device=im.device)
+    else: out = torch.empty((B, Hp, Wp), dtype=dtype, device=im.device)
     nbytes = api.sdf_2d_workspace_bytes(B, H, W, padlen)
     if nbytes == 0:
       raise ValueError('sdf_2d_batch: padlen must be non-negative')
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.int32, device=im.device)
-    api.check(api.sdf_2d(im.data_ptr(), codes[im.dtype], B, H, W, padlen, float(res), out.data_ptr(), codes[dtype], ws.data_ptr(), ws.numel() * 4,
-                         torch.cuda.current_stream(im.device).cuda_stream))
+    api.check(api.sdf_2d(im.data_ptr(), codes[im.dtype], B, H, W, padlen, float(res), out.data_ptr(), codes[dtype], _capi.DGP_SDF_TILED4 if tiled else _capi.DGP_SDF_ROWMAJOR,
+                         ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream(im.device).cuda_stream))
+  if tiled:
+    out._dgp_hw = (Hp, Wp)
+    return out
   return out[0] if squeeze else (out.unsqueeze(1) if channel else out)
 
 

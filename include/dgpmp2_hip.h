@@ -255,8 +255,9 @@ int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch,
                           void* g_sdf, int64_t g_sdf_batch_stride, int32_t g_sdf_copies, void* stream);
 
 /* One iteration of the reference's training loop (learning/train_planner.py:311-327): dgp_gn_step, then the unweighted errors of
- * DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (the sum formed in io_dtype, as torch forms th_curr_b + dthetab) -- two
- * stream-ordered launches behind one call, no th + dtheta tensor in between.  unw_* (B), any may be NULL (all NULL: dgp_gn_step). */
+ * DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (the sum formed in io_dtype, as torch forms th_curr_b + dthetab), no th + dtheta
+ * tensor in between.  unw_* (B), any may be NULL (all NULL: dgp_gn_step).  ONE launch (the step kernels with an errors epilogue) for row-major
+ * grids, num_states <= 128 and static / DGP_QC_SCALAR / per-state (B,n-1,dof,dof) covariances; otherwise two stream-ordered launches. */
 int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
                        const void* th, const void* start, const void* goal,
                        const DgpSdf* sdf, const DgpCovs* covs,
@@ -264,10 +265,10 @@ int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
                        void* unw_sg, void* unw_gp, void* unw_obs, void* stream);
 
 /* Backward of dgp_gn_step_errors: cotangents of dtheta, err_ext and of the three unweighted errors at th + dtheta in, every gradient
- * of dgp_gn_step_backward out (same conventions; g_sdf accumulated).  Two stream-ordered launches: the errors' backward at th + dtheta
- * leaves dL/d(th + dtheta) in `workspace` ((B,n,d) elements of io_dtype, caller-provided: nothing is allocated inside a call) and its
- * share of g_start / g_goal / g_eps / g_sdf; the step's backward adds the workspace to the dtheta cotangent and to g_th and its own
- * share to the small gradients.  No unweighted-error cotangent: exactly dgp_gn_step_backward (workspace may be NULL). */
+ * of dgp_gn_step_backward out (same conventions; g_sdf accumulated).  num_states <= 256: ONE launch -- the errors' backward at th + dtheta runs
+ * as a prologue of the step's backward kernel and hands dL/d(th + dtheta) over in g_th itself (`workspace`, (B,n,d) elements of io_dtype, is needed
+ * only when g_th is NULL); longer trajectories: two stream-ordered launches through `workspace` (caller-provided: nothing is allocated inside a
+ * call).  No unweighted-error cotangent: exactly dgp_gn_step_backward (workspace may be NULL). */
 int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch,
                                 const void* th, const void* start, const void* goal,
                                 const DgpSdf* sdf, const DgpCovs* covs,
@@ -296,13 +297,15 @@ int dgp_square_covariances_backward(const void* raw, int32_t dtype, int32_t batc
  *   sdf = (distance_transform_edt(im) - distance_transform_edt(1 - im)) * res (:16-20; scipy.ndimage underneath),
  * i.e. positive distances to the nearest obstacle pixel in free space, negative distances to the nearest free pixel inside obstacles.
  * image (batch, rows, cols) contiguous, image_dtype DGP_F32 / DGP_F64 / DGP_U8; sdf_out (batch, rows + 2 padlen, cols + 2 padlen),
- * out_dtype DGP_F32 / DGP_F64 (the reference returns float64).  Bit-identical to scipy's result in float64 (squared distances are
+ * out_dtype DGP_F32 / DGP_F64 (the reference returns float64); out_layout DGP_SDF_ROWMAJOR, or DGP_SDF_TILED4: batch grids of ceil(H'/4) * ceil(W'/4) * 16
+ * elements in the tiled layout of DgpSdf::layout (what the GN kernels read with half the cache lines when every trajectory has its own grid; padding cells
+ * of the last tile row / column are not written).  Bit-identical to scipy's result in float64 (squared distances are
  * integers), including its convention for an image with no pixel of the other kind (distances from the pixel at row -1, column 0).
  * workspace: device memory of at least dgp_sdf_2d_workspace_bytes(...) bytes, 4-byte aligned, owned by the call until the stream has
  * passed it.  Two stream-ordered launches (+ one memset of batch words); padded sides up to 8192, batch up to 65535. */
 size_t dgp_sdf_2d_workspace_bytes(int32_t batch, int32_t rows, int32_t cols, int32_t padlen);
 int dgp_sdf_2d(const void* image, int32_t image_dtype, int32_t batch, int32_t rows, int32_t cols, int32_t padlen, double res,
-               void* sdf_out, int32_t out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+               void* sdf_out, int32_t out_dtype, int32_t out_layout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Measurement aid (no counterpart in the reference): the NEXT kernel launched by the calling thread through any entry point
  * above records its own begin and end on the two HIP events (hipEvent_t, created with timing enabled, cast to void*), the way

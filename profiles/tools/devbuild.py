@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
 import isa_stats
 
 CSRC = os.path.join(ROOT, 'dgpmp2_amd', 'csrc')
-ALL = ['%d_%s_g%d' % (d, t, g) for d in (2, 3) for t in ('f32', 'f64') for g in (0, 1, 2, 3, 4)]
+ALL = ['%s_%s_g%d' % (d, t, g) for d in ('2', '3', '2t', '3t', '2e', '3e') for t in ('f32', 'f64') for g in (0, 1, 2, 3, 4)]      # (2t / 3t: the tiled twins, -DDGP_TL=1)
 
 
 def main():
@@ -38,7 +38,7 @@ def main():
   for u in a.units:
     dof, t, g = u.split('_')
     d = os.path.join(work, u); os.makedirs(d)
-    jobs.append(base + ['-DDGP_INST_DOF=' + dof, '-DDGP_INST_F64=%d' % (t == 'f64'), '-DDGP_INST_GROUP=' + g[1], os.path.join(CSRC, 'gn_inst.hip'),
+    jobs.append(base + (['-DDGP_TL=1'] if dof.endswith('t') else (['-DDGP_STEP_ERRS=1'] if dof.endswith('e') else [])) + ['-DDGP_INST_DOF=' + dof.rstrip('te'), '-DDGP_INST_F64=%d' % (t == 'f64'), '-DDGP_INST_GROUP=' + g[1], os.path.join(CSRC, 'gn_inst.hip'),
                         '-o', os.path.join(d, u + '.o')])
   d = os.path.join(work, 'abi'); os.makedirs(d)
   jobs.append(base + [os.path.join(CSRC, 'dgpmp2_hip.hip'), '-o', os.path.join(d, 'abi.o')])
@@ -50,7 +50,7 @@ def main():
   with open(stub, 'w') as f:
     f.write('#include "%s"\n' % os.path.join(CSRC, 'gn_device.h'))
     for u in ALL:
-      if u not in a.units:
+      if u not in a.units and not (u[1] == 'e' and u[-1] not in '03'):
         f.write('hipError_t dgp_launch_%s(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t) { return hipErrorInvalidValue; }\n' % u)
   d = os.path.join(work, 'stubs'); os.makedirs(d)
   jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', stub, '-o', os.path.join(d, 'stubs.o')])

@@ -15,7 +15,7 @@ if os.environ.get('DGP_EDT_LIB'):      # tuning aid: a library holding ONLY csrc
       self.sdf_2d_workspace_bytes = self.lib.dgp_sdf_2d_workspace_bytes; self.sdf_2d_workspace_bytes.restype = C.c_size_t
       self.sdf_2d_workspace_bytes.argtypes = [C.c_int32] * 4
       self.sdf_2d = self.lib.dgp_sdf_2d; self.sdf_2d.restype = C.c_int
-      self.sdf_2d.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+      self.sdf_2d.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
 
     def check(self, rc):
       assert rc == 0, rc

@@ -19,7 +19,13 @@ def short_name(mangled):
   args = []
   for t in re.findall(r'Li\d+E|Lb[01]E|[fd]', m.group(2)):
     args.append({'f': 'float', 'd': 'double'}.get(t) or (('true' if t[2] == '1' else 'false') if t[1] == 'b' else t[2:-1]))
-  return '%s<%s>' % (m.group(1), ','.join(args))
+  # the trailing TL argument of gn_kernel / gn_backward_kernel (the grid layout the translation unit is compiled for, csrc/gn_device.h): the standard kernels keep the
+  # names every table, baseline and tool knows them by; the tiled twins get a suffix
+  tiled = ''
+  if m.group(1) in ('gn_kernel', 'gn_backward_kernel') and len(args) == (7 if m.group(1) == 'gn_kernel' else 7):
+    tiled = {'0': '', '1': '[tiled]', '2': '[errs]'}.get(args[-1], '[twin %s]' % args[-1])
+    args = args[:-1]
+  return '%s<%s>%s' % (m.group(1), ','.join(args), tiled)
 
 
 def parse(path):

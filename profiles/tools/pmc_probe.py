@@ -3,7 +3,7 @@
 corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream, other
 widths uncalibrated), then launches of dgp_gn_step on ONE workload:
    gn_step (BASELINE configs[1], shared SDF) | per_sample_sdf (one 256x256 grid per trajectory; 6 grid sets cycled so that the
-   touched lines do not fit the 256 MiB Infinity Cache) | learned_covariances (per-state tensors) | config4_xyh (d = 6, 512x512)
+   touched lines do not fit the 256 MiB Infinity Cache) | per_sample_sdf_tiled (the same as 4 x 4 tiles) | learned_covariances (per-state tensors) | config4_xyh (d = 6, 512x512)
 usage: python profiles/tools/pmc_probe.py [workload]"""
 import ctypes, os, subprocess, sys
 import torch
@@ -49,6 +49,10 @@ sas = [s.sdf_arg(sdf.data_ptr(), G, G, 0)]
 if workload == 'per_sample_sdf':
   grids = [make_per_sample_sdfs(B, G, dev, seed=1 + i) for i in range(6)]
   sas = [s.sdf_arg(t.data_ptr(), G, G, G * G) for t in grids]
+if workload == 'per_sample_sdf_tiled':      # the same six grid sets stored as 4 x 4 tiles (DgpSdf::layout = DGP_SDF_TILED4)
+  from dgpmp2_amd.utils.sdf_utils import tile_sdf
+  grids = [tile_sdf(make_per_sample_sdfs(B, G, dev, seed=1 + i)) for i in range(6)]
+  sas = [s.sdf_arg(t.data_ptr(), G, G, G * G, layout=_capi.DGP_SDF_TILED4) for t in grids]
 if workload == 'learned_covariances':
   qc = torch.eye(dof, device=dev).expand(B, n - 1, dof, dof).contiguous(); ow = torch.full((B, n), 1e4, device=dev); ep = torch.full((B, n), 0.4, device=dev)
   keep = [qc, ow, ep]

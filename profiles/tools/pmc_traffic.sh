@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-for W in ${PMC_WORKLOADS:-gn_step per_sample_sdf learned_covariances config4_xyh}; do
+for W in ${PMC_WORKLOADS:-gn_step per_sample_sdf per_sample_sdf_tiled learned_covariances config4_xyh}; do
   OUT=$R/gpurun_out/pmc/$W
   mkdir -p "$OUT"
   P="python $R/profiles/tools/pmc_probe.py $W"

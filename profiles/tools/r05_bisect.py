@@ -15,7 +15,7 @@ for lpt, c in T.SHAPES:
     for n in (lpt * c, max(2, lpt * c - 3)):
       B = 64 // lpt + 1
       p, th, start, goal, sdf, qc, ow, eps, q_full = T._inputs(rs, dof, n, B, cov, io)      # (same random stream as the test)
-      if cov not in ('static_full', 'qfull'): continue
+      if cov not in sys.argv[3].split(','): continue
       sh = (B, n, 1, 1)
       okw = dict(qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh), q_full=q_full)
       dth, err, eex, info = be.step(p, th, start, goal, sdf, qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)

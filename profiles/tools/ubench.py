@@ -39,7 +39,7 @@ def main():
   ap.add_argument('--covs', default='static'); ap.add_argument('--dof', type=int, default=2); ap.add_argument('--sdf', default='shared')
   ap.add_argument('--B', type=int, default=4096); ap.add_argument('--n', type=int, default=64); ap.add_argument('--G', type=int, default=0)
   ap.add_argument('--io', default='f32'); ap.add_argument('--flags', default=''); ap.add_argument('--reps', type=int, default=1000)
-  ap.add_argument('--iters', type=int, default=10); ap.add_argument('--tag', default=''); ap.add_argument('--info', type=int, default=1); ap.add_argument('--grids', type=int, default=1, help='per-sample SDF: number of distinct 1 GiB grid sets cycled through (>= 5: the touched lines no longer fit the 256 MiB Infinity Cache)'); ap.add_argument('--th', type=int, default=3, help='GN iterations behind the timed trajectory (0: straight-line init)')
+  ap.add_argument('--iters', type=int, default=10); ap.add_argument('--tag', default=''); ap.add_argument('--info', type=int, default=1); ap.add_argument('--grids', type=int, default=1, help='per-sample SDF: number of distinct 1 GiB grid sets cycled through (>= 5: the touched lines no longer fit the 256 MiB Infinity Cache)'); ap.add_argument('--th', type=int, default=3, help='GN iterations behind the timed trajectory (0: straight-line init)'); ap.add_argument('--layout', default='rowmajor', help="rowmajor | tiled4 (the grids as 4 x 4 tiles, DgpSdf::layout)")
   a = ap.parse_args()
   dev = torch.device('cuda:0')
   dt = torch.float32 if a.io == 'f32' else torch.float64
@@ -56,8 +56,12 @@ def main():
   else:
     stride = 0
   s = _capi.Solver(solver_config(num_states=n, dof=dof, io_dtype=dt, **kw))
-  sa = s.sdf_arg(sdf.data_ptr(), G, G, stride)
-  sas = [s.sdf_arg(t.data_ptr(), G, G, stride) for t in sdfs]
+  lay = _capi.DGP_SDF_ROWMAJOR
+  if a.layout == 'tiled4':
+    from dgpmp2_amd.utils.sdf_utils import tile_sdf
+    sdfs = [tile_sdf(t if t.dim() == 4 else t.reshape(-1, 1, G, G)) for t in sdfs]; sdf = sdfs[0]; lay = _capi.DGP_SDF_TILED4
+  sa = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay)
+  sas = [s.sdf_arg(t.data_ptr(), G, G, stride, layout=lay) for t in sdfs]
   st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
   P = lambda t: None if t is None else t.data_ptr()
   covs, keep = None, []
@@ -83,7 +87,7 @@ def main():
   assert bool(torch.isfinite(ths[-1]).all())
   tp = [t.data_ptr() for t in ths]
   timer = _capi.KernelTimer(min(a.reps, 1000))
-  out = dict(grids=a.grids, tag=a.tag, lib=os.path.basename(_capi.LIB_PATH), B=B, n=n, dof=dof, io=a.io, covs=a.covs, sdf=a.sdf, flags=a.flags, shape=list(s.launch_shape(B)))
+  out = dict(layout=a.layout, grids=a.grids, tag=a.tag, lib=os.path.basename(_capi.LIB_PATH), B=B, n=n, dof=dof, io=a.io, covs=a.covs, sdf=a.sdf, flags=a.flags, shape=list(s.launch_shape(B)))
   for what in a.what.split(','):
     if what == 'step':
       f = lambda k: s.gn_step(B, tp[k % 4], P(start), P(goal), sas[k % len(sas)], covs, P(dth), P(err), P(eex), P(info), st)
@@ -101,6 +105,22 @@ def main():
       trace(0)
       if what == 'traced': f = trace
       else: f = lambda k: s.gn_solve_backward(B, P(start), P(goal), sa, a.iters, P(hist), P(tho), P(it), P(gfin), P(gth), P(gst), P(ggo), None, 0, st)
+    elif what == 'step_errs':      # dgp_gn_step_errors: the step + the unweighted errors at th + dtheta (two launches; `period_us` is the pair, `kernel_us` the first of them)
+      us_, ug_, uo_ = (torch.empty(B, device=dev, dtype=dt) for _ in range(3))
+      f = lambda k: s.gn_step_errors(B, tp[k % 4], P(start), P(goal), sas[k % len(sas)], covs, P(dth), P(err), P(eex), P(info), P(us_), P(ug_), P(uo_), st)
+    elif what in ('bwd_errs', 'bwd_errs_sdf'):      # dgp_gn_step_errors_backward with every cotangent: ONE launch (the errors' backward as the kernel's prologue)
+      g = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
+      ge = torch.ones(B, device=dev, dtype=dt); c1, c2, c3 = (torch.randn(B, device=dev, dtype=dt) for _ in range(3))
+      gq = (torch.empty(B, n - 1, dof, dof, device=dev, dtype=dt) if a.covs == 'scalar' else torch.empty_like(keep[0])) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
+      gp = torch.empty(B, n, device=dev, dtype=dt) if covs else None
+      gs, sab, copies = None, sa, 1
+      if what == 'bwd_errs_sdf':
+        copies = 8 if stride == 0 else 1
+        gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=torch.float64 if stride == 0 else dt)
+        if stride == 0: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_DENSE_F64)
+      s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
+      f = lambda k: s.gn_step_errors_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(c1), P(c2), P(c3), P(gth), P(gst), P(ggo), P(gs), stride,
+                                              P(gq), P(gw), P(gp), None, st, g_sdf_copies=copies)
     elif what == 'eval':
       f = lambda k: s.eval_errors(B, tp[k % 4], P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st)
     elif what.startswith('bwd'):
@@ -116,10 +136,10 @@ def main():
       gs, sab = None, sa
       if what == 'bwd_sparse':
         gs = torch.empty(B * n * 4, device=dev, dtype=dt); gi = torch.empty((4, B * n * 4), device=dev, dtype=torch.int64)
-        sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, grad_mode=_capi.DGP_GSDF_SPARSE, grad_indices=gi.data_ptr())
+        sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_SPARSE, grad_indices=gi.data_ptr())
       elif what != 'bwd':
         gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=torch.float64 if wide else dt)
-        if wide: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, grad_mode=_capi.DGP_GSDF_DENSE_F64)
+        if wide: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_DENSE_F64)
       s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
       f = lambda k: s.gn_step_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(gth), P(gst), P(ggo), P(gs), stride,
                                        P(gq), P(gw), P(gp), st, g_sdf_copies=copies)

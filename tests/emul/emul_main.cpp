@@ -12,6 +12,8 @@
 #include <vector>
 
 #define DGP_HD inline
+#define DGP_STEP_ERRS 1      // the step kernels' errors epilogue compiled in (behind its run-time test of GnParams::unw_*)
+#define DGP_TL 2      // the emulator decides the grid layout at run time (GnParams::sdf_layout): one build for row-major and tiled grids (gn_lane.h)
 #include "../../dgpmp2_amd/csrc/dgp_host.h"
 
 namespace {
@@ -190,13 +192,19 @@ void run_long(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
 }
 
 void run(const DgpHandle* h, const dgp::GnParams& p, const dgp::GnGradParams* g, int mode) {
+  if (p.sdf_layout != 0 && p.sdf && p.n > dgp_host::kMaxStatesTiled) {
+    fprintf(stderr, "emul: tiled grids are implemented for num_states <= 128 (the product library returns DGP_EUNSUPPORTED here)\n");
+    abort();
+  }
   if (dgp_host::is_long(p.n)) {
     const bool f64l = h->cfg.io_dtype == DGP_F64;
     if (h->cfg.dof == 2) { if (f64l) run_long<2, double>(p, g, mode); else run_long<2, float>(p, g, mode); }
     else { if (f64l) run_long<3, double>(p, g, mode); else run_long<3, float>(p, g, mode); }
     return;
   }
-  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p));
+  const bool step_errs = mode == (int)dgp_host::kModeStepErrs;      // dgp_gn_step_errors in one launch: MODE_STEP with the errors epilogue, on the twin kernels' shapes
+  if (step_errs) mode = dgp::MODE_STEP;
+  const DgpShape sh = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(mode, p), step_errs || (p.sdf_layout != 0 && p.sdf != nullptr));      // (the shape the product launches)
   const bool f64 = h->cfg.io_dtype == DGP_F64;
   if (h->cfg.dof == 2) { if (f64) run_all<2, double>(p, g, mode, sh); else run_all<2, float>(p, g, mode, sh); }
   else { if (f64) run_all<3, double>(p, g, mode, sh); else run_all<3, float>(p, g, mode, sh); }
@@ -240,7 +248,7 @@ int emul_num_factor_rows(const DgpHandle* h) { return h ? h->M : DGP_EINVAL; }
 
 // dgp_sdf_2d is not a lane program: nothing to emulate (tests/test_sdf_edt.py checks the HIP kernels against scipy and oracle/edt_oracle.py)
 size_t emul_sdf_2d_workspace_bytes(int32_t, int32_t, int32_t, int32_t) { return 0; }
-int emul_sdf_2d(const void*, int32_t, int32_t, int32_t, int32_t, int32_t, double, void*, int32_t, void*, size_t, void*) {
+int emul_sdf_2d(const void*, int32_t, int32_t, int32_t, int32_t, int32_t, double, void*, int32_t, int32_t, void*, size_t, void*) {
   return dgp_host::fail(DGP_EUNSUPPORTED, "the emulator covers the wavefront lane programs only");
 }
 int emul_time_next_launch(void*, void*) { return DGP_OK; }      // nothing to time: the emulator runs on the host
@@ -316,7 +324,7 @@ int emul_eval_errors_backward(const DgpHandle* h, int32_t batch, const void* th,
 namespace {
 struct EmulLaunch {
   const DgpHandle* h;
-  int operator()(int mode, const dgp::GnParams& p, const dgp::GnGradParams* g) const { run(h, p, g, mode); return DGP_OK; }
+  int operator()(int mode, const dgp::GnParams& p, const dgp::GnGradParams* g) const { run(h, p, g, mode); return DGP_OK; }      // (kModeStepErrs: run() maps it to MODE_STEP on a four-states-per-lane shape)
 };
 }  // namespace
 

@@ -36,6 +36,20 @@ def emul_api():
   return _emul_api
 
 
+def tile_np(a):
+  """(B, 1, H, W) -> (B, 1, ceil(H/4), ceil(W/4), 4, 4): the 4 x 4 tiles of DgpSdf::layout = DGP_SDF_TILED4 (padding cells zero)"""
+  a = np.asarray(a)
+  B, C_, H, W = a.shape
+  Ht, Wt = (H + 3) // 4, (W + 3) // 4
+  p = np.zeros((B, C_, Ht * 4, Wt * 4), dtype=a.dtype); p[:, :, :H, :W] = a
+  return np.ascontiguousarray(p.reshape(B, C_, Ht, 4, Wt, 4).transpose(0, 1, 2, 4, 3, 5))
+
+
+def untile_np(t, hw):
+  B, C_, Ht, Wt = t.shape[:4]
+  return np.ascontiguousarray(t.transpose(0, 1, 2, 4, 3, 5).reshape(B, C_, Ht * 4, Wt * 4)[:, :, :hw[0], :hw[1]])
+
+
 def config_from_oracle(p, io):
   """oracle.OracleParams -> DgpConfig."""
   return _capi.make_config(num_states=p.n, dof=p.dof, io_dtype=_capi.DGP_F64 if io == 'f64' else _capi.DGP_F32,
@@ -58,6 +72,7 @@ class Backend(object):
       self.api = _capi.get_api()
     self._keep = []
     self.misalign = False      # True: hand the C-ABI buffers that start one element past a 16-byte boundary (scalar row access path)
+    self.sdf_tiled = False     # True: every grid goes down as 4 x 4 tiles (DgpSdf::layout = DGP_SDF_TILED4) and dense grid gradients come back untiled -- any parity case can be re-run on the tiled layout
 
   # -- memory ------------------------------------------------------------------------------------
   def _np_dtype(self, io): return np.float64 if io == 'f64' else np.float32
@@ -111,9 +126,14 @@ class Backend(object):
       sdf = np.asarray(sdf)
       assert sdf.ndim == 4 and sdf.shape[1] == 1
       shared = sdf.shape[0] == 1 and B >= 1
-      _, sdf_p = self.to_dev(sdf, io)
       H, W = sdf.shape[-2], sdf.shape[-1]
-      sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
+      if self.sdf_tiled:
+        til = tile_np(sdf)
+        _, sdf_p = self.to_dev(til, io)
+        sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else til[0].size, layout=_capi.DGP_SDF_TILED4)
+      else:
+        _, sdf_p = self.to_dev(sdf, io)
+        sdf_arg = solver.sdf_arg(sdf_p, H, W, 0 if shared else H * W)
     mode = _capi.DGP_QC_STATIC if qc is None else (_capi.DGP_QC_QFULL if q_full else _capi.DGP_QC_PERSTATE)
     if qc is not None and np.asarray(qc).ndim == 2: mode = _capi.DGP_QC_SCALAR      # (B, n-1) scalars: Q_c^-1 = s_k Q_c_inv (dgp_gn_step only)
     if raw is not None:
@@ -143,6 +163,14 @@ class Backend(object):
     COO indices; `passes` tap blocks, zero-filled as the chain kernels' caller must).  -> (state for _gsdf_out, g_sdf address, batch stride)"""
     sdf = np.asarray(sdf)
     stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    if self.sdf_tiled:
+      # a tiled grid takes a dense gradient in its own layout (sparse taps carry row-major indices: the dense form stands in, same values once untiled)
+      H, W = sdf.shape[-2], sdf.shape[-1]
+      tshape = ((sdf_copies if sdf_copies > 1 else sdf.shape[0]), 1, (H + 3) // 4, (W + 3) // 4, 4, 4)
+      wide = sdf_grad == 'f64'
+      g, g_p = self.empty(tshape, dtype=np.float64, fill=0.0) if wide else self.empty(tshape, io, fill=0.0)
+      if wide: sdf_arg.grad_mode = _capi.DGP_GSDF_DENSE_F64
+      return ('tiled', g, (H, W)), g_p, (0 if sdf.shape[0] == 1 else tshape[2] * tshape[3] * 16)
     if sdf_grad == 'sparse':
       assert sdf_copies == 1 and stride != 0
       nnz = passes * B * n * 4
@@ -162,6 +190,7 @@ class Backend(object):
     """-> the gradient as a float64 array: the grid(s) as written (partial copies unsummed), or the sparse taps scattered into a grid of sdfb's shape"""
     if st is None: return None
     if st[0] == 'dense': return self.to_np(st[1])
+    if st[0] == 'tiled': return untile_np(self.to_np(st[1]), st[2])
     vals = self.to_np(st[1])
     if self.kind == 'emul': idx = np.array(st[2])
     else:
@@ -299,7 +328,7 @@ class Backend(object):
 
   def step_errors_backward(self, p, th, start, goal, sdf, dtheta, g_dtheta, g_err_ext, g_unw_sg, g_unw_gp, g_unw_obs, qc=None, ow=None, eps=None,
                            q_full=False, io='f64', sdf_copies=1, sdf_grad='dense', raw=None):
-    """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps (raw: `out`)"""
+    """dgp_gn_step_errors_backward -> dict of gradients: th, start, goal, sdf, qc, ow, eps (raw: `out`).  sdf_grad 'none': no grid gradient requested"""
     solver, B, th_p, st_p, go_p, sdf_arg, covs = self._common(p, io, th, start, goal, sdf, qc, ow, eps, q_full, raw)
     n = th.shape[1]
     _, dth_p = self.to_dev(dtheta, io)
@@ -309,7 +338,7 @@ class Backend(object):
     gst, gst_p = self.empty(np.asarray(start).shape, io)
     ggo, ggo_p = self.empty(np.asarray(goal).shape, io)
     errs = any(c is not None for c in (g_unw_sg, g_unw_gp, g_unw_obs))
-    gs, gsdf_p, stride = self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n, passes=2 if errs else 1)
+    gs, gsdf_p, stride = (None, None, 0) if sdf_grad == 'none' else self._gsdf(sdf, sdf_arg, io, sdf_copies, sdf_grad, B, n, passes=2 if errs else 1)
     qshape = None if qc is None else (np.asarray(qc).shape if np.asarray(qc).ndim != 2 else np.asarray(qc).shape + (p.dof, p.dof))      # DGP_QC_SCALAR: the gradient of the blocks s_k I
     gqc, gqc_p = self.empty(qshape, io) if qc is not None else (None, None)
     gow, gow_p = self.empty((B, n), io) if ow is not None else (None, None)

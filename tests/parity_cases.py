@@ -762,8 +762,11 @@ def case_step_errors(be, golden, io):
   npdt = np.float64 if io == 'f64' else np.float32
   th_new = (th.astype(npdt) + d2.astype(npdt)).astype(np.float64)
   _, _, s2, g2, o2 = be.eval_errors(p, th_new, st, go, sdf, eps=eps, io=io)
-  assert np.array_equal(dth, d2) and np.array_equal(err, e2) and np.array_equal(eex, x2)
-  assert np.array_equal(usg, s2) and np.array_equal(ugp, g2) and np.array_equal(uobs, o2)
+  # (to rounding, not bit for bit, since round 5: with a row-major grid and up to 128 states the call is ONE launch of the step kernels that carry the errors epilogue -- a
+  #  separate compilation of the same source, whose FMA contraction may differ from the standard kernels')
+  same = lambda a_, b_: rel_err(a_, b_) < (1e-12 if io == 'f64' else 2e-6)
+  assert same(dth, d2) and same(err, e2) and same(eex, x2) and np.array_equal(info, i2)
+  assert same(usg, s2) and same(ugp, g2) and same(uobs, o2)
   tolv = 1e-11 if io == 'f64' else 3e-5
   assert rel_err(dth, g['b_dth']) < TOL[io]
   for got, key in ((usg, 'b_sg'), (ugp, 'b_gp'), (uobs, 'b_obs')):
@@ -916,7 +919,7 @@ def case_raw_squared_covariances(be, golden, io):
     # the training iteration: forward and the single-launch backward
     ea = be.step_errors(p, th, st, go, sdf, raw=raw, io=io)
     eb = be.step_errors(p, th, st, go, sdf, qc=qc, ow=ow, eps=eps, io=io)
-    for x, y in zip(ea, eb): assert np.array_equal(x, y)
+    for x, y in zip(ea, eb): assert np.array_equal(x, y)      # (the same launches on the same squared values)
     fa = be.step_errors_backward(p, th, st, go, sdf, ea[0], gd, ce, cs, cg, co, raw=raw, io=io)
     fb = be.step_errors_backward(p, th, st, go, sdf, ea[0], gd, ce, cs, cg, co, qc=qc, ow=ow, eps=eps, io=io)
     for k in ('th', 'start', 'goal'): assert np.array_equal(fa[k], fb[k]), k

@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = [(l, c) for l in (16, 32, 64) for c in (1, 2, 4)]
 COVS = ['static', 'static_full', 'perstate', 'qfull']
+ERRS_LENGTHS = (64, 37, 128, 100)      # test_hip_every_step_errors_kernel: the 16- and the 32-lane shape, exact fit and ragged
 
 
 @pytest.fixture(scope='module')
@@ -36,6 +37,7 @@ def _inputs(rs, dof, n, B, cov, io):
   if cov == 'static_full':
     A = rs.randn(dof, dof) * 0.3
     kw['Q_c_inv'] = np.eye(dof) + A @ A.T
+  if cov == 'static_diag': kw['Q_c_inv'] = np.diag(1.0 + 0.5 * np.arange(dof))      # diagonal, not c I: the block-elimination static kernels, no Woodbury
   p = O.OracleParams(dof=dof, total_time_step=n - 1, reg=0.1, epsilon_dist=0.3, **kw)
   H, W = 24, 40
   yy, xx = np.meshgrid(np.linspace(5, -5, H), np.linspace(-5, 5, W), indexing='ij')
@@ -165,6 +167,51 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
         # systems here.  The fp64 run pins the mathematics at 1e-6; this one only has to catch code-generation faults (O(1) errors).
         if not eb < (1e-6 if io == 'f64' else 2e-3): bad.append((tag, key, eb))
   assert not bad, '%d backward results differ from the autograd oracle:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_step_errors_kernel(be, dof, io, monkeypatch):
+  """Round 5: the step kernels with the errors epilogue (gn_inst.hip compiled with -DDGP_STEP_ERRS=1: 2 robots x 2 I/O types x the two four-states-per-lane shapes x
+  Woodbury exact / ragged, block elimination, scaled, Kronecker -- dgp_gn_step_errors as ONE launch) against the two launches they replace (the standard step kernel and
+  the error kernel, themselves pinned to the C oracle above), and the errors' backward as the PROLOGUE of every backward kernel shape that holds the trajectory against
+  its two halves run by hand (dgp_eval_errors_backward at th + dtheta, then dgp_gn_step_backward with that gradient joined to the dtheta cotangent)."""
+  rs = np.random.RandomState(500 * dof + (io == 'f32'))
+  npdt = np.float64 if io == 'f64' else np.float32
+  bad = []
+  for n in ERRS_LENGTHS:
+    for cov in ('static', 'static_diag', 'scalar', 'perstate'):
+      monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
+      B = 6
+      p, th, start, goal, sdf, qc, ow, eps, _ = _inputs(rs, dof, n, B, 'perstate' if cov == 'scalar' else cov, io)
+      if cov == 'scalar': qc = PC.rnd(rs.uniform(0.3, 3.0, (B, n - 1)) ** 2, io)
+      kw = dict(qc=qc, ow=ow, eps=eps, io=io)
+      tag = 'dof %d %s n %d cov %s' % (dof, io, n, cov)
+      fw = be.step_errors(p, th, start, goal, sdf, **kw)
+      d2, e2, x2, i2 = be.step(p, th, start, goal, sdf, **kw)
+      th_new = (th.astype(npdt) + d2.astype(npdt)).astype(np.float64)
+      _, _, s2, g2, o2 = be.eval_errors(p, th_new, start, goal, sdf, eps=eps, io=io)
+      tol = 1e-10 if io == 'f64' else 2e-5
+      for name, a_, b_ in (('dtheta', fw[0], d2), ('err', fw[1], e2), ('err_ext', fw[2], x2), ('unw_sg', fw[4], s2), ('unw_gp', fw[5], g2), ('unw_obs', fw[6], o2)):
+        e = PC.rel_err(a_, b_) if np.all(np.isfinite(a_)) else np.inf
+        if not e < tol: bad.append((tag, name, e))
+      if fw[3].any(): bad.append((tag, 'info'))
+      # ---- the backward prologue, every shape that holds n states
+      gd = PC.rnd(rs.randn(B, n, 2 * dof), io); ce = PC.rnd(rs.randn(B), io)
+      cs, cg, co = (PC.rnd(rs.randn(B), io) for _ in range(3))
+      h1 = be.eval_backward(p, th_new, start, goal, sdf, None, cs, cg, co, eps=eps, io=io)
+      h2 = be.backward(p, th, start, goal, sdf, d2, (gd.astype(npdt) + h1['th'].astype(npdt)).astype(np.float64), ce, **kw)
+      want = dict(th=h2['th'] + h1['th'], start=h2['start'] + h1['start'], goal=h2['goal'] + h1['goal'], qc=h2['qc'], ow=h2['ow'],
+                  eps=None if eps is None else h2['eps'] + h1['eps'])
+      for lpt, c in [(None, None)] + [sh for sh in SHAPES if sh[0] * sh[1] >= n]:
+        if lpt is not None: monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+        if os.environ.get('DGP_TEST_VERBOSE'): print(tag, 'backward shape', (lpt, c), flush=True)      # (a wild store aborts the process: run with -s to see where)
+        r = be.step_errors_backward(p, th, start, goal, sdf, fw[0], gd, ce, cs, cg, co, sdf_grad='none', **kw)
+        for key in ('th', 'start', 'goal', 'qc', 'ow', 'eps'):
+          if want[key] is None or r[key] is None: continue
+          eb = np.abs(r[key] - want[key]).max() / max(np.abs(want[key]).max(), 1e-300) if np.all(np.isfinite(r[key])) else np.inf
+          if not eb < (1e-8 if io == 'f64' else 2e-3): bad.append((tag, 'backward shape %s' % ((lpt, c),), key, eb))
+  assert not bad, '%d step-errors results differ:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
 @pytest.mark.parametrize('io', ['f64', 'f32'])

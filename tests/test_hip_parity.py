@@ -23,6 +23,45 @@ def test_hip_case(be, golden, case, io):
   case(be, golden, io)
 
 
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+def test_hip_tiled_grids(golden, io):
+  """DgpSdf::layout = DGP_SDF_TILED4: parity cases re-run with every grid stored as 4 x 4 tiles (harness.Backend.sdf_tiled) -- per-sample and shared grids, odd-sized
+  and non-square ones (padding cells), trajectories leaving the grid, both robots, the fused loop, the backward pass (dense gradients come back tiled and are
+  untiled for the comparison), the training iteration."""
+  bt = harness.Backend('hip'); bt.sdf_tiled = True
+  for case in (PC.case_c2mini_per_sample_sdf, PC.case_c2mini_covs, PC.case_edges, PC.case_c1, PC.case_c4_xyh, PC.case_solve, PC.case_backward_golden,
+               PC.case_shared_sdf_gradient_partial_copies, PC.case_sdf_gradient_delivery, PC.case_step_errors, PC.case_solve_backward, PC.case_eval_errors_backward):
+    case(bt, golden, io)
+  # the 64-lane launch shapes (more than 128 states) are compiled without the tiled branch: refused, not silently read as row-major
+  from dgpmp2_amd import _capi
+  p = PC.P2d(160)
+  th = np.zeros((2, 160, 4)); st = np.zeros((2, 1, 4)); sdf = np.ones((1, 1, 16, 16))
+  with pytest.raises(_capi.DgpError) as e:
+    bt.step(p, th, st, st, sdf, io=io)
+  assert e.value.code == _capi.DGP_EUNSUPPORTED and 'tiled' in str(e.value)
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+def test_hip_c2_tiled_equals_row_major(io):
+  """BASELINE config 2's shape with 1024 DISTINCT grids: the step on the tiled grids equals the step on the row-major ones to rounding (the same taps read from
+  another address -- but by the tiled translation units, a separate compilation of the same source whose FMA contraction may differ), and so does the per-sample
+  grid gradient once untiled."""
+  B, n, G = 1024, 64, 256
+  p = PC.P2d(n)
+  th, start, goal, _ = _c2_inputs(B, n, G, seed=0, perturb=0.05)
+  rs = np.random.RandomState(5)
+  base = O.circles_sdf(G, O.C2_CIRCLES)
+  sdf = (base[None, None] + 0.02 * rs.randn(B, 1, 1, 1) + 0.01 * rs.randn(1, 1, G, G)).astype(np.float64)      # (distinct grids without 2 GiB of host memory)
+  th, start, goal, sdf = PC.rnd(th, io), PC.rnd(start, io), PC.rnd(goal, io), PC.rnd(sdf, io)
+  br = harness.Backend('hip'); bt = harness.Backend('hip'); bt.sdf_tiled = True
+  a = br.step(p, th, start, goal, sdf, io=io); b = bt.step(p, th, start, goal, sdf, io=io)
+  tol = 1e-11 if io == 'f64' else 2e-6
+  assert PC.rel_err_per_traj(a[0], b[0]) < tol and rel_err(a[1], b[1]) < tol and rel_err(a[2], b[2]) < tol and np.array_equal(a[3], b[3])
+  gd = PC.rnd(rs.randn(B, n, 4), io)
+  ga = br.backward(p, th, start, goal, sdf, a[0], gd, None, io=io); gb = bt.backward(p, th, start, goal, sdf, a[0], gd, None, io=io)
+  assert rel_err(ga['th'], gb['th']) < 100 * tol and rel_err(ga['sdf'], gb['sdf']) < (1e-9 if io == 'f64' else 1e-4) and np.abs(ga['sdf']).max() > 0
+
+
 def _c2_inputs(B, n, G, seed=0, perturb=0.0):
   rs = np.random.RandomState(seed)
   start = np.concatenate([rs.uniform(-4, 4, (B, 1, 2)), np.zeros((B, 1, 2))], -1)

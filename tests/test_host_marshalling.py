@@ -151,7 +151,7 @@ def test_per_state_covariances_and_backward_arguments(layer):
 
 
 def test_shared_grid_gradient_uses_partial_copies(layer):
-  B = 3
+  B = 512                                                                      # (B n >= 8192 taps: one partial grid per XCD; a small batch accumulates into a single grid)
   th, st, go, sdf = _inputs(B)
   sdf.requires_grad_(True)
   dth, err, eex = layer(th, st, go, None, sdf.expand(B, 1, 8, 10), None, None, None)
@@ -170,6 +170,10 @@ def test_shared_grid_gradient_uses_partial_copies(layer):
   dth, err, eex = layer(th, st, go, None, flat[None, None].expand(B, 1, 8, 10), None, None, None)
   dth.sum().backward()
   assert layer._pc.calls[-1][0] == 'sum_partial_grids' and layer._pc.calls[-1][1][4] == 1.0 / B and flat.grad.shape == flat.shape
+  th3, st3, go3, _ = _inputs(3)
+  sdf3 = torch.randn(1, 1, 8, 10, requires_grad=True)
+  layer(th3, st3, go3, None, sdf3.expand(3, 1, 8, 10), None, None, None)[0].sum().backward()
+  assert layer._pc.calls[-2][1][24] == 1 and layer._pc.calls[-1][1][2] == 1      # 48 taps: one grid, device-scope atomics (still float64, still cast by the sum kernel)
 
 
 def test_per_sample_grid_gradient_as_sparse_taps(layer):
@@ -242,7 +246,7 @@ def test_input_validation(layer):
 def test_real_trampoline_argument_counts():
   pc = _capi.get_pycall()
   for name, n in (('gn_step', 21), ('gn_solve', 25), ('eval_errors', 22), ('gn_step_backward', 29), ('eval_errors_backward', 28), ('sum_partial_grids', 8),
-                  ('square_covariances', 13), ('square_covariances_backward', 13)):
+                  ('square_covariances', 13), ('square_covariances_backward', 13), ('gn_step_errors', 24), ('gn_step_errors_backward', 33)):
     with pytest.raises(TypeError):
       getattr(pc, name)(*([0] * (n - 1)))
   # a NULL handle comes back as the C-ABI's DGP_EINVAL, not as a crash

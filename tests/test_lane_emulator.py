@@ -44,6 +44,18 @@ def test_emul_step_errors(be, golden): PC.case_step_errors(be, golden, 'f64')
 def test_emul_step_errors_f32(be, golden): PC.case_step_errors(be, golden, 'f32')
 def test_emul_sdf_gradient_delivery(be, golden): PC.case_sdf_gradient_delivery(be, golden, 'f64')
 def test_emul_sdf_gradient_delivery_f32(be, golden): PC.case_sdf_gradient_delivery(be, golden, 'f32')
+def test_emul_tiled_grids(golden):
+  """DgpSdf::layout = DGP_SDF_TILED4 (round 5): parity cases re-run with every grid stored as 4 x 4 tiles and the dense grid gradients untiled -- per-sample and
+  shared grids, non-square / odd-sized grids (padding cells), trajectories leaving the grid, the backward pass with partial copies and the training iteration."""
+  bt = harness.Backend('emul'); bt.sdf_tiled = True
+  PC.case_c2mini_per_sample_sdf(bt, golden, 'f64', nb=3)
+  PC.case_edges(bt, golden, 'f64')
+  PC.case_c1(bt, golden, 'f64', steps=(0,))
+  PC.case_backward_golden(bt, golden, 'f64')
+  PC.case_backward_golden(bt, golden, 'f32')
+  PC.case_shared_sdf_gradient_partial_copies(bt, golden, 'f64')
+  PC.case_sdf_gradient_delivery(bt, golden, 'f32')
+  PC.case_step_errors(bt, golden, 'f64')
 def test_emul_raw_squared_covariances(be, golden): PC.case_raw_squared_covariances(be, golden, 'f64')
 def test_emul_raw_squared_covariances_f32(be, golden): PC.case_raw_squared_covariances(be, golden, 'f32')
 

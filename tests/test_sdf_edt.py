@@ -72,11 +72,12 @@ def test_capi_rejects_bad_arguments_without_launching():
 
   def call(**kw):
     a = dict(ok); a.update(kw)
-    return api.sdf_2d(a['image'], a['image_dtype'], a['batch'], a['rows'], a['cols'], a['padlen'], a['res'], a['out'], a['out_dtype'], a['ws'], a['ws_bytes'], None)
+    return api.sdf_2d(a['image'], a['image_dtype'], a['batch'], a['rows'], a['cols'], a['padlen'], a['res'], a['out'], a['out_dtype'], a.get('layout', _capi.DGP_SDF_ROWMAJOR),
+                      a['ws'], a['ws_bytes'], None)
 
   assert call(image=None) == _capi.DGP_EINVAL and call(out=None) == _capi.DGP_EINVAL and call(ws=None) == _capi.DGP_EINVAL
   assert call(batch=0) == _capi.DGP_EINVAL and call(rows=0) == _capi.DGP_EINVAL and call(padlen=-1) == _capi.DGP_EINVAL
-  assert call(image_dtype=7) == _capi.DGP_EINVAL and call(out_dtype=_capi.DGP_U8) == _capi.DGP_EINVAL
+  assert call(image_dtype=7) == _capi.DGP_EINVAL and call(out_dtype=_capi.DGP_U8) == _capi.DGP_EINVAL and call(layout=5) == _capi.DGP_EINVAL
   assert call(ws_bytes=16) == _capi.DGP_EINVAL and b'workspace' in api.last_error()
   assert call(rows=20000) == _capi.DGP_EUNSUPPORTED and call(batch=70000) == _capi.DGP_EUNSUPPORTED
   assert call(ws=p + 1) == _capi.DGP_EINVAL
@@ -126,6 +127,23 @@ def test_hip_matches_scipy_and_oracle_on_ragged_batches(H, W, fill, pad):
   np.testing.assert_array_equal(_gpu((ims * 255).astype(np.uint8), padlen=pad, res=0.04), out)
   import torch
   np.testing.assert_array_equal(_gpu(ims, padlen=pad, res=0.04, dtype=torch.float32), out.astype(np.float32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('H,W,pad', [(64, 64, 0), (254, 254, 1), (17, 23, 1), (63, 65, 3), (3, 70, 0)])
+def test_hip_tiled_output_is_the_tiled_row_major_field(H, W, pad):
+  """sdf_2d_batch(layout='tiled4') writes the same field as 4 x 4 tiles (DgpSdf::layout = DGP_SDF_TILED4): untiled, bit-identical to the row-major result; tagged with its
+  logical size; equal to tile_sdf() of the row-major tensor (padding cells zero)."""
+  import torch
+  rs = np.random.RandomState(H + 7 * W)
+  ims = torch.as_tensor(_random_images(rs, 4, H, W, 0.7)).cuda()
+  for dt in (torch.float64, torch.float32):
+    rm = sdf_utils.sdf_2d_batch(ims, padlen=pad, res=0.04, dtype=dt)
+    tl = sdf_utils.sdf_2d_batch(ims, padlen=pad, res=0.04, dtype=dt, layout='tiled4')
+    Hp, Wp = H + 2 * pad, W + 2 * pad
+    assert tl.shape == (4, 1, (Hp + 3) // 4, (Wp + 3) // 4, 4, 4) and tl._dgp_hw == (Hp, Wp)
+    assert torch.equal(sdf_utils.untile_sdf(tl)[:, 0], rm)
+    assert torch.equal(sdf_utils.tile_sdf(rm.unsqueeze(1)), tl)
 
 
 @pytest.mark.gpu
