@@ -428,7 +428,11 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   if (errs && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors is not implemented for num_states > 256");
   // ONE launch where the step kernels with the errors epilogue exist (round 5): row-major grid, up to 128 states (the two four-states-per-lane shapes), the static /
   // scaled / per-state Kronecker families; everything else: the error kernel stream-ordered behind the step, as in round 4
-  if (errs && p.sdf_layout == 0 && p.n <= kMaxStatesTiled && dgp::kernel_variant(p) != dgp::QK_GENERAL && !h->force_lpt) {
+  // (not the d = 6 block-elimination static kernels -- a diagonal Q_c_inv that is not c I, or velocity limits: hipcc 7.0 miscompiled the twin <3,16,4,float,STEP,static>,
+  //  dtheta wrong by O(1), found by tests/test_hip_every_kernel.py::test_hip_every_step_errors_kernel; the d = 6 Woodbury, scaled and Kronecker twins are verified there)
+  const int qk = dgp::kernel_variant(p);
+  const bool twin_ok = qk != dgp::QK_GENERAL && !(h->cfg.dof == 3 && qk == dgp::QK_STATIC && !p.wb_ok);
+  if (errs && p.sdf_layout == 0 && p.n <= kMaxStatesTiled && twin_ok && !h->force_lpt) {
     p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
     return launch((int)kModeStepErrs, p, (const dgp::GnGradParams*)nullptr);
   }
@@ -454,15 +458,17 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
   if (errs && !dtheta) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs dtheta when an unweighted-error cotangent is given");
   if (errs && !is_long(h ? h->cfg.num_states : 0)) {
     // ONE launch (round 5): the errors' backward at th + dtheta runs as a prologue of the step's backward kernel (gn_backward.h: unweighted_errors_prologue) and hands
-    // its trajectory gradient over in g_th itself (or in the workspace when g_th is not wanted)
+    // its trajectory gradient over in the lane's LDS slots (d = 4) or in g_th itself (d = 6; in the workspace when g_th is not wanted)
+    const bool lds_handover = h->cfg.dof == 2;
     void* buf = g_th ? g_th : workspace;
-    if (!buf) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs g_th or a (B,n,d) workspace when an unweighted-error cotangent is given");
+    if (!buf && !lds_handover) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs g_th or a (B,n,d) workspace when an unweighted-error cotangent is given");
     int rc = fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
                            g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
     if (rc != DGP_OK) return rc;
     g.f_unw_sg = g_unw_sg; g.f_unw_gp = g_unw_gp; g.f_unw_obs = g_unw_obs; g.f_addend = dtheta;
-    g.g_th_new = buf; g.accumulate = 1; g.g_sdf_passes = 2;
-    p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && aligned16(buf)) ? 1 : 0;
+    g.g_sdf_passes = 2;
+    if (!lds_handover) { g.g_th_new = buf; g.accumulate = 1; }
+    p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && (lds_handover ? aligned16(g_th) : aligned16(buf))) ? 1 : 0;
     return launch((int)kModeBackward, p, &g);
   }
   if (errs) {

@@ -154,7 +154,7 @@ template <int DOF, bool CHAIN> struct BwdParks {
 // sparse gradient).  Same formulas as the rows of gn_backward_lane_program with lambda = 0, ebar = 0.  (A first version ordered the stores before the main
 // program's loads with an agent-scope fence -- an L2 write-back per wavefront on gfx950: 57 instead of 36 us; with a workgroup-scope fence 31 us: the store
 // round trip in front of the main program's first loads.)
-template <int DOF, int LPT, int C, typename IO, typename Ctx>
+template <int DOF, int LPT, int C, typename IO, bool PARK, typename Ctx>
 DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp, Ctx& cx, const double (&th_rows)[C][2 * DOF], const double (&dq)[C][2 * DOF],
                                        const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], double (&gfold)[C][2 * DOF]) {
   constexpr int D = 2 * DOF;
@@ -192,6 +192,10 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
 #pragma unroll
     for (int a = 0; a < D; ++a) gfold[k][a] = 0.0;
   }
+  // PARK (d = 4): nothing is stored to memory here -- the rows and the shares of g_start / g_goal / g_eps go to the lane's LDS slots (FoldSlots) below
+  double sh_s[D], sh_g[D], sh_e[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) { sh_s[a] = 0.0; sh_g[a] = 0.0; sh_e[a] = 0.0; }
 #pragma unroll
   for (int k = 0; k < C; ++k) {
     const int g = g0 + k;
@@ -209,7 +213,8 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
       for (int a = 0; a < D; ++a) {
         const double t = gsg * ((is_start ? mu_s[a] : mu_g[a]) - xk[a]);
         gx[a] -= t;
-        if (gmu) st<IO>(gmu, b * D + a, t);
+        if constexpr (PARK) { if (is_start) sh_s[a] = t; else sh_g[a] = t; }
+        else if (gmu) st<IO>(gmu, b * D + a, t);
       }
     }
     if (g < n - 1) {                                  // 1/2 |x_{g+1} - Phi x_g|^2 / (n - 1): this row's share is -Phi^T e
@@ -246,10 +251,22 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
         }
       }
     }
-    if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
-    st_row<IO, D>((void*)gp.g_th_new, b * n + g, vec, gx);
+    if constexpr (PARK) {
+      sh_e[k] = g_eps;
+    } else {
+      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
+      st_row<IO, D>((void*)gp.g_th_new, b * n + g, vec, gx);
+    }
 #pragma unroll
     for (int a = 0; a < D; ++a) gfold[k][a] = gx[a];
+  }
+  if constexpr (PARK) {
+    static_assert(C <= D, "the epsilon shares of a lane's C states travel in one d-vector");
+#pragma unroll
+    for (int k = 0; k < C; ++k) fold_put<C, D>(cx.chain_lds(), lane, k, gfold[k]);
+    fold_put<C, D>(cx.chain_lds(), lane, C, sh_s);
+    fold_put<C, D>(cx.chain_lds(), lane, C + 1, sh_g);
+    fold_put<C, D>(cx.chain_lds(), lane, C + 2, sh_e);
   }
   if (gp.g_sdf && has_grid) {
     if (gp.g_sdf_mode == GSDF_SPARSE) sdf_emit_sparse<C, IO>(p, gp, b, g0, traj_ok, gp.g_sdf_pass0 + 1, (int64_t)gp.g_sdf_passes * p.B * p.n * 4, taps, tap_i, tap_v);
@@ -283,6 +300,11 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   const bool vec = p.vec_io != 0;
   double x[C][D], gbar[C][D], lam[C][D], mu_s[D], mu_g[D];
   bool folded = false;
+#ifndef DGP_BWD_FOLD
+#define DGP_BWD_FOLD 1             // 0: compile the prologue out (A/B builds, profiles/tools/devbuild.py: what its presence costs the plain step backward)
+#endif
+  // d = 4: the prologue hands its results to the main program through the lane's LDS slots (FoldSlots) instead of through g_th / g_start / g_goal / g_eps
+  constexpr bool kFoldLds = !CHAIN && DOF == 2 && DGP_BWD_FOLD != 0;
   // d = 4: a fully populated wavefront block whose length fills the shape moves its row tensors (th, the dtheta cotangent, dtheta in;
   // g_th out) as full cache lines through the LDS staging block, as the forward step does (load / store_rows_through_lds; the output
   // write-through) instead of 16 bytes per lane at a 64-byte stride.  Wave-uniform.
@@ -311,16 +333,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
-#ifndef DGP_BWD_FOLD
-#define DGP_BWD_FOLD 1             // 0: compile the prologue out (A/B builds, profiles/tools/devbuild.py: what its presence costs the plain step backward)
-#endif
   if constexpr (!CHAIN && DGP_BWD_FOLD != 0) {
     if (gp.f_addend) {             // wave-uniform: dgp_gn_step_errors_backward in one launch -- the errors' share of the dtheta cotangent arrives in gbar
       double dq[C][D], gd[C][D];
       load_rows(gp.f_addend, dq);
       const bool have_gd = gp.g_dtheta != nullptr;
       if (have_gd) load_rows(gp.g_dtheta, gd);      // (in flight under the prologue's arithmetic)
-      unweighted_errors_prologue<DOF, LPT, C, IO>(p, gp, cx, x, dq, mu_s, mu_g, gbar);
+      unweighted_errors_prologue<DOF, LPT, C, IO, kFoldLds>(p, gp, cx, x, dq, mu_s, mu_g, gbar);
       if (have_gd) {
 #pragma unroll
         for (int k = 0; k < C; ++k)
@@ -348,7 +367,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         for (int a = 0; a < D; ++a) gbar[k][a] += gnew[k][a];
     }
   }
-  const bool have_gbar = gp.g_dtheta != nullptr || (!CHAIN && gp.g_th_new != nullptr);
+  const bool have_gbar = gp.g_dtheta != nullptr || (!CHAIN && gp.g_th_new != nullptr) || folded;
+  const bool lds_fold = kFoldLds && folded;      // wave-uniform
   LaneQ<D, C, QK> lq;              // generic covariances: Q^-1 of the lane's C + 1 GP factors, shared by the adjoint solve and the chain rule
   load_lane_Q<DOF, C, IO>(p, b, g0, traj_ok, lq);
   // ---- CHAIN: running cotangent (starts as the cotangent of th_final, loaded into gbar above), accumulated mean gradients, pass count
@@ -529,6 +549,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   int32_t tap_i[C][4];
   IO tap_v[C][4];
   double gxs[kBlockRows ? C : 1][D];              // block_rows: the g_th rows, stored together behind the row loop
+  double eold[D];                                 // the prologue's shares of the lane's epsilon gradients (LDS hand-over), else zero
+#pragma unroll
+  for (int a = 0; a < D; ++a) eold[a] = 0.0;
+  if constexpr (kFoldLds) { if (lds_fold) fold_get<C, D>(cx.chain_lds(), lane, C + 2, eold); }
 #pragma unroll
   for (int k = 0; k < C; ++k)
 #pragma unroll
@@ -557,6 +581,10 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       const double w = is_start ? p.w_s : p.w_g;
       double tacc[kLean ? D : 1];
       if constexpr (kLean) chain_get<C, D>(cx.chain_lds(), lane, is_start ? C : C + 1, tacc);
+      double told[D];              // the prologue's share of this mean's gradient (LDS hand-over), else zero
+#pragma unroll
+      for (int a = 0; a < D; ++a) told[a] = 0.0;
+      if constexpr (kFoldLds) { if (lds_fold) fold_get<C, D>(cx.chain_lds(), lane, is_start ? C : C + 1, told); }
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double ea = (is_start ? mu_s[a] : mu_g[a]) - xk[a];
@@ -569,7 +597,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
         } else {
           if (gmu) {
             if (gp.accumulate) st<IO>(gmu, b * D + a, t + ld<IO>(gmu, b * D + a));
-            else st<IO>(gmu, b * D + a, t);
+            else st<IO>(gmu, b * D + a, t + told[a]);
           }
         }
       }
@@ -738,7 +766,7 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       }
       if (gp.g_eps) {
         if (gp.accumulate) st<IO>(gp.g_eps, b * n + g, g_eps + ld<IO>(gp.g_eps, b * n + g));
-        else st<IO>(gp.g_eps, b * n + g, g_eps);
+        else st<IO>(gp.g_eps, b * n + g, g_eps + eold[k]);
       }
       if (gp.g_obs_w) st<IO>(gp.g_obs_w, b * n + g, g_w);
     }
@@ -782,7 +810,14 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       for (int a = 0; a < D; ++a) gk[a] += pass_on ? gx[a] : 0.0;
       chain_put<C, D>(cx.chain_lds(), lane, k, gk);
     } else if (gp.g_th) {
-      if (gp.g_th_new) {             // (dgp_gn_step_errors_backward: the errors' share of the trajectory gradient)
+      if (lds_fold) {                // (dgp_gn_step_errors_backward: the errors' share of the trajectory gradient -- from the lane's LDS slots, d = 4 ...
+        if constexpr (kFoldLds) {
+          double t[D];
+          fold_get<C, D>(cx.chain_lds(), lane, k, t);
+#pragma unroll
+          for (int a = 0; a < D; ++a) gx[a] += t[a];
+        }
+      } else if (gp.g_th_new) {      //  ... or from memory: d = 6, and the second of two launches)
         double t[D];
         ld_row<IO, D>(gp.g_th_new, b * n + g, vec, t);
 #pragma unroll

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) gn_backward_kernel(const dgp::GnParams p_a
   constexpr int kMax = kPairBytes > kRowBytes ? kPairBytes : kRowBytes;      // (the stash is dead by the time the pair staging is used: aliased)
   constexpr int kAll = kMax > kStash ? kMax : kStash;
   constexpr int kWb = dgp::is_wb(QK) ? dgp::kWbLdsBytes : 0;
-  constexpr int kChain = CHAIN ? dgp::ChainSlots<C, 2 * DOF>::kBytes : 0;
+  constexpr int kChain = CHAIN ? dgp::ChainSlots<C, 2 * DOF>::kBytes : (DOF == 2 ? dgp::FoldSlots<C, 2 * DOF>::kBytes : 0);      // (d = 4 single step: the prologue's hand-over slots)
   __shared__ __attribute__((aligned(16))) char lds[kAll + kWb + kChain];
   DevCtx cx;
   cx.lds_ = lds;
@@ -292,7 +292,8 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
           return hipGetLastError();                                                                                        \
         }                                                                                                                  \
       }                                                                                                                    \
-      if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));                 \
+      if constexpr (DGP_STEP_ERRS == 1 && DOF == 3) return hipErrorInvalidValue;      /* (host-checked: dgp_host::gn_step_errors -- a miscompiled twin) */ \
+      else if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));            \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
       if (mode == dgp::MODE_STEP) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));         \

@@ -2981,6 +2981,30 @@ DGP_HD void chain_get(const char* base, int lane, int v, double (&x)[D]) {
   for (int i = 0; i < D / 2; ++i) { const V2 t = *(const V2*)(l + i * 16); x[2 * i] = t[0]; x[2 * i + 1] = t[1]; }
 }
 
+// Lane-private LDS slots of the d = 4 single-step backward kernels (round 5, dgp_gn_step_errors_backward in one launch): what the errors' prologue hands to
+// the main program of the SAME lane -- the C trajectory-gradient rows (vectors 0 .. C-1), its shares of the start / goal gradients (C, C + 1) and of the C
+// epsilon gradients (C + 2, first C doubles).  Through memory these cost the main program one exposed round trip per row: every re-read sat behind the
+// previous row's stores.  (d = 6 keeps the memory hand-over: its backward kernels hold 34 KB of LDS already, and four wavefronts per CU must fit in 160 KB.)
+template <int C, int D> struct FoldSlots {
+  static constexpr int kCells = (C + 3) * D / 2;
+  static constexpr int kStride = ((kCells % 2) ? kCells : kCells + 1) * 16;
+  static constexpr int kBytes = 64 * kStride;
+};
+template <int C, int D>
+DGP_HD void fold_put(char* base, int lane, int v, const double (&x)[D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  char* l = base + lane * FoldSlots<C, D>::kStride + v * D * 8;
+#pragma unroll
+  for (int i = 0; i < D / 2; ++i) { V2 t; t[0] = x[2 * i]; t[1] = x[2 * i + 1]; *(V2*)(l + i * 16) = t; }
+}
+template <int C, int D>
+DGP_HD void fold_get(const char* base, int lane, int v, double (&x)[D]) {
+  typedef double V2 __attribute__((vector_size(16)));
+  const char* l = base + lane * FoldSlots<C, D>::kStride + v * D * 8;
+#pragma unroll
+  for (int i = 0; i < D / 2; ++i) { const V2 t = *(const V2*)(l + i * 16); x[2 * i] = t[0]; x[2 * i + 1] = t[1]; }
+}
+
 }  // namespace dgp
 #include "gn_woodbury.h"
 namespace dgp {

@@ -10,7 +10,7 @@ K="${1:-}"
 if [ -n "$K" ]; then
   (timeout 1800 python -m pytest tests -m gpu -q -x -k "$K" > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
 else
-  (timeout 1800 python -m pytest tests -m gpu -q -x > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
+  (timeout 1800 python -m pytest tests -m gpu -q > "$O/pytest_gpu.log" 2>&1; echo "pytest rc $?" >> "$O/pytest_gpu.log")
 fi
 tail -15 "$O/pytest_gpu.log"
 timeout 900 python profiles/tools/train_iteration.py 2> "$O/ti.err" | grep -a '^{' > "$O/train_iteration.json"
@@ -25,7 +25,7 @@ for B in ('B4096', 'B32'):
       print(B, k, t, 'eager %.1f' % e['eager_us'], 'replay', e.get('hip_graph_replay_us'), e.get('grad_layout', ''), e.get('grad_bytes', ''), e.get('graph_error', ''))
 PY
 timeout 600 python profiles/tools/graph_replay_breakdown.py 2>/dev/null | tee "$O/graph_replay.txt"
-( U="python profiles/tools/ubench.py"; $U --what step,step_errs,bwd_errs; $U --what step,step_errs,bwd_errs --covs perstate; $U --what step,step_errs,bwd_errs --covs scalar; $U --what bwd,bwd_sdf16,bwd_sdf16w,bwd_sdf8w --covs perstate; $U --what bwd,bwd_sdf,bwd_sparse --covs perstate --sdf persample; $U --what bwd,bwd_sdf16,bwd_sdf16w; $U --what bwd,bwd_sdf,bwd_sparse --sdf persample; $U --what step,eval,bwd,bwd_sdf --sdf persample --grids 6; $U --what step,eval,bwd,bwd_sdf --sdf persample --grids 6 --layout tiled4; $U --what step --layout tiled4; $U --what step ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
+( U="python profiles/tools/ubench.py"; $U --what step,step_errs,bwd,bwd_errs,bwd_errs_noobs; $U --what step,step_errs,bwd,bwd_errs,bwd_errs_noobs --covs perstate; $U --what step,step_errs,bwd_errs,bwd_errs_noobs --covs scalar; $U --what bwd,bwd_sdf16,bwd_sdf16w,bwd_sdf8w --covs perstate; $U --what bwd,bwd_sdf,bwd_sparse --covs perstate --sdf persample; $U --what bwd,bwd_sdf16,bwd_sdf16w; $U --what bwd,bwd_sdf,bwd_sparse --sdf persample; $U --what step,eval,bwd,bwd_sdf --sdf persample --grids 6; $U --what step,eval,bwd,bwd_sdf --sdf persample --grids 6 --layout tiled4; $U --what step --layout tiled4; $U --what step ) 2>/dev/null | grep -a '^{' > "$O/ubench.jsonl"
 cat "$O/ubench.jsonl"
 cd /tmp && export TMPDIR=/tmp
 for w in shared per_sample; do

@@ -108,7 +108,8 @@ def main():
     elif what == 'step_errs':      # dgp_gn_step_errors: the step + the unweighted errors at th + dtheta (two launches; `period_us` is the pair, `kernel_us` the first of them)
       us_, ug_, uo_ = (torch.empty(B, device=dev, dtype=dt) for _ in range(3))
       f = lambda k: s.gn_step_errors(B, tp[k % 4], P(start), P(goal), sas[k % len(sas)], covs, P(dth), P(err), P(eex), P(info), P(us_), P(ug_), P(uo_), st)
-    elif what in ('bwd_errs', 'bwd_errs_sdf'):      # dgp_gn_step_errors_backward with every cotangent: ONE launch (the errors' backward as the kernel's prologue)
+    elif what in ('bwd_errs', 'bwd_errs_sdf', 'bwd_errs_noobs'):      # dgp_gn_step_errors_backward with every cotangent: ONE launch (the errors' backward as the kernel's prologue;
+      # _noobs: without the obs_error cotangent -- the prologue then reads no grid: what its gather + hinge arithmetic cost)
       g = torch.randn_like(th0); gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
       ge = torch.ones(B, device=dev, dtype=dt); c1, c2, c3 = (torch.randn(B, device=dev, dtype=dt) for _ in range(3))
       gq = (torch.empty(B, n - 1, dof, dof, device=dev, dtype=dt) if a.covs == 'scalar' else torch.empty_like(keep[0])) if covs else None; gw = torch.empty(B, n, device=dev, dtype=dt) if covs else None
@@ -119,8 +120,9 @@ def main():
         gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=torch.float64 if stride == 0 else dt)
         if stride == 0: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_DENSE_F64)
       s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
-      f = lambda k: s.gn_step_errors_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(c1), P(c2), P(c3), P(gth), P(gst), P(ggo), P(gs), stride,
-                                              P(gq), P(gw), P(gp), None, st, g_sdf_copies=copies)
+      if what == 'bwd_errs_noobs': c3 = None
+      f = lambda k, c3=c3: s.gn_step_errors_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(c1), P(c2), P(c3), P(gth), P(gst), P(ggo), P(gs), stride,
+                                                     P(gq), P(gw), P(gp), None, st, g_sdf_copies=copies)
     elif what == 'eval':
       f = lambda k: s.eval_errors(B, tp[k % 4], P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st)
     elif what.startswith('bwd'):
