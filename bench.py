@@ -520,10 +520,24 @@ def planner_api_backward_rate(device, reps=200):
   gth = torch.empty_like(th0); gst = torch.empty_like(start); ggo = torch.empty_like(goal)
   sarg = sv.sdf_arg(sdf.data_ptr(), GRID, GRID, 0)
   raw = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+  eh = torch.empty(B, GN_ITERS, dtype=torch.float32, device=device); eeh = torch.empty_like(eh); ef = torch.empty(B, dtype=torch.float32, device=device)
   k_fwd = time_launches(lambda k: sv.gn_solve_traced(B, th0.data_ptr(), start.data_ptr(), goal.data_ptr(), sarg, None, GN_ITERS, 0.0, tho.data_ptr(), its.data_ptr(),
-                                                     None, None, None, inf.data_ptr(), hist.data_ptr(), raw), 100, warm_s=0.1)
+                                                     eh.data_ptr(), eeh.data_ptr(), ef.data_ptr(), inf.data_ptr(), hist.data_ptr(), raw), 100, warm_s=0.1)
   k_bwd = time_launches(lambda k: sv.gn_solve_backward(B, start.data_ptr(), goal.data_ptr(), sarg, GN_ITERS, hist.data_ptr(), tho.data_ptr(), its.data_ptr(),
                                                        g.data_ptr(), gth.data_ptr(), gst.data_ptr(), ggo.data_ptr(), None, 0, raw), 100, warm_s=0.1)
+  # ... with the gradient of the shared grid, as forward_backward() asks for it (what PlanLayer launches: eight float64 partial grids, zero-filled, accumulated by the chain
+  # kernel, summed and cast by dgp_sum_partial_grids) -- the figure us_per_call is to be held against
+  copies = 8                                       # (plan_layer._SDF_GRAD_COPIES)
+  gpart = torch.empty((copies, 1, GRID, GRID), dtype=torch.float64, device=device); gsum = torch.empty((1, 1, GRID, GRID), dtype=torch.float32, device=device)
+  sarg64 = sv.sdf_arg(sdf.data_ptr(), GRID, GRID, 0, grad_mode=_capi.DGP_GSDF_DENSE_F64)
+  pc = _capi.get_pycall()
+
+  def bwd_with_grid(k):
+    gpart.zero_()
+    sv.gn_solve_backward(B, start.data_ptr(), goal.data_ptr(), sarg64, GN_ITERS, hist.data_ptr(), tho.data_ptr(), its.data_ptr(), g.data_ptr(), gth.data_ptr(),
+                         gst.data_ptr(), ggo.data_ptr(), gpart.data_ptr(), 0, raw, g_sdf_copies=copies)
+    pc.sum_partial_grids(gpart.data_ptr(), _capi.DGP_F64, copies, GRID * GRID, 1.0, gsum.data_ptr(), _capi.DGP_F32, raw.value)
+  k_bwd_grid = time_launches(bwd_with_grid, 100, warm_s=0.1)
 
   def graphed(f):
     """f (forward + torch.autograd.grad) captured once in a HIP graph (torch.cuda.CUDAGraph, torch's whole-iteration capture recipe: warm-up on a side
@@ -570,11 +584,15 @@ def planner_api_backward_rate(device, reps=200):
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '
                                           'C-ABI call each way: dgp_gn_step_errors / dgp_gn_step_errors_backward, two stream-ordered launches each)'},
           'forward_backward_fused': {'us_per_call': fb, 'us_per_gn_iteration': fb / GN_ITERS, 'gn_iterations': GN_ITERS,
-                                     'kernel_us': {'dgp_gn_solve_traced': k_fwd, 'dgp_gn_solve_backward': k_bwd, 'per_gn_iteration': (k_fwd + k_bwd) / GN_ITERS},
+                                     'kernel_us': {'dgp_gn_solve_traced': k_fwd, 'dgp_gn_solve_backward': k_bwd, 'per_gn_iteration': (k_fwd + k_bwd) / GN_ITERS,
+                                                   'dgp_gn_solve_backward_with_grid_gradient': k_bwd_grid, 'sum_as_called': k_fwd + k_bwd_grid},
+                                     'wall_over_kernels': fb / (k_fwd + k_bwd_grid),
                                      'note': 'DiffGPMP2Planner.forward with requires_grad inputs + torch.autograd.grad through all 10 iterations w.r.t. the '
                                              'initial trajectory and the grid: dgp_gn_solve_traced + dgp_gn_solve_backward, one launch each (us_per_call: wall, with '
                                              'the host side of forward() -- one device-to-host copy of the per-sample errors, which waits for the forward launch, and the '
-                                             'reference API\'s python lists; kernel_us: the two launches by HIP events, no grid gradient)'},
+                                             'reference API\'s python lists; kernel_us: the launches by HIP events -- the forward with its error outputs; the backward without and, _with_grid_gradient, with '
+                                             'the shared grid\'s gradient as this call asks for it: zero fill of the eight float64 partial grids + the chain kernel + '
+                                             'dgp_sum_partial_grids; wall_over_kernels = us_per_call / sum_as_called)'},
           'note': 'wall time of DiffGPMP2Planner.step() + torch.autograd.grad through it, B=4096: static covariances with the gradient w.r.t. the '
                   'trajectory (us_per_call), and per-state qc_inv / obscov_inv / eps tensors with gradients w.r.t. all four (learned_covariances_us_per_call); '
                   'two kernel launches (dgp_gn_step, dgp_gn_step_backward) + the autograd engine.  tbptt_window10_us_per_step: ten chained steps '
@@ -865,7 +883,7 @@ def main():
         'roofline': roofline_block(bytes_per_launch, period_ms * 1e3, kname, traffic_key='gn_step',
                                    note='kernel_avg_ms = the dominant kernel\'s average duration in the regime it is benchmarked in -- HIP events on the launch stream around 2000 '
                                         'back-to-back launches / 2000, median of three passes -- which is what rocprofv3 --kernel-trace --stats reports as its average for this '
-                                        'command (profiles/r04_kernel_trace.txt: within 2 % on every box so far); kernel_isolated_avg_ms = mean over 1000 launches that each record '
+                                        'command (profiles/r05_kernel_trace.txt: within 2 % on every box so far); kernel_isolated_avg_ms = mean over 1000 launches that each record '
                                         'their OWN begin / end events (dgp_time_next_launch): such launches dispatch ~5 us apart, every kernel starts on an idle GPU without '
                                         'overlapping its predecessor\'s tail, and runs 2-5 % longer.  HBM is the bound SURVEY 8(d) prescribes; the measured limiter is fp64 VALU '
                                         'issue (see valu_fp64 and DESIGN.md section 5)'),

@@ -58,7 +58,7 @@ def solver_config(num_states, dof, io_dtype, total_time_sec=10.0, x_lims=(-5.0, 
                            cost_sigma=cost_sigma, epsilon_dist=epsilon_dist, **kw)
 
 
-_SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2: one FLOAT64 partial grid per XCD (XCD-local atomics; summed afterwards by dgp_sum_partial_grids).  (Two per XCD -- round 4's fp32 choice -- run the backward kernel no faster with double grids and double the zero fill and the sum: 27.7 vs 27.5 us, profiles/r05_ubench.txt)
+_SDF_GRAD_COPIES = 8      # MI355X has 8 XCDs, each with its own L2: one FLOAT64 partial grid per XCD (XCD-local atomics; summed afterwards by dgp_sum_partial_grids).  (Two per XCD -- round 4's fp32 choice -- run the backward kernel no faster with double grids and double the zero fill and the sum: 27.7 vs 27.5 us, profiles/tools/ubench.py --what bwd_sdf16w,bwd_sdf8w --covs perstate)
 _ALL_STATIC = (True, True, True)
 _NO_COVS = (_capi.DGP_QC_STATIC, None, None, None)       # the four fields of DgpCovs as the trampoline takes them
 
