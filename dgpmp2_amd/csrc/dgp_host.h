@@ -456,24 +456,19 @@ int gn_step_errors_backward(const DgpHandle* h, int32_t batch, const void* th, c
   dgp::GnGradParams g;
   const bool errs = g_unw_sg || g_unw_gp || g_unw_obs;
   if (errs && !dtheta) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs dtheta when an unweighted-error cotangent is given");
-  if (errs && !is_long(h ? h->cfg.num_states : 0)) {
-    // ONE launch (round 5): the errors' backward at th + dtheta runs as a prologue of the step's backward kernel (gn_backward.h: unweighted_errors_prologue) and hands
-    // its trajectory gradient over in the lane's LDS slots (d = 4) or in g_th itself (d = 6; in the workspace when g_th is not wanted)
-    const bool lds_handover = h->cfg.dof == 2;
-    void* buf = g_th ? g_th : workspace;
-    if (!buf && !lds_handover) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs g_th or a (B,n,d) workspace when an unweighted-error cotangent is given");
+  if (errs && h && h->cfg.dof == 2 && !is_long(h->cfg.num_states)) {
+    // ONE launch (round 5, d = 4): the errors' backward at th + dtheta runs as a prologue of the step's backward kernel (gn_backward.h: unweighted_errors_prologue) and
+    // hands its trajectory gradient and its shares of the small gradients over in the lane's LDS slots -- no workspace
     int rc = fill_backward(h, batch, th, start, goal, sdf, covs, dtheta, g_dtheta, g_err_ext, g_th, g_start, g_goal, g_sdf, g_sdf_batch_stride,
                            g_sdf_copies, g_qc_inv, g_obs_w, g_eps, p, g);
     if (rc != DGP_OK) return rc;
     g.f_unw_sg = g_unw_sg; g.f_unw_gp = g_unw_gp; g.f_unw_obs = g_unw_obs; g.f_addend = dtheta;
     g.g_sdf_passes = 2;
-    if (!lds_handover) { g.g_th_new = buf; g.accumulate = 1; }
-    p.vec_io = (aligned16(th) && aligned16(dtheta) && aligned16(g_dtheta) && (lds_handover ? aligned16(g_th) : aligned16(buf))) ? 1 : 0;
     return launch((int)kModeBackward, p, &g);
   }
   if (errs) {
-    // long trajectories (the loop kernels of gn_long.h): two launches, as in round 4
-    if (!workspace) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs a (B,n,d) workspace for num_states > 256");
+    // d = 6 (no prologue in its backward kernels: registers, LDS -- gn_backward.h) and long trajectories (the loop kernels of gn_long.h): two launches, as in round 4
+    if (!workspace) return fail(DGP_EINVAL, "dgp_gn_step_errors_backward needs a (B,n,d) workspace for dof = 3 and for num_states > 256");
     // launch 1: backward of the unweighted errors at th + dtheta -> workspace (gradient w.r.t. th + dtheta), start / goal / eps / grid shares
     int rc = fill_eval_backward(h, batch, th, start, goal, sdf, covs, nullptr, g_unw_sg, g_unw_gp, g_unw_obs, workspace, g_start, g_goal, g_sdf,
                                 g_sdf_batch_stride, g_sdf_copies, nullptr, p, g);

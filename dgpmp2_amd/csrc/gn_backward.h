@@ -44,8 +44,8 @@ struct GnGradParams {
   int32_t g_sdf_mode;
   int32_t g_sdf_passes, g_sdf_pass0; // GSDF_SPARSE: tap blocks the caller's arrays hold (1; max_iters for the chain kernels; 2 for dgp_gn_step_errors_backward) and the block this launch's first pass writes
   int64_t* g_sdf_idx;
-  // round 5 -- dgp_gn_step_errors_backward as ONE launch: the backward of the unweighted errors at th + f_addend runs as a prologue of this kernel
-  // (unweighted_errors_prologue below) and leaves its trajectory gradient in g_th_new, its shares of g_start / g_goal / g_eps in place (accumulate = 1)
+  // round 5 -- dgp_gn_step_errors_backward as ONE launch (d = 4): the backward of the unweighted errors at th + f_addend runs as a prologue of this kernel
+  // (unweighted_errors_prologue below) and hands its trajectory gradient and its shares of g_start / g_goal / g_eps to the main program in lane-private LDS
   const void *f_unw_sg, *f_unw_gp, *f_unw_obs;   // (B) cotangents of the three unweighted errors, null = 0
   const void* f_addend;                          // (B,n,d) dtheta of the forward pass; null: no prologue
 };
@@ -148,13 +148,15 @@ template <int DOF, bool CHAIN> struct BwdParks {
 // round 4 launched as a kernel of its own in front of it (dgp_gn_step_errors_backward: +15 us of a 58 us replayed training iteration -- a second launch, the
 // general chain rule evaluated with lambda = 0, a 4 MB workspace written and read back by the next launch).  No solve, no covariance weights, only the three
 // cotangents: every lane hands the gradient rows of its states w.r.t. th + dtheta back in `gfold` (registers: the main program adds them to the dtheta cotangent in
-// front of the adjoint solve, after which they are dead) AND stores them to gp.g_th_new (the caller passes g_th itself: behind the solve and the chain rule, some
-// 15 us later, the main program reads ITS OWN rows back -- same lane, same addresses, program order: no fence, and nothing waits for the stores here), writes its
-// share of g_start / g_goal / g_eps in place (the main program accumulates onto them, lane-private too) and scatters its grid taps (tap block g_sdf_pass0 + 1 of a
-// sparse gradient).  Same formulas as the rows of gn_backward_lane_program with lambda = 0, ebar = 0.  (A first version ordered the stores before the main
-// program's loads with an agent-scope fence -- an L2 write-back per wavefront on gfx950: 57 instead of 36 us; with a workgroup-scope fence 31 us: the store
-// round trip in front of the main program's first loads.)
-template <int DOF, int LPT, int C, typename IO, bool PARK, typename Ctx>
+// front of the adjoint solve, after which they are dead) AND parks them, with its shares of g_start / g_goal / g_eps, in the lane's LDS slots (FoldSlots, gn_lane.h):
+// behind the solve, some 15 us later, the chain rule of the SAME lane adds them to its own rows.  The grid taps are scattered here (tap block g_sdf_pass0 + 1 of a
+// sparse gradient).  Same formulas as the rows of gn_backward_lane_program with lambda = 0, ebar = 0.  d = 4 kernels only: the d = 6 backward kernels have neither
+// the registers (the prologue's presence cost their scaled variant 5 of 57 us and put 23 more of them into the spill range of the known miscompiles) nor the LDS
+// (34 KB already; four wavefronts per CU share 160 KB) -- the host gives d = 6 the two-launch form.  Hand-overs that were tried first: through g_th / g_start /
+// g_goal / g_eps themselves -- every re-read in the chain rule then sits behind the previous row's stores, one exposed memory round trip per row (static backward
+// with error cotangents 24.1 us against 17.1 us with the LDS slots); ordered by an agent-scope fence -- an L2 write-back per wavefront on gfx950: 57 instead of 36 us;
+// by a workgroup-scope fence: 31 us.
+template <int DOF, int LPT, int C, typename IO, typename Ctx>
 DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp, Ctx& cx, const double (&th_rows)[C][2 * DOF], const double (&dq)[C][2 * DOF],
                                        const double (&mu_s)[2 * DOF], const double (&mu_g)[2 * DOF], double (&gfold)[C][2 * DOF]) {
   constexpr int D = 2 * DOF;
@@ -192,7 +194,7 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
 #pragma unroll
     for (int a = 0; a < D; ++a) gfold[k][a] = 0.0;
   }
-  // PARK (d = 4): nothing is stored to memory here -- the rows and the shares of g_start / g_goal / g_eps go to the lane's LDS slots (FoldSlots) below
+  // nothing is stored to memory here: the rows and the shares of g_start / g_goal / g_eps go to the lane's LDS slots (FoldSlots) below
   double sh_s[D], sh_g[D], sh_e[D];
 #pragma unroll
   for (int a = 0; a < D; ++a) { sh_s[a] = 0.0; sh_g[a] = 0.0; sh_e[a] = 0.0; }
@@ -208,13 +210,11 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
     for (int a = 0; a < D; ++a) gx[a] = 0.0;
     if (g == 0 || g == n - 1) {                       // 1/2 |mu - x|^2
       const bool is_start = (g == 0);
-      void* gmu = is_start ? gp.g_start : gp.g_goal;
 #pragma unroll
       for (int a = 0; a < D; ++a) {
         const double t = gsg * ((is_start ? mu_s[a] : mu_g[a]) - xk[a]);
         gx[a] -= t;
-        if constexpr (PARK) { if (is_start) sh_s[a] = t; else sh_g[a] = t; }
-        else if (gmu) st<IO>(gmu, b * D + a, t);
+        if (is_start) sh_s[a] = t; else sh_g[a] = t;
       }
     }
     if (g < n - 1) {                                  // 1/2 |x_{g+1} - Phi x_g|^2 / (n - 1): this row's share is -Phi^T e
@@ -251,23 +251,16 @@ DGP_HD void unweighted_errors_prologue(const GnParams& p, const GnGradParams& gp
         }
       }
     }
-    if constexpr (PARK) {
-      sh_e[k] = g_eps;
-    } else {
-      if (gp.g_eps) st<IO>(gp.g_eps, b * n + g, g_eps);
-      st_row<IO, D>((void*)gp.g_th_new, b * n + g, vec, gx);
-    }
+    sh_e[k] = g_eps;
 #pragma unroll
     for (int a = 0; a < D; ++a) gfold[k][a] = gx[a];
   }
-  if constexpr (PARK) {
-    static_assert(C <= D, "the epsilon shares of a lane's C states travel in one d-vector");
+  static_assert(C <= D, "the epsilon shares of a lane's C states travel in one d-vector");
 #pragma unroll
-    for (int k = 0; k < C; ++k) fold_put<C, D>(cx.chain_lds(), lane, k, gfold[k]);
-    fold_put<C, D>(cx.chain_lds(), lane, C, sh_s);
-    fold_put<C, D>(cx.chain_lds(), lane, C + 1, sh_g);
-    fold_put<C, D>(cx.chain_lds(), lane, C + 2, sh_e);
-  }
+  for (int k = 0; k < C; ++k) fold_put<C, D>(cx.chain_lds(), lane, k, gfold[k]);
+  fold_put<C, D>(cx.chain_lds(), lane, C, sh_s);
+  fold_put<C, D>(cx.chain_lds(), lane, C + 1, sh_g);
+  fold_put<C, D>(cx.chain_lds(), lane, C + 2, sh_e);
   if (gp.g_sdf && has_grid) {
     if (gp.g_sdf_mode == GSDF_SPARSE) sdf_emit_sparse<C, IO>(p, gp, b, g0, traj_ok, gp.g_sdf_pass0 + 1, (int64_t)gp.g_sdf_passes * p.B * p.n * 4, taps, tap_i, tap_v);
     else sdf_scatter_pairs<LPT, C, IO>(p, gp, cx, tap_i, tap_v);
@@ -303,7 +296,8 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
 #ifndef DGP_BWD_FOLD
 #define DGP_BWD_FOLD 1             // 0: compile the prologue out (A/B builds, profiles/tools/devbuild.py: what its presence costs the plain step backward)
 #endif
-  // d = 4: the prologue hands its results to the main program through the lane's LDS slots (FoldSlots) instead of through g_th / g_start / g_goal / g_eps
+  // the errors' prologue (dgp_gn_step_errors_backward in one launch) exists in the d = 4 single-step kernels; it hands its results to the main program through the
+  // lane's LDS slots (FoldSlots)
   constexpr bool kFoldLds = !CHAIN && DOF == 2 && DGP_BWD_FOLD != 0;
   // d = 4: a fully populated wavefront block whose length fills the shape moves its row tensors (th, the dtheta cotangent, dtheta in;
   // g_th out) as full cache lines through the LDS staging block, as the forward step does (load / store_rows_through_lds; the output
@@ -333,13 +327,13 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
   ld_row<IO, D>(p.start, traj_ok ? b : 0, vec && p.vec_mu, mu_s);
   ld_row<IO, D>(p.goal, traj_ok ? b : 0, vec && p.vec_mu, mu_g);
   if constexpr (is_wb(QK)) wb_stage_issue<(QK == QK_WBR)>(p, cx, wbv);
-  if constexpr (!CHAIN && DGP_BWD_FOLD != 0) {
+  if constexpr (kFoldLds) {
     if (gp.f_addend) {             // wave-uniform: dgp_gn_step_errors_backward in one launch -- the errors' share of the dtheta cotangent arrives in gbar
       double dq[C][D], gd[C][D];
       load_rows(gp.f_addend, dq);
       const bool have_gd = gp.g_dtheta != nullptr;
       if (have_gd) load_rows(gp.g_dtheta, gd);      // (in flight under the prologue's arithmetic)
-      unweighted_errors_prologue<DOF, LPT, C, IO, kFoldLds>(p, gp, cx, x, dq, mu_s, mu_g, gbar);
+      unweighted_errors_prologue<DOF, LPT, C, IO>(p, gp, cx, x, dq, mu_s, mu_g, gbar);
       if (have_gd) {
 #pragma unroll
         for (int k = 0; k < C; ++k)
@@ -810,14 +804,14 @@ DGP_HD void gn_backward_lane_program(const GnParams& p, const GnGradParams& gp, 
       for (int a = 0; a < D; ++a) gk[a] += pass_on ? gx[a] : 0.0;
       chain_put<C, D>(cx.chain_lds(), lane, k, gk);
     } else if (gp.g_th) {
-      if (lds_fold) {                // (dgp_gn_step_errors_backward: the errors' share of the trajectory gradient -- from the lane's LDS slots, d = 4 ...
+      if (lds_fold) {                // (dgp_gn_step_errors_backward: the errors' share of the trajectory gradient -- from the lane's LDS slots, one launch, d = 4 ...
         if constexpr (kFoldLds) {
           double t[D];
           fold_get<C, D>(cx.chain_lds(), lane, k, t);
 #pragma unroll
           for (int a = 0; a < D; ++a) gx[a] += t[a];
         }
-      } else if (gp.g_th_new) {      //  ... or from memory: d = 6, and the second of two launches)
+      } else if (gp.g_th_new) {      //  ... or from memory: the second of two launches, d = 6 and long trajectories)
         double t[D];
         ld_row<IO, D>(gp.g_th_new, b * n + g, vec, t);
 #pragma unroll

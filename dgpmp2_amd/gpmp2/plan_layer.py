@@ -422,9 +422,9 @@ class _GNStepErrors(torch.autograd.Function):
     g_qc = _grad_like(qc, th) if (need[6] and cv[1] is not None) else None
     g_ow = _grad_like(ow, th) if (need[7] and cv[2] is not None) else None
     g_eps = _grad_like(eps, th) if (need[8] and cv[3] is not None) else None
-    # the errors' backward runs as a prologue of the step's backward kernel and hands dL/d(th + dtheta) over in g_th itself; a workspace is only needed
-    # when no trajectory gradient is wanted (or for the two-launch form of long trajectories)
-    ws = torch.empty_like(th) if (errs and (g_th is None or n > 256)) else None
+    # d = 4: the errors' backward runs as a prologue of the step's backward kernel (one launch, hand-over in LDS); the two-launch form of the (x, y, theta)
+    # robot and of long trajectories hands dL/d(th + dtheta) over in a workspace
+    ws = torch.empty_like(th) if (errs and (d != 4 or n > 256)) else None
     _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
             *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),
             _ptr(g_go), gs.ptr, gs.stride, gs.copies, _ptr(g_qc), _ptr(g_ow), _ptr(g_eps), _ptr(ws), _raw_stream(dev))
@@ -532,7 +532,7 @@ class _GNStepRaw(torch.autograd.Function):
       if raw.n_gp: gq = torch.empty_like(raw.qc)
       gw = torch.empty_like(raw.ow)
       if raw.learn_eps: ge = torch.empty_like(raw.eps)
-    ws = torch.empty_like(th) if (errs and g_th is None) else None
+    ws = torch.empty_like(th) if (errs and (d != 4 or n > 256)) else None
     if ctx.with_errors:
       _launch(dev, layer._pc.gn_step_errors_backward, solver.h, B, th.data_ptr(), stc.data_ptr(), goc.data_ptr(), *gs.sd(sd),
               *cv[:4], dth.data_ptr(), _ptr(g_dth), _ptr(g_eex), _ptr(g_usg), _ptr(g_ugp), _ptr(g_uobs), _ptr(g_th), _ptr(g_st),

@@ -265,10 +265,10 @@ int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
                        void* unw_sg, void* unw_gp, void* unw_obs, void* stream);
 
 /* Backward of dgp_gn_step_errors: cotangents of dtheta, err_ext and of the three unweighted errors at th + dtheta in, every gradient
- * of dgp_gn_step_backward out (same conventions; g_sdf accumulated).  num_states <= 256: ONE launch -- the errors' backward at th + dtheta runs
- * as a prologue of the step's backward kernel and hands dL/d(th + dtheta) over inside the launch (dof = 2: lane-private LDS; dof = 3: in g_th itself --
- * `workspace`, (B,n,d) elements of io_dtype, is then needed when g_th is NULL); longer trajectories: two stream-ordered launches through `workspace`
- * (caller-provided: nothing is allocated inside a call).  No unweighted-error cotangent: exactly dgp_gn_step_backward (workspace may be NULL). */
+ * of dgp_gn_step_backward out (same conventions; g_sdf accumulated).  dof = 2, num_states <= 256: ONE launch -- the errors' backward at th + dtheta
+ * runs as a prologue of the step's backward kernel and hands dL/d(th + dtheta) over inside the launch (lane-private LDS), `workspace` may be NULL.
+ * dof = 3 and longer trajectories: two stream-ordered launches, the first leaves dL/d(th + dtheta) in `workspace` ((B,n,d) elements of io_dtype,
+ * caller-provided: nothing is allocated inside a call).  No unweighted-error cotangent: exactly dgp_gn_step_backward (workspace may be NULL). */
 int dgp_gn_step_errors_backward(const DgpHandle* h, int32_t batch,
                                 const void* th, const void* start, const void* goal,
                                 const DgpSdf* sdf, const DgpCovs* covs,

@@ -121,8 +121,9 @@ def main():
         if stride == 0: sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_DENSE_F64)
       s.gn_step(B, tp[a.th], P(start), P(goal), sa, covs, P(dth), P(err), P(eex), P(info), st)
       if what == 'bwd_errs_noobs': c3 = None
+      ws = torch.empty_like(th0) if dof == 3 else None      # (the two-launch form of the (x, y, theta) robot hands dL/d(th + dtheta) over in a workspace)
       f = lambda k, c3=c3: s.gn_step_errors_backward(B, tp[a.th], P(start), P(goal), sab, covs, P(dth), P(g), P(ge), P(c1), P(c2), P(c3), P(gth), P(gst), P(ggo), P(gs), stride,
-                                                     P(gq), P(gw), P(gp), None, st, g_sdf_copies=copies)
+                                                     P(gq), P(gw), P(gp), P(ws), st, g_sdf_copies=copies)
     elif what == 'eval':
       f = lambda k: s.eval_errors(B, tp[k % 4], P(start), P(goal), sa, covs, P(err), P(eex), None, None, None, st)
     elif what.startswith('bwd'):
