@@ -130,6 +130,29 @@ for case in range(args.cases):
     print('%3d %s dof=%d n=%3d B=%4d %s shape=%s sdf=%dx%d%s cov=%s Qc=%s flags=%s  dth %.1e err %.1e' % (case, status, dof, n, B, io, forced or 'auto', H, W, '(per-sample)' if per_sample else '', cov, qmode,
           ','.join(k for k in ('non_holonomic', 'use_vel_limits') if k in kw), e, ee), flush=True)
     assert not status.startswith('FAIL'), status
+  # round 5: the twin translation units on the same configuration (no extra random draws: the seeds keep their meaning) -- the step kernels with the errors
+  # epilogue (dgp_gn_step_errors in one launch where the host offers it; otherwise the call runs its two-launch form, checked all the same) against the step above
+  # and the error kernel at th + dtheta, and the tiled-grid twins against the row-major result
+  if ok.all() and n <= 256 and not q_full:
+    tw = 10 * PC.TOL[io] * (30 if p.reg < 0.01 else 1)      # (ten times the main check's bound, which sends what exceeds it to the extended-precision arbiter: seed 4 case 83 is 2.4 x
+                                                            #  over on a cond 1e7 system in another launch shape; a miscompiled twin is wrong by O(1))
+    os.environ.pop('DGP_FORCE_SHAPE', None)
+    kwc = dict(qc=qc if qc_step is None else qc_step, ow=ow, eps=eps, io=io)
+    fw = be.step_errors(p, th, start, goal, sdf, **kwc)
+    npdt = np.float64 if io == 'f64' else np.float32
+    th_new = (th.astype(npdt) + fw[0].astype(npdt)).astype(np.float64)
+    _, _, s2, g2, o2 = be.eval_errors(p, th_new, start, goal, sdf, eps=eps, io=io)
+    e1 = np.abs(fw[0] - c_dth).reshape(B, -1).max(1) / (np.abs(c_dth).reshape(B, -1).max(1) + 1e-300)
+    tu = 1e-9 if io == 'f64' else 2e-4
+    e2 = max(PC.rel_err(fw[4], s2), PC.rel_err(fw[5], g2), PC.rel_err(fw[6], o2))
+    assert e1.max() < tw and e2 < tu and not fw[3].any(), ('step_errors', case, e1.max(), e2)
+    if n <= 128 and W >= 4 and H >= 4:
+      be.sdf_tiled = True
+      try: dt_, et_, xt_, it_ = be.step(p, th, start, goal, sdf, **kwc)
+      finally: be.sdf_tiled = False
+      e3 = np.abs(dt_ - c_dth).reshape(B, -1).max(1) / (np.abs(c_dth).reshape(B, -1).max(1) + 1e-300)
+      assert e3.max() < tw and not it_.any(), ('tiled grids', case, e3.max())
+    if forced: os.environ['DGP_FORCE_SHAPE'] = '%d,%d' % forced
   # (not for n > 256 with fp32 I/O: the loop kernels keep the fused loop's state in th_out, i.e. rounded to fp32 between iterations, so neither the f64-I/O
   #  loop nor a host-side chain of f32 steps -- which rounds dtheta AND the sum -- is a reference at better than cond(Lambda) x 6e-8 per iteration;
   #  tests/parity_cases.py::case_long_trajectories pins that path)
