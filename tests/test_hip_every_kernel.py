@@ -216,6 +216,58 @@ def test_hip_every_step_errors_kernel(be, dof, io, monkeypatch):
 
 @pytest.mark.parametrize('io', ['f64', 'f32'])
 @pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_tiled_twin_kernel(be, dof, io, monkeypatch):
+  """Round 5: the tiled-grid twins (gn_inst.hip compiled with -DDGP_TL=1: every kernel family in the two four-states-per-lane shapes, 2 robots x 2 I/O types -- step,
+  fused loop, error kernel, backward with the grid gradient, chain backward) against the standard kernels on the same grids stored row-major (each of which the tests
+  above hold against an oracle).  A separate compilation of the same source: equal to rounding, and a miscompiled twin is wrong by O(1).  Per-sample grids (odd-sized:
+  padding cells of the last tile row / column) and a shared one."""
+  rs = np.random.RandomState(700 * dof + (io == 'f32'))
+  bt = harness.Backend(be.kind); bt.sdf_tiled = True
+  monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
+  bad = []
+  tol = 1e-9 if io == 'f64' else 2e-4
+  K = 3
+
+  def cmp(tag, what, a_, b_, scale_with=None, t=None):
+    if a_ is None or b_ is None: return
+    if not np.all(np.isfinite(a_)): bad.append((tag, what, 'non-finite')); return
+    e = np.abs(a_ - b_).max() / max(np.abs(b_).max(), 0.0 if scale_with is None else np.abs(scale_with).max(), 1e-300)
+    if not e < (t or tol): bad.append((tag, what, e))
+  for n in ERRS_LENGTHS:
+    for cov in ('static', 'static_diag', 'static_full', 'scalar', 'perstate', 'qfull'):
+      B = 5
+      p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, 'perstate' if cov == 'scalar' else cov, io)
+      if cov == 'scalar': qc = PC.rnd(rs.uniform(0.3, 3.0, (B, n - 1)) ** 2, io)
+      if (n + len(cov)) % 2:      # every other configuration: one grid per trajectory, 23 x 37 (neither a multiple of four)
+        sdf = PC.rnd(np.stack([sdf[0, :, :23, :37] + 0.05 * rs.randn() for _ in range(B)]), io)
+      kw = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
+      tag = 'dof %d %s n %d cov %s%s' % (dof, io, n, cov, ' per-sample grids' if sdf.shape[0] > 1 else '')
+      a = be.step(p, th, start, goal, sdf, **kw); b = bt.step(p, th, start, goal, sdf, **kw)
+      for i, name in enumerate(('dtheta', 'err', 'err_ext')): cmp(tag, 'step ' + name, b[i], a[i])
+      if b[3].any() or a[3].any(): bad.append((tag, 'info')); continue
+      ea = be.eval_errors(p, th, start, goal, sdf, eps=eps, io=io); eb = bt.eval_errors(p, th, start, goal, sdf, eps=eps, io=io)
+      for i, name in enumerate(('err', 'err_ext', 'unw_sg', 'unw_gp', 'unw_obs')): cmp(tag, 'errors ' + name, eb[i], ea[i])
+      gb = PC.rnd(rs.randn(B, n, 2 * dof), io); ge = PC.rnd(rs.randn(B), io)
+      gm = 'f64' if io == 'f32' else 'dense'
+      bkw = dict(kw)
+      if cov == 'scalar': bkw['qc'] = PC.rnd(qc[:, :, None, None] * np.eye(dof), io)      # (the scaled backward twin through DGP_QC_SCALAR as well)
+      for kq in ((kw, 'backward'),) + (((bkw, 'backward (dense blocks)'),) if cov == 'scalar' else ()):
+        ra = be.backward(p, th, start, goal, sdf, a[0], gb, ge, sdf_grad=gm, **kq[0]); rb = bt.backward(p, th, start, goal, sdf, a[0], gb, ge, sdf_grad=gm, **kq[0])
+        for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'): cmp(tag, kq[1] + ' ' + key, rb[key], ra[key], scale_with=ra['th'] if key == 'sdf' else None, t=100 * tol)
+      if cov != 'scalar':      # the fused loop (DGP_QC_SCALAR is a step-only mode)
+        sa = be.solve(p, th, start, goal, sdf, K, 0.0, **kw); sb = bt.solve(p, th, start, goal, sdf, K, 0.0, **kw)
+        cmp(tag, 'fused loop', sb[0], sa[0], t=100 * tol)
+      if cov == 'static':      # ... and its backward
+        tho, its, hist, info = be.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
+        tht, itt, hist_t, info_t = bt.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
+        cmp(tag, 'traced loop', tht, tho, t=100 * tol)
+        ca = be.solve_backward(p, start, goal, sdf, K, hist, tho, its, gb, io=io, sdf_grad=gm); cb = bt.solve_backward(p, start, goal, sdf, K, hist, tho, its, gb, io=io, sdf_grad=gm)
+        for key in ('th', 'start', 'goal', 'sdf'): cmp(tag, 'chain backward ' + key, cb[key], ca[key], scale_with=ca['th'] if key == 'sdf' else None, t=100 * tol)
+  assert not bad, '%d tiled-twin results differ from the row-major kernels:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('io', ['f64', 'f32'])
+@pytest.mark.parametrize('dof', [2, 3])
 def test_hip_every_chain_backward_kernel(be, dof, io, monkeypatch):
   """Every instantiation of the fused loop's backward (dgp_gn_solve_backward: 2 robots x 2 I/O types x 9 shapes x block elimination / Woodbury exact
   fit / Woodbury ragged) and of the traced fused loop in front of it: the history must reproduce the plain loop bit for bit, and the gradients
