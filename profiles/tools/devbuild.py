@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Tuning build: compile only SOME kernel translation units (the full library takes ~3 min on 8 cores) into
+"""Tuning build: compile only SOME kernel translation units (the full library takes ~5.5 min on 8 cores) into
 dgpmp2_amd/lib/libdgpmp2_dev.so; the launch entry points of the units left out are stubs that fail with hipErrorInvalidValue.
 Use it with DGP_LIB_PATH=dgpmp2_amd/lib/libdgpmp2_dev.so (dgpmp2_amd/_capi.py).  Never the product build.
 
