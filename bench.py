@@ -582,7 +582,8 @@ def planner_api_backward_rate(device, reps=200):
                                   'note': 'learned covariances (per-state qc_inv / obscov_inv / eps that require grad): step + unweighted errors at th + dtheta + '
                                           'backward of a loss on all four outputs w.r.t. all four inputs, wall per iteration -- PlanLayer.forward + '
                                           'unweighted_errors_batch (2 + 2 launches, two autograd nodes) against PlanLayer.forward_with_errors (one node, one '
-                                          'C-ABI call each way: dgp_gn_step_errors / dgp_gn_step_errors_backward, two stream-ordered launches each)'},
+                                          'C-ABI call each way: dgp_gn_step_errors / dgp_gn_step_errors_backward, ONE launch each since round 5 -- the step kernels with an errors epilogue, the errors\' '
+                                          'backward as a prologue of the step\'s backward kernel)'},
           'forward_backward_fused': {'us_per_call': fb, 'us_per_gn_iteration': fb / GN_ITERS, 'gn_iterations': GN_ITERS,
                                      'kernel_us': {'dgp_gn_solve_traced': k_fwd, 'dgp_gn_solve_backward': k_bwd, 'per_gn_iteration': (k_fwd + k_bwd) / GN_ITERS,
                                                    'dgp_gn_solve_backward_with_grid_gradient': k_bwd_grid, 'sum_as_called': k_fwd + k_bwd_grid},

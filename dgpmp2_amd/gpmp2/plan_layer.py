@@ -348,8 +348,9 @@ _SPARSE_MIN_DENSE_BYTES = 16 << 20      # 'auto': below this a zero-filled dense
 
 class _GNStepErrors(torch.autograd.Function):
   """One iteration of the reference's training loop as ONE autograd node (learning/train_planner.py:311-327): dtheta, err, err_ext of the
-  step AND the three unweighted errors at th + dtheta -- forward = dgp_gn_step_errors, backward = dgp_gn_step_errors_backward (each two
-  stream-ordered launches behind one C-ABI call; no th + dtheta tensor, no second Function.apply, no second trip through the autograd engine)."""
+  step AND the three unweighted errors at th + dtheta -- forward = dgp_gn_step_errors, backward = dgp_gn_step_errors_backward (one
+  launch each for the 2-D robot with a row-major grid and up to 128 / 256 states, two stream-ordered launches otherwise, behind one C-ABI call; no th + dtheta tensor,
+  no second Function.apply, no second trip through the autograd engine)."""
 
   @staticmethod
   def launch(layer, static, th, start, goal, sdf, qc, ow, eps, own_info=False):
