@@ -91,6 +91,41 @@ def test_step_loop_is_capturable_in_a_hip_graph(golden):
     assert torch.equal(static_out, loop(T(g['th_hist'][2])))
 
 
+def test_training_iteration_gradient_subsets(golden):
+  """forward_with_errors + backward when only SOME inputs require grad (the one-launch backward with a NULL g_th / NULL covariance gradients / missing cotangents): every
+  gradient that is asked for equals the one of the full call."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  start, goal = T(g['start']), T(g['goal'])
+  gen = torch.Generator(device=DEV).manual_seed(11)
+  A = torch.randn(B, n - 1, 2, 2, device=DEV, dtype=torch.float64, generator=gen) * 0.2
+  base = dict(th=T(g['th_hist'][1]), qc=torch.eye(2, device=DEV, dtype=torch.float64) + A @ A.transpose(-1, -2),
+              ow=torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 1e4 + 50,
+              eps=torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 0.5 + 0.1, start=start.clone(), goal=goal.clone())
+  c_dth = torch.randn(B, n, 4, device=DEV, dtype=torch.float64, generator=gen)
+  c_e = torch.randn(B, 1, 1, device=DEV, dtype=torch.float64, generator=gen)
+
+  def run(names, outs):
+    L = {k: (v.clone().requires_grad_(True) if k in names else v.clone()) for k, v in base.items()}
+    dth, _, eex, sg, gp_, ob = planner.plan_layer.forward_with_errors(L['th'], L['start'], L['goal'], None, sdf, L['qc'], L['ow'], L['eps'])
+    o = dict(dth=(dth, c_dth), eex=(eex, c_e), sg=(sg, c_e.view(B, 1)), gp=(gp_, c_e), ob=(ob, c_e))
+    loss = sum((o[k][0] * o[k][1]).sum() for k in outs)
+    return dict(zip(names, torch.autograd.grad(loss, [L[k] for k in names], allow_unused=True)))
+  every = ('th', 'start', 'goal', 'qc', 'ow', 'eps')
+  full = run(every, ('dth', 'eex', 'sg', 'gp', 'ob'))
+  for names in (('qc', 'ow', 'eps'), ('th',), ('start', 'goal'), ('eps',), ('th', 'qc')):
+    part = run(names, ('dth', 'eex', 'sg', 'gp', 'ob'))
+    for k in names:
+      assert rel_err(part[k].cpu().numpy(), full[k].cpu().numpy()) < 1e-12, (names, k)
+  # missing cotangents: only the errors, only dtheta, one error alone -- against the sum rule
+  parts = [run(every, (k,)) for k in ('dth', 'eex', 'sg', 'gp', 'ob')]
+  for k in every:
+    tot = sum(p[k] if p[k] is not None else torch.zeros_like(full[k]) for p in parts)
+    assert rel_err(tot.cpu().numpy(), full[k].cpu().numpy()) < 1e-9, k
+
+
 def test_training_iteration_is_capturable_in_a_hip_graph(golden):
   """One iteration of the training loop -- step_with_errors with learned per-state covariances + the backward of all four outputs w.r.t. the trajectory
   and the three covariance tensors (learning/train_planner.py:311-327, 366) -- captured in a HIP graph: forward AND backward launches are recorded
