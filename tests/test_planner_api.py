@@ -126,6 +126,44 @@ def test_training_iteration_gradient_subsets(golden):
     assert rel_err(tot.cpu().numpy(), full[k].cpu().numpy()) < 1e-9, k
 
 
+def test_training_iteration_xyh_robot_two_launch_backward():
+  """The (x, y, theta) robot (d = 6, non-holonomic factor): forward_with_errors + backward -- the C entry point keeps two backward launches through a workspace that
+  PlanLayer allocates -- against the two calls it replaces (forward() and unweighted_errors(th + dtheta), two autograd nodes), learned per-state covariances."""
+  from dgpmp2_amd.robot_models import PointRobotXYH
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  B, n, G = 6, 40, 64
+  gp, ob, pp, op, ev = ref_params(n)
+  gp.update(Q_c_inv=torch.eye(3, dtype=torch.float64), K_d=torch.tensor(0.05, dtype=torch.float64))
+  pp.update(dof=3, state_dim=6, non_holonomic=True)
+  robot = PointRobotXYH(torch.tensor(0.4, dtype=torch.float64), use_cuda=True, batch_size=B, num_traj_states=n)
+  planner = DiffGPMP2Planner(gp, ob, pp, op, ev, robot, batch_size=B, use_cuda=True)
+  pl = planner.plan_layer
+  rs = np.random.RandomState(4)
+  sdf = T(O.circles_sdf(G, O.C2_CIRCLES))[None, None].expand(B, 1, G, G)
+  start = np.zeros((B, 1, 6)); goal = np.zeros((B, 1, 6))
+  start[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, :2] = rs.uniform(-4, 4, (B, 2)); goal[:, 0, 2] = rs.uniform(-1, 1, B)
+  th = O.straight_line_trajb(start[:, :, :3], goal[:, :, :3], 10.0, n - 1, 3) + 0.05 * rs.randn(B, n, 6)
+  A = rs.randn(B, n - 1, 3, 3) * 0.2
+  base = dict(th=T(th), qc=T(np.eye(3) + A @ np.swapaxes(A, -1, -2)), ow=T(rs.uniform(50, 2e4, (B, n, 1, 1))), eps=T(rs.uniform(0.1, 0.6, (B, n, 1, 1))))
+  start, goal = T(start), T(goal)
+  c_dth, c_e = T(rs.randn(B, n, 6)), T(rs.randn(B, 1, 1))
+
+  def leaves(): return {k: v.clone().requires_grad_(True) for k, v in base.items()}
+  L = leaves()
+  dth, _, eex, sg, gp_, ob_ = pl.forward_with_errors(L['th'], start, goal, None, sdf, L['qc'], L['ow'], L['eps'])
+  loss = (dth * c_dth).sum() + (eex * c_e).sum() + (sg * c_e.view(B, 1)).sum() + (gp_ * c_e).sum() + (ob_ * c_e).sum()
+  ga = torch.autograd.grad(loss, [L[k] for k in ('th', 'qc', 'ow', 'eps')])
+  L2 = leaves()
+  d2, _, x2 = pl(L2['th'], start, goal, None, sdf, L2['qc'], L2['ow'], L2['eps'])
+  s2, g2, o2 = pl.unweighted_errors(L2['th'] + d2, sdf)
+  loss2 = (d2 * c_dth).sum() + (x2 * c_e).sum() + (s2 * c_e.view(B, 1)).sum() + (g2 * c_e).sum() + (o2 * c_e).sum()
+  gb = torch.autograd.grad(loss2, [L2[k] for k in ('th', 'qc', 'ow', 'eps')])
+  for a_, b_ in ((dth, d2), (eex, x2), (sg, s2), (gp_, g2), (ob_, o2)):
+    assert rel_err(a_.detach().cpu().numpy(), b_.detach().cpu().numpy()) < 1e-11
+  for k, a_, b_ in zip(('th', 'qc', 'ow', 'eps'), ga, gb):
+    assert rel_err(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-9, (k, rel_err(a_.cpu().numpy(), b_.cpu().numpy()))
+
+
 def test_training_iteration_is_capturable_in_a_hip_graph(golden):
   """One iteration of the training loop -- step_with_errors with learned per-state covariances + the backward of all four outputs w.r.t. the trajectory
   and the three covariance tensors (learning/train_planner.py:311-327, 366) -- captured in a HIP graph: forward AND backward launches are recorded
