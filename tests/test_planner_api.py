@@ -162,6 +162,23 @@ def test_training_iteration_xyh_robot_two_launch_backward():
     assert rel_err(a_.detach().cpu().numpy(), b_.detach().cpu().numpy()) < 1e-11
   for k, a_, b_ in zip(('th', 'qc', 'ow', 'eps'), ga, gb):
     assert rel_err(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-9, (k, rel_err(a_.cpu().numpy(), b_.cpu().numpy()))
+  # ... and the default learned mode from the module's raw output vector (diag_identity: the scaled d = 6 kernels, dgp_square_covariances[_backward] around them)
+  # against the route through get_covariances
+  out0 = T(np.concatenate([rs.uniform(0.7, 1.5, (B, 1, n - 1)), rs.uniform(20, 120, (B, 1, n))], axis=2))
+  res = []
+  for route in ('raw', 'explicit'):
+    out = out0.clone().requires_grad_(True); thr = base['th'].clone().requires_grad_(True)
+    if route == 'raw':
+      raw = pl.raw_covs(out, 'diag_identity', False)
+      assert raw is not None
+      dth, _, eex, sg, gp_, ob_ = pl.forward_raw(thr, start, goal, None, sdf, raw, with_errors=True)[:6]
+    else:
+      qc_s, ow_s = planner.get_covariances(out, 'diag_identity')
+      dth, _, eex, sg, gp_, ob_ = pl.forward_with_errors(thr, start, goal, None, sdf, qc_s, ow_s, None)
+    loss = (dth * c_dth).sum() + (eex * c_e).sum() + (sg.reshape(B, 1) * c_e.view(B, 1)).sum() + (gp_ * c_e).sum() + (ob_ * c_e).sum()
+    res.append((dth.detach(), ob_.detach()) + torch.autograd.grad(loss, (thr, out)))
+  for a_, b_ in zip(*res):
+    assert rel_err(a_.cpu().numpy(), b_.cpu().numpy()) < 1e-9
 
 
 def test_training_iteration_is_capturable_in_a_hip_graph(golden):
