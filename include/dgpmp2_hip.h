@@ -257,7 +257,8 @@ int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch,
 /* One iteration of the reference's training loop (learning/train_planner.py:311-327): dgp_gn_step, then the unweighted errors of
  * DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (the sum formed in io_dtype, as torch forms th_curr_b + dthetab), no th + dtheta
  * tensor in between.  unw_* (B), any may be NULL (all NULL: dgp_gn_step).  ONE launch (the step kernels with an errors epilogue) for row-major
- * grids, num_states <= 128 and static / DGP_QC_SCALAR / per-state (B,n-1,dof,dof) covariances; otherwise two stream-ordered launches. */
+ * grids and num_states <= 128 -- dof = 2: every covariance representation; dof = 3: static (Q_c_inv = c I, no velocity limits), DGP_QC_SCALAR and
+ * per-state (B,n-1,dof,dof) covariances; otherwise two stream-ordered launches. */
 int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
                        const void* th, const void* start, const void* goal,
                        const DgpSdf* sdf, const DgpCovs* covs,

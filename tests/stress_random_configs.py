@@ -133,11 +133,11 @@ for case in range(args.cases):
   # round 5: the twin translation units on the same configuration (no extra random draws: the seeds keep their meaning) -- the step kernels with the errors
   # epilogue (dgp_gn_step_errors in one launch where the host offers it; otherwise the call runs its two-launch form, checked all the same) against the step above
   # and the error kernel at th + dtheta, and the tiled-grid twins against the row-major result
-  if ok.all() and n <= 256 and not q_full:
+  if ok.all() and n <= 256:
     tw = 10 * PC.TOL[io] * (30 if p.reg < 0.01 else 1)      # (ten times the main check's bound, which sends what exceeds it to the extended-precision arbiter: seed 4 case 83 is 2.4 x
                                                             #  over on a cond 1e7 system in another launch shape; a miscompiled twin is wrong by O(1))
     os.environ.pop('DGP_FORCE_SHAPE', None)
-    kwc = dict(qc=qc if qc_step is None else qc_step, ow=ow, eps=eps, io=io)
+    kwc = dict(qc=qc if qc_step is None else qc_step, ow=ow, eps=eps, q_full=q_full, io=io)
     fw = be.step_errors(p, th, start, goal, sdf, **kwc)
     npdt = np.float64 if io == 'f64' else np.float32
     th_new = (th.astype(npdt) + fw[0].astype(npdt)).astype(np.float64)

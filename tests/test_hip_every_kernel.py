@@ -173,19 +173,19 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
 @pytest.mark.parametrize('dof', [2, 3])
 def test_hip_every_step_errors_kernel(be, dof, io, monkeypatch):
   """Round 5: the step kernels with the errors epilogue (gn_inst.hip compiled with -DDGP_STEP_ERRS=1: 2 robots x 2 I/O types x the two four-states-per-lane shapes x
-  Woodbury exact / ragged, block elimination, scaled, Kronecker -- dgp_gn_step_errors as ONE launch) against the two launches they replace (the standard step kernel and
+  Woodbury exact / ragged, block elimination, scaled, Kronecker, general -- dgp_gn_step_errors as ONE launch) against the two launches they replace (the standard step kernel and
   the error kernel, themselves pinned to the C oracle above), and the errors' backward as the PROLOGUE of every backward kernel shape that holds the trajectory against
   its two halves run by hand (dgp_eval_errors_backward at th + dtheta, then dgp_gn_step_backward with that gradient joined to the dtheta cotangent)."""
   rs = np.random.RandomState(500 * dof + (io == 'f32'))
   npdt = np.float64 if io == 'f64' else np.float32
   bad = []
   for n in ERRS_LENGTHS:
-    for cov in ('static', 'static_diag', 'scalar', 'perstate'):
+    for cov in ('static', 'static_diag', 'scalar', 'perstate', 'static_full', 'qfull'):      # (the last two: the general family -- twins for d = 4, two launches for d = 6)
       monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
       B = 6
-      p, th, start, goal, sdf, qc, ow, eps, _ = _inputs(rs, dof, n, B, 'perstate' if cov == 'scalar' else cov, io)
+      p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, 'perstate' if cov == 'scalar' else cov, io)
       if cov == 'scalar': qc = PC.rnd(rs.uniform(0.3, 3.0, (B, n - 1)) ** 2, io)
-      kw = dict(qc=qc, ow=ow, eps=eps, io=io)
+      kw = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io=io)
       tag = 'dof %d %s n %d cov %s' % (dof, io, n, cov)
       fw = be.step_errors(p, th, start, goal, sdf, **kw)
       d2, e2, x2, i2 = be.step(p, th, start, goal, sdf, **kw)
