@@ -310,7 +310,6 @@ inline int fill_gsdf(const DgpHandle* h, const DgpSdf* sdf, void* g_sdf, int64_t
       if (!sdf->grad_indices) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs DgpSdf::grad_indices");
       if (g_sdf_copies != 1) return fail(DGP_EINVAL, "DGP_GSDF_SPARSE takes no partial copies");
       if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_SPARSE is not implemented for num_states > 256");
-      if (sdf->layout != DGP_SDF_ROWMAJOR) return fail(DGP_EUNSUPPORTED, "DGP_GSDF_SPARSE delivers row-major (y, x) indices: a tiled grid takes a dense (tiled) gradient");
       if ((reinterpret_cast<uintptr_t>(g_sdf) & 15u) || (reinterpret_cast<uintptr_t>(sdf->grad_indices) & 15u))
         return fail(DGP_EINVAL, "DGP_GSDF_SPARSE needs 16-byte aligned value / index arrays (vector stores)");
       g.g_sdf_idx = sdf->grad_indices;

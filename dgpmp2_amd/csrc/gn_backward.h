@@ -132,6 +132,17 @@ DGP_HD void sdf_emit_sparse(const GnParams& p, const GnGradParams& gp, int64_t b
     i64x2* r0 = (i64x2*)(idx + q); i64x2* r1 = (i64x2*)(idx + nnz + q); i64x2* r2 = (i64x2*)(idx + 2 * nnz + q); i64x2* r3 = (i64x2*)(idx + 3 * nnz + q);
     const i64x2 bb = {(long long)b, (long long)b}, zz = {0, 0};
     r0[0] = bb; r0[1] = bb; r1[0] = zz; r1[1] = zz;
+#if DGP_TL != 0      // (preprocessor, not `if`: the standard units keep the exact code they were verified with -- even a constant-false branch moved 228 backward kernels by a few instructions)
+    if (grid_is_tiled(p)) {
+      // a tiled grid tensor (B,1,Ht,Wt,4,4): SIX index rows -- b, 0, tile row, tile column, row in tile, column in tile  (taps (x1,y1), (x2,y1), (x1,y2), (x2,y2))
+      i64x2* r4 = (i64x2*)(idx + 4 * nnz + q); i64x2* r5 = (i64x2*)(idx + 5 * nnz + q);
+      r2[0] = i64x2{y1 >> 2, y1 >> 2}; r2[1] = i64x2{y2 >> 2, y2 >> 2};
+      r3[0] = i64x2{x1 >> 2, x2 >> 2}; r3[1] = i64x2{x1 >> 2, x2 >> 2};
+      r4[0] = i64x2{y1 & 3, y1 & 3}; r4[1] = i64x2{y2 & 3, y2 & 3};
+      r5[0] = i64x2{x1 & 3, x2 & 3}; r5[1] = i64x2{x1 & 3, x2 & 3};
+      continue;
+    }
+#endif
     r2[0] = i64x2{y1, y1}; r2[1] = i64x2{y2, y2};                                  // taps (x1,y1), (x2,y1), (x1,y2), (x2,y2)
     r3[0] = i64x2{x1, x2}; r3[1] = i64x2{x1, x2};
   }

@@ -262,7 +262,8 @@ class _SdfGrad(object):
                  the duplicates of neighbouring states included; .to_dense() / .coalesce() give the reference's tensor).  AccumulateGrad takes a sparse gradient
                  for a dense leaf (sdfb.grad is then sparse, and sums with dense or sparse gradients from other nodes);
         'auto'   (default) sparse when sdfb is a LEAF tensor, the trajectory has at most 256 states and the dense gradient would be larger than both
-                 _SPARSE_MIN_DENSE_BYTES and twice the sparse one; dense otherwise (a non-leaf's producer may not accept sparse gradients)."""
+                 _SPARSE_MIN_DENSE_BYTES and twice the sparse one; dense otherwise (a non-leaf's producer may not accept sparse gradients).
+  A tiled grid tensor (B,1,H/4,W/4,4,4) gets a gradient of its own shape either way: dense tiles, or a sparse tensor with six index rows."""
 
   __slots__ = ('g', 'idx', 'ptr', 'stride', 'copies', 'mode', 'shared', 'shape', 'pc', 'dev')
 
@@ -273,7 +274,7 @@ class _SdfGrad(object):
     self.idx = None
     self.pc, self.dev = layer._pc, th.get_device()
     tiled = sd[4] != _capi.DGP_SDF_ROWMAJOR
-    # the grid of one gradient: (1, H, W), or the (1, Ht, Wt, 4, 4) tiles of a tiled sdfb (the gradient of a tiled tensor is tiled: dense only)
+    # the grid of one gradient: (1, H, W), or the (1, Ht, Wt, 4, 4) tiles of a tiled sdfb (the gradient of a tiled tensor is tiled)
     gshape = (1, (H + 3) // 4, (W + 3) // 4, 4, 4) if tiled else (1, H, W)
     gelems = gshape[1] * gshape[2] * (16 if tiled else 1)
     if self.shared:
@@ -287,14 +288,14 @@ class _SdfGrad(object):
       want = layer.sdf_grad
       nnz = passes * B * n * 4
       sparse = False
-      if want != 'dense' and n <= 256 and not tiled:
-        dense_bytes, sparse_bytes = B * H * W * th.element_size(), nnz * (32 + th.element_size())
+      if want != 'dense' and n <= 256:
+        dense_bytes, sparse_bytes = B * gelems * th.element_size(), nnz * ((48 if tiled else 32) + th.element_size())
         sparse = want == 'sparse' or (sdf.is_leaf and dense_bytes > _SPARSE_MIN_DENSE_BYTES and dense_bytes > 2 * sparse_bytes)
       if sparse:
         self.mode = _capi.DGP_GSDF_SPARSE
         mk = torch.zeros if zero_fill else torch.empty
         self.g = mk((nnz,), dtype=th.dtype, device=th.device)
-        self.idx = mk((4, nnz), dtype=torch.int64, device=th.device)
+        self.idx = mk((6 if tiled else 4, nnz), dtype=torch.int64, device=th.device)      # (b, 0, y, x), or the six indices of a tiled tensor (b, 0, y/4, x/4, y%4, x%4)
         self.shape = (B,) + tuple(sdf.shape[1:])
       else:
         self.mode = _capi.DGP_GSDF_DENSE

@@ -98,8 +98,8 @@ typedef struct DgpHandle DgpHandle;
  *   DGP_GSDF_DENSE_F64 the same with grids of DOUBLES whatever io_dtype: the partial copies of a shared grid, summed (and cast) by the caller -- the
  *                      accumulation over thousands of trajectories no longer depends on the order of fp32 atomics;
  *   DGP_GSDF_SPARSE    no grid at all: g_sdf = (passes, B, n, 4) tap VALUES (io_dtype) and grad_indices = the (4, passes*B*n*4) int64 COO indices
- *                      (b, 0, y, x) of a sparse tensor of sdfb's shape (torch.sparse_coo_tensor; explicit zeros and duplicates included; row-major
- *                      (y, x) whatever `layout`).  passes = 1 (dgp_gn_step_backward, dgp_eval_errors_backward), 2 (dgp_gn_step_errors_backward with an
+ *                      (b, 0, y, x) of a sparse tensor of sdfb's shape (torch.sparse_coo_tensor; explicit zeros and duplicates included).  A TILED grid
+ *                      (layout DGP_SDF_TILED4, tensor (B,1,H'/4,W'/4,4,4)): SIX index rows (b, 0, y / 4, x / 4, y % 4, x % 4), a (6, nnz) array.  passes = 1 (dgp_gn_step_backward, dgp_eval_errors_backward), 2 (dgp_gn_step_errors_backward with an
  *                      unweighted-error cotangent: the taps at th + dtheta, then those at th) or max_iters (dgp_gn_solve_backward, whose caller
  *                      ZERO-FILLS both arrays: passes a trajectory did not run stay untouched).  No atomics, no O(B H' W') zero fill: the dense
  *                      gradient of B per-sample grids is 1 GiB of zeros at B = 4096, 256 x 256 around 4 MB of taps.  num_states <= 256.  */
@@ -115,7 +115,7 @@ typedef struct DgpSdf {
   int64_t     batch_stride;
   int32_t     layout;        /* DGP_SDF_*: layout of `data` (and of a dense g_sdf)                                                  */
   int32_t     grad_mode;     /* DGP_GSDF_*: backward entry points only                                                              */
-  int64_t*    grad_indices;  /* DGP_GSDF_SPARSE: the (4, nnz) int64 index array, else ignored                                        */
+  int64_t*    grad_indices;  /* DGP_GSDF_SPARSE: the (4, nnz) -- tiled grids: (6, nnz) -- int64 index array, else ignored              */
 } DgpSdf;
 
 /* Per-call covariance inputs = the three trailing arguments of PlanLayer.forward. */

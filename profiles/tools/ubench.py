@@ -138,7 +138,7 @@ def main():
       copies = int(num) if what.startswith('bwd_sdf') and num else 1
       gs, sab = None, sa
       if what == 'bwd_sparse':
-        gs = torch.empty(B * n * 4, device=dev, dtype=dt); gi = torch.empty((4, B * n * 4), device=dev, dtype=torch.int64)
+        gs = torch.empty(B * n * 4, device=dev, dtype=dt); gi = torch.empty((6 if a.layout == 'tiled4' else 4, B * n * 4), device=dev, dtype=torch.int64)      # (a tiled grid tensor has six index rows)
         sab = s.sdf_arg(sdf.data_ptr(), G, G, stride, layout=lay, grad_mode=_capi.DGP_GSDF_SPARSE, grad_indices=gi.data_ptr())
       elif what != 'bwd':
         gs = torch.zeros((copies if stride == 0 else B, 1, G, G), device=dev, dtype=torch.float64 if wide else dt)

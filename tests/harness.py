@@ -163,8 +163,17 @@ class Backend(object):
     COO indices; `passes` tap blocks, zero-filled as the chain kernels' caller must).  -> (state for _gsdf_out, g_sdf address, batch stride)"""
     sdf = np.asarray(sdf)
     stride = 0 if sdf.shape[0] == 1 else sdf.shape[-1] * sdf.shape[-2]
+    if self.sdf_tiled and sdf_grad == 'sparse':
+      # a tiled grid tensor (B,1,Ht,Wt,4,4): six index rows (b, 0, y/4, x/4, y%4, x%4)
+      assert sdf_copies == 1 and stride != 0
+      H, W = sdf.shape[-2], sdf.shape[-1]
+      nnz = passes * B * n * 4
+      vals, vals_p = self.empty((nnz,), io, fill=0.0)
+      idx, idx_p = self.empty((6, nnz), dtype=np.int64, fill=0)
+      sdf_arg.grad_mode = _capi.DGP_GSDF_SPARSE; sdf_arg.grad_indices = idx_p
+      return ('sparse_tiled', vals, idx, (sdf.shape[0], 1, (H + 3) // 4, (W + 3) // 4, 4, 4), (H, W)), vals_p, ((H + 3) // 4) * ((W + 3) // 4) * 16
     if self.sdf_tiled:
-      # a tiled grid takes a dense gradient in its own layout (sparse taps carry row-major indices: the dense form stands in, same values once untiled)
+      # a tiled grid takes a dense gradient in its own layout
       H, W = sdf.shape[-2], sdf.shape[-1]
       tshape = ((sdf_copies if sdf_copies > 1 else sdf.shape[0]), 1, (H + 3) // 4, (W + 3) // 4, 4, 4)
       wide = sdf_grad == 'f64'
@@ -191,6 +200,16 @@ class Backend(object):
     if st is None: return None
     if st[0] == 'dense': return self.to_np(st[1])
     if st[0] == 'tiled': return untile_np(self.to_np(st[1]), st[2])
+    if st[0] == 'sparse_tiled':
+      vals = self.to_np(st[1])
+      if self.kind == 'emul': idx = np.array(st[2])
+      else:
+        self.torch.cuda.synchronize(); idx = st[2].cpu().numpy()
+      shape = st[3]
+      for r in range(6): assert idx[r].min() >= 0 and idx[r].max() < shape[r], (r, idx[r].min(), idx[r].max(), shape)
+      out = np.zeros(shape, dtype=np.float64)
+      np.add.at(out, tuple(idx[r] for r in range(6)), vals)
+      return untile_np(out, st[4])
     vals = self.to_np(st[1])
     if self.kind == 'emul': idx = np.array(st[2])
     else:

@@ -911,6 +911,15 @@ def test_planner_accepts_tiled_grids(golden):
   ((d_r[0] * gd).sum() + ob_r.sum()).backward(); ((d_t[0] * gd).sum() + ob_t.sum()).backward()
   assert close(thr.grad, tht.grad, 1e-9) and sdf_t.grad.shape == sdf_t.shape
   assert rel_err(untile_sdf(sdf_t.grad, (G, G)).cpu().numpy(), sdf_r.grad.cpu().numpy()) < 1e-9 and float(sdf_r.grad.abs().max()) > 0
+  # ... and as sparse taps: a sparse tensor of the TILED tensor's shape (six index rows), no (B,1,H,W)-sized zero fill
+  planner.plan_layer.sdf_grad = 'sparse'
+  sdf_s = tile_sdf(sdf).requires_grad_(True); ths = th.clone().requires_grad_(True)
+  d_s = planner.step(ths, start, goal, None, sdf_s)
+  sg_s, gp_s, ob_s = planner.unweighted_errors_batch(ths + d_s[0], sdf_s)
+  ((d_s[0] * gd).sum() + ob_s.sum()).backward()
+  assert sdf_s.grad.is_sparse and sdf_s.grad.shape == sdf_s.shape
+  assert rel_err(untile_sdf(sdf_s.grad.to_dense(), (G, G)).cpu().numpy(), sdf_r.grad.cpu().numpy()) < 1e-9 and close(ths.grad, thr.grad, 1e-9)
+  planner.plan_layer.sdf_grad = 'dense'
   # forward(): the fused loop; a shared tiled grid as an expand()ed view, with its gradient
   one = T(base)[None, None]
   smooth = one.repeat(B, 1, 1, 1)      # (per-sample copies of the noise-free grid: ten chained non-converging solves on the noisy ones amplify the rounding differences of the two compilations)
