@@ -431,10 +431,14 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   //  dtheta wrong by O(1), found by tests/test_hip_every_kernel.py::test_hip_every_step_errors_kernel; the d = 6 Woodbury, scaled and Kronecker twins are verified there)
   const int qk = dgp::kernel_variant(p);
   // (the general family: d = 4 only, and not its 32-lane fp32 twin <2,32,4,float,STEP,general> -- miscompiled like the d = 6 static one, found by the same test)
-  const bool twin_ok = !(h->cfg.dof == 3 && (qk == dgp::QK_GENERAL || (qk == dgp::QK_STATIC && !p.wb_ok))) &&
-                       !(qk == dgp::QK_GENERAL && h->cfg.io_dtype == DGP_F32 && p.n > 64);
+  const bool twin_ok = DGP_ALLOW_ALL_TWINS ? !(h->cfg.dof == 3 && qk == dgp::QK_GENERAL)
+                                           : (!(h->cfg.dof == 3 && (qk == dgp::QK_GENERAL || (qk == dgp::QK_STATIC && !p.wb_ok))) &&
+                                              !(qk == dgp::QK_GENERAL && h->cfg.io_dtype == DGP_F32 && p.n > 64));
   if (errs && p.sdf_layout == 0 && p.n <= kMaxStatesTiled && twin_ok && !h->force_lpt) {
     p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
+#if DGP_ALLOW_ALL_TWINS      // reproducer builds: DGP_TWIN_NO_ERRS=1 launches the twin kernel with its epilogue switched off at run time (is the main body or the epilogue wrong?)
+    if (getenv("DGP_TWIN_NO_ERRS")) p.unw_sg = p.unw_gp = p.unw_obs = nullptr;
+#endif
     return launch((int)kModeStepErrs, p, (const dgp::GnGradParams*)nullptr);
   }
   rc = launch(dgp::MODE_STEP, p, (const dgp::GnGradParams*)nullptr);

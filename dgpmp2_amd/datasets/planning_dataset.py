@@ -40,7 +40,15 @@ def _imwrite(path, im):
 class PlanningDataset(Dataset):
   """Same constructor arguments, length and sample dict as the reference's PlanningDataset."""
 
-  def __init__(self, root_dir, mode='train', num_envs=-1, num_env_probs=-1, label_subdir='opt_trajs_gpmp2'):
+  def __init__(self, root_dir, mode='train', num_envs=-1, num_env_probs=-1, label_subdir='opt_trajs_gpmp2', sdf_layout='rowmajor', keep_rowmajor=False):
+    """sdf_layout (an addition): 'rowmajor' -- sample['sdf'] is the (1,H,W) field as the reference yields it; 'tiled4' -- the same values as the 4 x 4 tiles the GN
+    kernels read with half the memory traffic when every trajectory has its own grid (utils.sdf_utils.tile_sdf: a (1,H/4,W/4,4,4) TiledSdf that carries (H,W)).
+    Tiling runs here, in the DataLoader workers, so the training loop never pays for it; the default collate stacks the samples into the (B,1,H/4,W/4,4,4)
+    tensor that step() / forward() / the error helpers take in place of sdfb (PlanningDataset.collate does the same explicitly).  The learn modules of the
+    reference read `sdf` as an image channel (train_planner.py:273): keep_rowmajor=True keeps the row-major field next to the tiles, as sample['sdf_rm']."""
+    if sdf_layout not in ('rowmajor', 'tiled4'): raise ValueError("sdf_layout must be 'rowmajor' or 'tiled4'")
+    self.sdf_layout = sdf_layout
+    self.keep_rowmajor = bool(keep_rowmajor)
     self.root_dir = os.path.abspath(root_dir)
     self.subdir = os.path.join(root_dir, mode)
     self.imsdf_dir = os.path.join(self.subdir, 'im_sdf')
@@ -64,8 +72,26 @@ class PlanningDataset(Dataset):
     im = torch.from_numpy(np.array([im > 0.75], dtype=np.float64))
     sdf = torch.from_numpy(np.asarray(np.load(os.path.join(self.imsdf_dir, '%d_sdf.npy' % env_idx)), dtype=np.float64)[None])
     npf = np.load(os.path.join(self.label_dir, 'env_%d_prob_%d.npz' % (env_idx, prob_idx)))
-    return {'im': im, 'sdf': sdf, 'start': torch.from_numpy(np.atleast_2d(npf['start'])), 'goal': torch.from_numpy(np.atleast_2d(npf['goal'])),
-            'th_opt': torch.from_numpy(np.asarray(npf['th_opt']))}
+    sample = {'im': im, 'sdf': sdf, 'start': torch.from_numpy(np.atleast_2d(npf['start'])), 'goal': torch.from_numpy(np.atleast_2d(npf['goal'])),
+              'th_opt': torch.from_numpy(np.asarray(npf['th_opt']))}
+    if self.sdf_layout == 'tiled4':
+      from ..utils.sdf_utils import tile_sdf
+      if self.keep_rowmajor: sample['sdf_rm'] = sdf
+      sample['sdf'] = tile_sdf(sdf)
+    return sample
+
+  @staticmethod
+  def collate(samples):
+    """collate_fn for torch.utils.data.DataLoader: the default collation, with the tiled fields re-declared as a TiledSdf of the samples' logical size (the default
+    collate already keeps it; this one does not depend on that and checks that every sample has the same size)."""
+    from torch.utils.data import default_collate
+    from ..utils.sdf_utils import tiled_hw, as_tiled
+    batch = default_collate(samples)
+    hws = set(tiled_hw(s_['sdf']) for s_ in samples)
+    if hws != {None}:
+      if len(hws) != 1: raise ValueError('PlanningDataset.collate: tiled fields of different logical sizes in one batch: %s' % (sorted(hws, key=str),))
+      batch['sdf'] = as_tiled(batch['sdf'], hws.pop())
+    return batch
 
 
 def write_environment(root_dir, mode, env_idx, image, sdf):

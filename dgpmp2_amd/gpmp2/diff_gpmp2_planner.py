@@ -16,6 +16,7 @@ build's scope: pass your own modules as `learn_module_conv` / `learn_module_fcn`
 their output vector and the solver's covariance inputs, diff_gpmp2_planner.py:247-290) is provided.
 """
 import time
+from collections.abc import Sequence
 
 import numpy as np
 import torch
@@ -32,10 +33,32 @@ def _global_module_hooks():
               or getattr(m, '_global_forward_hooks_always_called', None))
 
 
-class _PerSampleHistory(object):
+class _LazySeq(Sequence):
+  """Base of the opt-in lazy per-sample results of forward() (DiffGPMP2Planner.lazy_results = True): a read-only collections.abc.Sequence (index / count /
+  `in` / reversed come from the mixin) that concatenates, compares and pickles like the python list it stands for."""
+
+  __slots__ = ()
+
+  def tolist(self): return [self[i] for i in range(len(self))]
+  def __add__(self, o): return self.tolist() + list(o)
+  def __radd__(self, o): return list(o) + self.tolist()
+  def __mul__(self, k): return self.tolist() * k
+  __rmul__ = __mul__
+  def __eq__(self, o):
+    if isinstance(o, _LazySeq): o = o.tolist()
+    return self.tolist() == (list(o) if isinstance(o, (list, tuple)) else o)
+  def __ne__(self, o): return not self.__eq__(o)
+  __hash__ = None
+  def __reduce__(self): return (list, (self.tolist(),))      # pickles (and deep-copies) as the plain list
+  def __repr__(self): return repr(self.tolist())
+
+
+class _PerSampleHistory(_LazySeq):
   """List-like view of a (B, max_iters) history array: item b is the python list of sample b's first iters[b] entries --
   what the reference accumulates sample by sample (diff_gpmp2_planner.py:140-141,163-164) -- built lazily, because
   materialising 4096 python lists costs more than the whole fused solve."""
+
+  __slots__ = ('_h', '_k')
 
   def __init__(self, hist, iters):
     self._h, self._k = hist, iters
@@ -51,14 +74,14 @@ class _PerSampleHistory(object):
   def __iter__(self):
     return (self[b] for b in range(len(self)))
 
-  def __repr__(self):
-    return 'PerSampleHistory(%d samples)' % len(self)
+  def tolist(self):
+    return [row[:int(k)].tolist() for row, k in zip(self._h, self._k)]
 
 
-class _LazyList(object):
+class _LazyList(_LazySeq):
   """A per-sample result of forward() -- the reference returns python lists with one entry per sample (diff_gpmp2_planner.py:138-174) -- kept as the numpy array
-  that came back from the device: indexing, slicing, iteration, len(), ==, np.asarray() and tolist() behave like the list, which is only materialised when someone
-  asks for it (building four 4096-element lists costs more host time than the whole fused solve runs)."""
+  that came back from the device: indexing, slicing, iteration, len(), ==, +, index(), count(), pickling, np.asarray() and tolist() behave like the list, which is
+  only materialised when someone asks for it.  Opt-in (DiffGPMP2Planner.lazy_results): forward() returns real lists by default, as the reference does."""
 
   __slots__ = ('_a',)
 
@@ -70,12 +93,6 @@ class _LazyList(object):
   def __iter__(self): return iter(self._a.tolist())
   def __array__(self, dtype=None, copy=None): return self._a if dtype is None else self._a.astype(dtype)
   def tolist(self): return self._a.tolist()
-  def __eq__(self, o):
-    if isinstance(o, _LazyList): o = o._a.tolist()
-    return self._a.tolist() == (list(o) if isinstance(o, (list, tuple)) else o)
-  def __ne__(self, o): return not self.__eq__(o)
-  __hash__ = None
-  def __repr__(self): return repr(self._a.tolist())
 
 
 class _SquaredCovs(torch.autograd.Function):
@@ -339,6 +356,9 @@ class DiffGPMP2Planner(nn.Module):
     return self._forward_stepwise(th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t)
 
   fused_history_budget = 2 << 30      # bytes of fp64 trajectory history a differentiable fused forward() may hold until its graph is freed
+  # forward() returns its per-sample results (err_initb, err_finalb, err_per_iterb, err_ext_per_iterb, jb) as python lists, like the reference.  True: list-like
+  # read-only views of the arrays that came back from the device instead (_LazyList / _PerSampleHistory: no 4096-element list construction per call)
+  lazy_results = False
 
   def _chain_backward_available(self, B=1, max_iters=1):
     """dgp_gn_solve_backward covers static covariances with a diagonal Q_c_inv and trajectories of up to 256 states; anything else
@@ -355,6 +375,7 @@ class DiffGPMP2Planner(nn.Module):
     pl = self.plan_layer
     pl._check_inputs(th_initb, startb, goalb)
     B = th_initb.shape[0]
+    if pl.auto_tile: sdfb = pl._auto_tiled(sdfb, B)
     dt, dev = th_initb.dtype, th_initb.device
     solver = pl._solver(dt)
     idx = th_initb.get_device()
@@ -395,7 +416,9 @@ class DiffGPMP2Planner(nn.Module):
     ef_c = host[2 * B * m:2 * B * m + B].numpy()
     jb = host[2 * B * m + B:].view(torch.int32)[:B].numpy()
     t = time.time() - start_t
-    return (th_out, None, _LazyList(eh_c[:, 0]), _LazyList(ef_c), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), _LazyList(jb), [t] * B)
+    res = (_LazyList(eh_c[:, 0]), _LazyList(ef_c), _PerSampleHistory(eh_c, jb), _PerSampleHistory(eeh_c, jb), _LazyList(jb))
+    if not self.lazy_results: res = tuple(r.tolist() for r in res)      # python lists, one entry per sample, as the reference returns them (:138-174)
+    return (th_out, None) + res + ([t] * B,)
 
   def _forward_stepwise(self, th_initb, startb, goalb, imb, sdfb, hiddenb, max_iters, tol_delta, plan_time, start_t):
     """Differentiable / learned / time-limited variant: chained batched step() calls with a per-trajectory freeze once
@@ -429,7 +452,17 @@ class DiffGPMP2Planner(nn.Module):
     E = torch.stack(errs, 1).cpu().numpy(); EE = torch.stack(errs_ext, 1).cpu().numpy(); jl = jb.cpu().tolist()
     t = time.time() - start_t
     hidden_newb = hidden if hiddenb is not None else None
-    return th, hidden_newb, E[:, 0].tolist(), err_final, _PerSampleHistory(E, jl), _PerSampleHistory(EE, jl), jl, [t] * B
+    he, hee = _PerSampleHistory(E, jl), _PerSampleHistory(EE, jl)
+    if not self.lazy_results: he, hee = he.tolist(), hee.tolist()
+    return th, hidden_newb, E[:, 0].tolist(), err_final, he, hee, jl, [t] * B
+
+  def graphed_iteration(self, fn, warmup=3, clone_outputs=False):
+    """`fn` -- one iteration of an outer loop written against this planner (step() / step_with_errors() / the error helpers, a loss, autograd.grad or backward(),
+    optionally the optimiser step), a function of its tensor arguments -- as a callable that records the iteration in a HIP graph at its first call and replays
+    it afterwards: the eager loop of learning/train_planner.py:297-403 keeps its shape and loses Python, the autograd engine and ~20 launch enqueues per iteration
+    (utils/graph_utils.py: the rules `fn` must obey, and what is returned).  No counterpart in the reference."""
+    from ..utils.graph_utils import GraphedIteration
+    return GraphedIteration(fn, warmup=warmup, clone_outputs=clone_outputs)
 
   def error_batch(self, thb, sdfb):
     return self.plan_layer.error_batch(thb, sdfb)

@@ -216,6 +216,9 @@ def _expand_base(t):
   launch) and returns the (1, 1, H, W) gradient itself.  Anything else (a view of a view, a differently strided base) is returned unchanged and gets B
   equal shares (see _SdfGrad.finish)."""
   if t is None or t.dim() not in (4, 6) or t.shape[0] <= 1 or t.stride(0) != 0 or not t._is_view(): return t
+  # the view itself is wanted as a gradient target (retain_grad(), a tensor hook on it): differentiate w.r.t. the view as the reference would -- it gets B equal
+  # shares and autograd's ExpandBackward sums them.  (torch.autograd.grad(..., inputs=view) cannot be seen from here: pass the base, or a non-expanded tensor.)
+  if t.retains_grad or t._backward_hooks: return t
   b = t._base
   if (b is not None and b.dim() == t.dim() and b.shape[0] == 1 and b.shape[1:] == t.shape[1:] and b.stride()[1:] == t.stride()[1:] and b.data_ptr() == t.data_ptr()
       and b.dtype is t.dtype and b.requires_grad == t.requires_grad):
@@ -257,11 +260,11 @@ class _SdfGrad(object):
       which the atomics landed; summed over the copies here.
   per-sample grids (the reference's API shape, sdfb (B,1,H,W) with `sdf_b.requires_grad_(True)`, learning/train_planner.py:267): the reference's gradient is a
       dense (B,1,H,W) tensor -- 1 GiB of zeros around 4 MB of taps at B = 4096, 256 x 256.  `layer.sdf_grad`:
-        'dense'  that tensor (zero-filled here, atomics in the kernel; the reference's layout);
+        'dense'  (default) that tensor (zero-filled here, atomics in the kernel; the reference's layout);
         'sparse' a torch.sparse_coo_tensor of sdfb's shape holding the 4 n B taps (DGP_GSDF_SPARSE: no zero fill, no atomics; uncoalesced -- explicit zeros and
                  the duplicates of neighbouring states included; .to_dense() / .coalesce() give the reference's tensor).  AccumulateGrad takes a sparse gradient
                  for a dense leaf (sdfb.grad is then sparse, and sums with dense or sparse gradients from other nodes);
-        'auto'   (default) sparse when sdfb is a LEAF tensor, the trajectory has at most 256 states and the dense gradient would be larger than both
+        'auto'   sparse when sdfb is a LEAF tensor, the trajectory has at most 256 states and the dense gradient would be larger than both
                  _SPARSE_MIN_DENSE_BYTES and twice the sparse one; dense otherwise (a non-leaf's producer may not accept sparse gradients).
   A tiled grid tensor (B,1,H/4,W/4,4,4) gets a gradient of its own shape either way: dense tiles, or a sparse tensor with six index rows."""
 
@@ -685,6 +688,31 @@ class _EvalErrors(torch.autograd.Function):
 _EvalErrors._backward_once = staticmethod(once_differentiable(_EvalErrors._backward_impl))
 
 
+class _AutoTile(torch.autograd.Function):
+  """PlanLayer.auto_tile: a per-sample ROW-MAJOR sdfb (B,1,H,W) stands in the graph, the kernels read its 4 x 4-tiled copy `tiles` (made once per batch of grids,
+  PlanLayer._auto_tiled).  forward: the cached tiles, no work; backward: the gradient of the tiled tensor -> the gradient of the row-major one -- a dense tiled gradient
+  is un-tiled (views + one slice: AccumulateGrad's copy is the only pass over it), a sparse one (six index rows b,0,y/4,x/4,y%4,x%4) gets the four row-major index
+  rows (b,0,y,x); taps of padding cells do not exist (the lookup clamps to H-1 / W-1)."""
+
+  @staticmethod
+  def forward(ctx, sdfb, tiles):
+    ctx.hw = (int(sdfb.shape[-2]), int(sdfb.shape[-1]))
+    ctx.shape = tuple(sdfb.shape)
+    return tiles.detach()
+
+  @staticmethod
+  @once_differentiable
+  def backward(ctx, g):
+    H, W = ctx.hw
+    if g.is_sparse:
+      i = g._indices()
+      idx = torch.stack((i[0], i[1], i[2] * 4 + i[4], i[3] * 4 + i[5]))
+      return torch.sparse_coo_tensor(idx, g._values(), ctx.shape, check_invariants=False), None
+    with torch._C.DisableTorchFunctionSubclass():
+      B, C_, Ht, Wt = g.shape[:4]
+      return g.permute(0, 1, 2, 4, 3, 5).reshape(B, C_, Ht * 4, Wt * 4)[:, :, :H, :W], None
+
+
 class PlanLayer(nn.Module):
   """See module docstring.  Constructor mirrors plan_layer.py:14."""
 
@@ -717,7 +745,17 @@ class PlanLayer(nn.Module):
     self.dynamics_mode = learn_params['dgpmp2']['dynamics_mode'] if learn_params is not None else None
     self._q_full = learn_params is not None and self.dynamics_mode == 'q_full'        # plan_layer.py:90
     self.check_spd = check_spd
-    self.sdf_grad = 'auto'             # how the gradient of PER-SAMPLE grids is returned: 'auto' | 'dense' | 'sparse' (see _SdfGrad)
+    # how the gradient of PER-SAMPLE grids is returned: 'dense' (default: the reference's layout, a dense tensor of sdfb's shape) | 'sparse' | 'auto' (sparse for
+    # large leaf grids) -- see _SdfGrad; sparse gradients are an opt-in because optimisers, clip_grad_norm_ and DDP buckets do not take them
+    self.sdf_grad = 'dense'
+    self.sdf_hw = None                 # logical (H, W) of tiled grids that arrive as PLAIN (B,1,Ht,Wt,4,4) tensors (a utils.sdf_utils.TiledSdf carries its own)
+    # True: a per-sample row-major sdfb (B,1,H,W) -- the reference's API shape -- is tiled ONCE per batch of grids (per tensor object / storage / version) and every
+    # launch that follows reads the tiles: half the grid traffic per step.  Pays when a batch of grids is used for more launches than the
+    # tiling pass costs (one read + one write of the grids: ~0.4 ms per GiB; ~3 us saved per launch at B = 4096) -- the TBPTT window of learning/train_planner.py
+    # re-uses one batch for every iteration of a window.  Off by default: a single step() per batch of grids would lose.  Grids that are already tiled, shared
+    # (expand()ed) grids and trajectories of more than 128 states are left alone.
+    self.auto_tile = False
+    self._tile_cache = None            # (weakref to the row-major tensor, data_ptr, version, shape, dtype) -> its TiledSdf
     self.last_info = None
     self._last = None
     self._solvers = {}                 # torch dtype -> _capi.Solver
@@ -806,19 +844,63 @@ class PlanLayer(nn.Module):
       self.__dict__['_sdf_cache'] = None
     return res[:7] + (t,)                       # (the caller's copy of the result keeps the view alive for the duration of the call)
 
+  def _auto_tiled(self, sdfb, B):
+    """auto_tile: sdfb as the launches should see it -- its cached 4 x 4-tiled copy when it is a per-sample row-major batch of grids, sdfb itself otherwise.  With
+    requires_grad the tiles enter the graph through _AutoTile, so gradients come back in sdfb's own (row-major) shape."""
+    if (sdfb is None or sdfb.dim() != 4 or sdfb.shape[0] != B or B == 1 or sdfb.stride(0) == 0 or sdfb.shape[1] != 1 or self.num_traj_states > 128
+        or sdfb.dtype not in (torch.float32, torch.float64)):
+      return sdfb
+    c = self._tile_cache
+    # (under HIP-graph capture the tiling pass is recorded with everything else and re-run by every replay -- a cached copy would go stale when the caller writes new
+    #  grids into the captured tensor: give a graphed iteration pre-tiled grids instead, PlanningDataset(sdf_layout='tiled4') / tile_sdf)
+    capturing = sdfb.is_cuda and torch.cuda.is_current_stream_capturing()
+    if capturing or not (c is not None and c[0]() is sdfb and c[1] == sdfb.data_ptr() and c[2] == sdfb._version and c[3] == sdfb.shape and c[4] is sdfb.dtype):
+      from ..utils.sdf_utils import tile_sdf
+      with torch.no_grad():
+        tiles = tile_sdf(sdfb.detach())
+      if capturing:
+        if sdfb.requires_grad and torch.is_grad_enabled():
+          out = _AutoTile.apply(sdfb, tiles)
+          out.__dict__.setdefault('_dgp_hw', tiles.__dict__['_dgp_hw'])
+          return out
+        return tiles
+      me = weakref.ref(self)
+
+      def _drop(_, me=me):
+        s_ = me()
+        if s_ is not None: s_.__dict__['_tile_cache'] = None
+      try: c = (weakref.ref(sdfb, _drop), sdfb.data_ptr(), sdfb._version, sdfb.shape, sdfb.dtype, tiles)
+      except TypeError: return sdfb
+      self.__dict__['_tile_cache'] = c
+    tiles = c[5]
+    if sdfb.requires_grad and torch.is_grad_enabled():
+      out = _AutoTile.apply(sdfb, tiles)
+      if '_dgp_hw' not in out.__dict__: out.__dict__['_dgp_hw'] = tiles.__dict__['_dgp_hw']
+      return out
+    return tiles
+
   def _tiled_sdf_args(self, sdfb, dtype, B, dev):
     """A grid stored as 4 x 4 tiles, (B | 1, 1, Ht, Wt, 4, 4) contiguous per grid (utils.sdf_utils.tile_sdf): -> the DgpSdf fields with layout DGP_SDF_TILED4.  The
-    logical size comes from the tensor's `_dgp_hw` tag (4 Ht x 4 Wt without one).  Not cached: the checks are cheap next to a kernel on per-sample grids."""
-    if sdfb.shape[1] != 1: raise ValueError('tiled sdfb must be (B,1,Ht,Wt,4,4)')
-    Ht, Wt = int(sdfb.shape[2]), int(sdfb.shape[3])
-    H, W = sdfb.__dict__.get('_dgp_hw', (Ht * 4, Wt * 4))
-    if (H + 3) // 4 != Ht or (W + 3) // 4 != Wt: raise ValueError('tiled sdfb of %d x %d tiles does not hold a %d x %d grid' % (Ht, Wt, H, W))
-    shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
-    if not shared and sdfb.shape[0] != B:
-      raise ValueError('sdfb has %d grids for a batch of %d trajectories (expected %d, or 1 / an expand()ed view for a shared grid)' % (sdfb.shape[0], B, B))
-    t = (sdfb[0:1] if shared else sdfb).detach()
-    if t.dtype != dtype or not t.is_contiguous(): t = t.to(dtype).contiguous()
-    return (t.data_ptr(), int(H), int(W), 0 if shared else Ht * Wt * 16, _capi.DGP_SDF_TILED4, 0, None, t)
+    logical size (H, W) -- it sets the resolution and the clamping of the lookup, and the tile counts do not determine it (130 and 132 both give 33 tiles) -- comes
+    from the tensor (a utils.sdf_utils.TiledSdf carries it through .to() / .detach() / indexing / collation) or, for a plain tensor that lost it, from
+    `self.sdf_hw`; without either the call is refused rather than guessed.  Not cached: the checks are cheap next to a kernel on per-sample grids."""
+    hw = sdfb.__dict__.get('_dgp_hw') or self.sdf_hw
+    with torch._C.DisableTorchFunctionSubclass():      # (a TiledSdf: no __torch_function__ round trip per attribute below)
+      if sdfb.shape[1] != 1: raise ValueError('tiled sdfb must be (B,1,Ht,Wt,4,4)')
+      Ht, Wt = int(sdfb.shape[2]), int(sdfb.shape[3])
+      if hw is None:
+        raise ValueError('tiled sdfb (B,1,%d,%d,4,4) carries no logical grid size: it is not a utils.sdf_utils.TiledSdf (tile_sdf / sdf_2d_batch(layout="tiled4") return one; '
+                         'as_tiled(t, (H, W)) re-declares tiles that went through foreign code) and plan_layer.sdf_hw is not set.  The size cannot be guessed: '
+                         '%d x %d tiles hold any grid from %d x %d to %d x %d, and H, W set the resolution and the clamping of the lookup' %
+                         (Ht, Wt, Ht, Wt, 4 * Ht - 3, 4 * Wt - 3, 4 * Ht, 4 * Wt))
+      H, W = int(hw[0]), int(hw[1])
+      if (H + 3) // 4 != Ht or (W + 3) // 4 != Wt: raise ValueError('tiled sdfb of %d x %d tiles does not hold a %d x %d grid' % (Ht, Wt, H, W))
+      shared = sdfb.stride(0) == 0 or sdfb.shape[0] == 1
+      if not shared and sdfb.shape[0] != B:
+        raise ValueError('sdfb has %d grids for a batch of %d trajectories (expected %d, or 1 / an expand()ed view for a shared grid)' % (sdfb.shape[0], B, B))
+      t = (sdfb[0:1] if shared else sdfb).detach()
+      if t.dtype != dtype or not t.is_contiguous(): t = t.to(dtype).contiguous()
+      return (t.data_ptr(), H, W, 0 if shared else Ht * Wt * 16, _capi.DGP_SDF_TILED4, 0, None, t)
 
   @staticmethod
   def static_flags(qc, ow, eps):
@@ -877,6 +959,7 @@ class PlanLayer(nn.Module):
   def forward(self, thb, startb, goalb, imb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb):
     """plan_layer.py:87-99.  -> (dthetab (B,n,d), err (B,1,1) [no grad], err_ext (B,1,1) [grad])."""
     self._check_inputs(thb, startb, goalb)
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     # like the reference (plan_layer.py:88-94) remember means / covariances for the error_* helpers below
     static = self.static_flags(qc_inv_trajb, obscov_inv_trajb, eps_trajb)
     # (start / goal / eps are kept WITH their graphs, as set_mean / set_eps do: error_ext_batch and the unweighted errors are
@@ -904,6 +987,7 @@ class PlanLayer(nn.Module):
     everything but err carries the graph (ONE autograd node, ONE backward call).  Equivalent to
         dth, err, eex = layer(thb, ...); sg, gp, ob = layer.unweighted_errors(thb + dth, sdfb)"""
     self._check_inputs(thb, startb, goalb)
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     B = thb.shape[0]
     if self.num_traj_states > 256:      # the fused entry points stop at 256 states: the two calls this method stands for (the loop kernels of gn_long.h)
       dth, err, eex = self.forward(thb, startb, goalb, imb, sdfb, qc_inv_trajb, obscov_inv_trajb, eps_trajb)
@@ -948,6 +1032,7 @@ class PlanLayer(nn.Module):
     -> (dthetab, err, err_ext[, err_sg (B,1), err_gp, err_obs], qc_inv_trajb or None, obscov_inv_trajb, eps_trajb or None): the last three are what
     get_covariances would have built (same values), carrying the graph to `out` like everything else."""
     self._check_inputs(thb, startb, goalb)
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     out = raw.out
     if out.dtype is not thb.dtype or out.get_device() != thb.get_device() or out.shape[0] != thb.shape[0]:
       raise ValueError('the learn module output must share dtype, device and batch with thb')
@@ -1004,6 +1089,7 @@ class PlanLayer(nn.Module):
     """(err, err_ext, start_goal_error, gp_error, obs_error), each (B,1,1), in one launch (dgp_eval_errors).  Unlike the
     reference (which reads the means/covariances left behind by the last forward()) everything is an argument."""
     self._check_inputs(thb, startb, goalb)
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     return tuple(self._eval(thb, sdfb, startb, goalb, qc_inv_trajb, obscov_inv_trajb, eps_trajb))
 
   def _last_or_raise(self):
@@ -1015,12 +1101,14 @@ class PlanLayer(nn.Module):
   def error_batch(self, thb, sdfb):
     """plan_layer.py:273-308: normalised factor-graph error at thb, no grad, with the covariances of the last forward()."""
     st, go, qc, ow, eps = self._last_or_raise()
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     with torch.no_grad():
       return self._eval(thb, sdfb, st, go, qc, ow, eps)[0]
 
   def _eval_diff(self, thb, sdfb, st, go, eps):
     """(err_ext, start_goal_error, gp_error, obs_error) at thb, each (B,1,1) (None where a grid is needed and sdfb is None), carrying
     the autograd graph the reference's plain torch ops would carry: w.r.t. thb, sdfb, the start / goal means and the current eps."""
+    if self.auto_tile: sdfb = self._auto_tiled(sdfb, thb.shape[0])
     if torch.is_grad_enabled():
       if sdfb is not None and sdfb.requires_grad: sdfb = _expand_base(sdfb)
       ts = (thb, st, go, sdfb, eps)

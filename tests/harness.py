@@ -19,11 +19,13 @@ def build_emulator(force=False):
   src = os.path.join(EMUL_DIR, 'emul_main.cpp')
   deps = [src] + [os.path.join(ROOT, 'dgpmp2_amd', 'csrc', f) for f in ('gn_lane.h', 'gn_woodbury.h', 'gn_backward.h', 'gn_long.h', 'dgp_host.h')] + \
          [os.path.join(ROOT, 'include', 'dgpmp2_hip.h')]
-  if force or not os.path.exists(EMUL_LIB) or any(os.path.getmtime(d) > os.path.getmtime(EMUL_LIB) for d in deps):
+  # DGP_EMUL_CXX / DGP_EMUL_LIB (profiles/tools/r06_emul_sanitize.sh): another compiler and output name -- the sanitizer / poisoned-stack builds of the lane program
+  lib = os.environ.get('DGP_EMUL_LIB', EMUL_LIB)
+  if force or not os.path.exists(lib) or any(os.path.getmtime(d) > os.path.getmtime(lib) for d in deps):
     extra = os.environ.get('DGP_EMUL_FLAGS', '').split()      # experiment macros of the kernel source (e.g. -DDGP_PCR_LDL=1), tuning only
-    subprocess.check_call(['g++', '-O1', '-std=c++17', '-ffp-contract=off', '-Wno-unknown-pragmas', '-fPIC', '-shared',
-                           '-pthread'] + extra + [src, '-o', EMUL_LIB])
-  return EMUL_LIB
+    subprocess.check_call([os.environ.get('DGP_EMUL_CXX', 'g++'), '-O1', '-std=c++17', '-ffp-contract=off', '-Wno-unknown-pragmas', '-fPIC', '-shared',
+                           '-pthread'] + extra + [src, '-o', lib])
+  return lib
 
 
 _emul_api = None

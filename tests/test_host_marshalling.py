@@ -266,3 +266,107 @@ def test_inplace_change_between_forward_and_backward_raises(layer):
   dth, err, eex = layer(th, st, go, None, sdf, None, None, None)
   dth.sum().backward()                                                            # untouched inputs: fine
   assert th.grad.shape == th.shape
+
+
+def test_tiled_grid_needs_its_logical_size(layer):
+  """a 6-D tiled grid without a logical size is refused, not read as 4 Ht x 4 Wt.  The size rides on utils.sdf_utils.TiledSdf through .to() / .detach() /
+  clone() / indexing / expand() / cat / stack; a plain tensor needs plan_layer.sdf_hw (or as_tiled)."""
+  from dgpmp2_amd.utils.sdf_utils import tile_sdf, untile_sdf, as_tiled, tiled_hw
+  th, st, go, _ = _inputs()
+  sdf = torch.randn(3, 1, 10, 13, dtype=torch.float32)             # 10 x 13: 3 x 4 tiles, which could as well hold 12 x 16
+  t = tile_sdf(sdf)
+  assert tuple(t.shape) == (3, 1, 3, 4, 4, 4) and t.hw == (10, 13) and torch.equal(untile_sdf(t), sdf)
+  for u in (t.to(torch.float64).float(), t.clone(), t.detach(), t[0:3], torch.cat([t[:1], t[1:]], 0), torch.stack([t[0], t[1], t[2]], 0), t.contiguous(), t * 1.0):
+    assert tiled_hw(u) == (10, 13), type(u)
+  assert tiled_hw(t.sum()) is None and tiled_hw(t.reshape(3, -1)) is None   # not tiles any more: a plain tensor
+  layer(th, st, go, None, t, None, None, None)
+  a = layer._pc.calls[-1][1]
+  assert a[5:10] == (t.data_ptr(), 10, 13, 3 * 4 * 16, _capi.DGP_SDF_TILED4)
+  plain = t.as_subclass(torch.Tensor)
+  assert tiled_hw(plain) is None
+  with pytest.raises(ValueError, match='carries no logical grid size'):
+    layer(th, st, go, None, plain, None, None, None)
+  layer.sdf_hw = (10, 13)                                           # the explicit size of plain tiled tensors
+  layer(th, st, go, None, plain, None, None, None)
+  assert layer._pc.calls[-1][1][6:8] == (10, 13)
+  layer.sdf_hw = (10, 17)                                           # ... is checked against the tile counts
+  with pytest.raises(ValueError, match='does not hold'):
+    layer(th, st, go, None, plain, None, None, None)
+  layer.sdf_hw = None
+  layer(th, st, go, None, as_tiled(plain, (10, 13)), None, None, None)
+  assert layer._pc.calls[-1][1][6:8] == (10, 13)
+  with pytest.raises(ValueError):
+    as_tiled(plain, (12, 17))
+  # a shared tiled grid: the expand()ed view keeps the size, and so does its base when the node differentiates w.r.t. it
+  one = tile_sdf(sdf[:1]).requires_grad_(True)
+  dth, err, eex = layer(th.clone().requires_grad_(True), st, go, None, one.expand(3, 1, 3, 4, 4, 4), None, None, None)
+  assert layer._pc.calls[-1][1][5:9] == (one.data_ptr(), 10, 13, 0)
+
+
+def test_per_sample_grid_gradient_is_dense_by_default(layer):
+  """the reference's layout (a dense tensor of sdfb's shape) unless the caller opts into 'sparse' / 'auto'."""
+  assert layer.sdf_grad == 'dense'
+  th, st, go, _ = _inputs()
+  old = PL._SPARSE_MIN_DENSE_BYTES
+  try:
+    PL._SPARSE_MIN_DENSE_BYTES = 0
+    big = torch.randn(3, 1, 64, 64).requires_grad_(True)
+    dth, err, eex = layer(th, st, go, None, big, None, None, None)
+    dth.sum().backward()
+    assert layer._pc.calls[-1][1][10] == _capi.DGP_GSDF_DENSE and not big.grad.is_sparse and big.grad.shape == big.shape
+  finally:
+    PL._SPARSE_MIN_DENSE_BYTES = old
+
+
+def test_expanded_grid_view_with_retain_grad_is_differentiated_as_it_is(layer):
+  """the node swaps an expand()ed shared grid for its base (no B-fold sum) -- unless the VIEW itself is wanted as a gradient target."""
+  th, st, go, sdf = _inputs()
+  base = sdf.clone().requires_grad_(True)
+  view = base.expand(3, 1, 8, 10)
+  assert PL._expand_base(view) is base
+  view2 = base.expand(3, 1, 8, 10); view2.retain_grad()
+  assert PL._expand_base(view2) is view2
+  view3 = base.expand(3, 1, 8, 10); view3.register_hook(lambda g: g)
+  assert PL._expand_base(view3) is view3
+  dth, err, eex = layer(th.clone().requires_grad_(True), st, go, None, view2, None, None, None)
+  dth.sum().backward()
+  assert view2.grad is not None and view2.grad.shape == view2.shape and base.grad.shape == base.shape
+
+
+def test_auto_tile_tiles_a_per_sample_batch_once(layer):
+  """plan_layer.auto_tile: a per-sample row-major sdfb is tiled once per (tensor, storage, version) and the launches read the tiles; the gradient comes back in sdfb's
+  own row-major shape (dense: un-tiled; sparse: four row-major index rows); shared / already tiled / single grids are left alone."""
+  from dgpmp2_amd.utils.sdf_utils import tile_sdf
+  th, st, go, sdf = _inputs()
+  per = torch.randn(3, 1, 10, 13, dtype=torch.float32)
+  layer(th, st, go, None, per, None, None, None)
+  assert layer._pc.calls[-1][1][9] == _capi.DGP_SDF_ROWMAJOR and layer._tile_cache is None      # off by default
+  layer.auto_tile = True
+  layer(th, st, go, None, per, None, None, None)
+  a = layer._pc.calls[-1][1]
+  tiles = layer._tile_cache[5]
+  assert a[5:10] == (tiles.data_ptr(), 10, 13, 3 * 4 * 16, _capi.DGP_SDF_TILED4) and torch.equal(tiles, tile_sdf(per))
+  layer(th, st, go, None, per, None, None, None)
+  assert layer._tile_cache[5] is tiles and layer._pc.calls[-1][1][5] == tiles.data_ptr()          # same tensor, same version: no second tiling pass
+  per.add_(1.0)                                                                                    # an in-place change bumps the version: tiled again
+  layer(th, st, go, None, per, None, None, None)
+  assert layer._tile_cache[5] is not tiles and torch.equal(layer._tile_cache[5], tile_sdf(per))
+  layer.error_batch(th, per)                                                                       # the error helpers read the same tiles
+  assert layer._pc.calls[-1][0] == 'eval_errors' and layer._pc.calls[-1][1][9] == _capi.DGP_SDF_TILED4
+  layer(th, st, go, None, sdf.expand(3, 1, 8, 10), None, None, None)                              # a shared grid stays as it is (it lives in L2)
+  assert layer._pc.calls[-1][1][9] == _capi.DGP_SDF_ROWMAJOR
+  # gradients arrive in the row-major shape of the tensor the caller holds
+  leaf = per.clone().requires_grad_(True)
+  dth, err, eex = layer(th.clone().requires_grad_(True), st, go, None, leaf, None, None, None)
+  dth.sum().backward()
+  b = layer._pc.calls[-1][1]
+  assert layer._pc.calls[-1][0] == 'gn_step_backward' and b[9] == _capi.DGP_SDF_TILED4 and b[10] == _capi.DGP_GSDF_DENSE
+  assert leaf.grad.shape == leaf.shape and not leaf.grad.is_sparse
+  # the index conversion of a sparse tiled gradient (b,0,y/4,x/4,y%4,x%4) -> (b,0,y,x)  (the recording stand-in fills no indices: the sparse launch itself runs on the GPU tests)
+  idx = torch.tensor([[0, 2], [0, 0], [1, 2], [3, 0], [2, 1], [0, 3]])
+  g = torch.sparse_coo_tensor(idx, torch.tensor([1.5, -2.0]), (3, 1, 3, 4, 4, 4), check_invariants=False)
+
+  class Ctx(object): hw = (10, 13); shape = (3, 1, 10, 13)
+  with torch.no_grad():
+    d = PL._AutoTile.backward(Ctx, g)[0].to_dense()
+  assert d.shape == (3, 1, 10, 13) and d[0, 0, 6, 12] == 1.5 and d[2, 0, 9, 3] == -2.0 and d.abs().sum() == 3.5
