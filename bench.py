@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 B_PER_GPU, N_STATES, DOF, GRID = 4096, 64, 2, 256
+STRONG_TOTAL = 32768      # --strong: BASELINE configs[4], one batch of 32768 trajectories for the whole node
 GN_ITERS = 10
 PREWARM_S = float(os.environ.get("DGP_BENCH_PREWARM_S", 0.6))      # (override: tuning only; 0.6 against 2.5 s makes no difference to the 20-step runs)
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -158,16 +159,41 @@ def quiet_fds():
     for fd in saved + [null]: os.close(fd)
 
 
+def mem_available_gb():
+  """Host memory this process may really take: min(MemAvailable, what the container's cgroup limit leaves) -- /proc/meminfo shows the HOST's memory inside a
+  container, and a process that outgrows its cgroup is killed without warning."""
+  avail = 0.0
+  try:
+    for line in open('/proc/meminfo'):
+      if line.startswith('MemAvailable:'): avail = int(line.split()[1]) / (1 << 20)
+  except (OSError, ValueError, IndexError):
+    return 0.0
+  for lim, use in (('/sys/fs/cgroup/memory.max', '/sys/fs/cgroup/memory.current'),
+                   ('/sys/fs/cgroup/memory/memory.limit_in_bytes', '/sys/fs/cgroup/memory/memory.usage_in_bytes')):
+    try:
+      v = open(lim).read().strip()
+      if v != 'max' and int(v) < (1 << 60):
+        avail = min(avail, (int(v) - int(open(use).read().strip())) / (1 << 30))
+    except (OSError, ValueError):
+      pass
+  return max(avail, 0.0)
+
+
 def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
-  """The reference's dense PyTorch-CPU op sequence (oracle/dense_torch.py, kind 'port'), fp64, all host cores, on a
-  bounded sample: `chunk` of the 4096 trajectories, 1 warm-up + `steps` timed steps; scaled to whole-batch steps/s."""
+  """The reference's dense PyTorch-CPU op sequence (oracle/dense_torch.py, kind 'port'), fp64, all host cores.  SURVEY 8(d): the FULL 4096-trajectory batch in one
+  call when the host has >= 40 GB available (the reference itself needs 30.5 GB RSS there; 1 warm-up + 1 timed step: a step takes ~7 s on 16 cores), otherwise a bounded
+  sample: `chunk` of the 4096 trajectories, 1 warm-up + `steps` timed steps, scaled to whole-batch steps/s.  `sample` says which.  DGP_BENCH_CPU_FULL=0 / 1 overrides."""
   from oracle import dense_torch as DT
   from oracle.gpmp2_oracle import OracleParams
   cores = usable_cores()
   torch.set_num_threads(cores)
   p = OracleParams(dof=DOF, total_time_step=N_STATES - 1)
   P = DT.params_from_oracle(p)
-  B = chunk
+  avail = mem_available_gb()
+  env = os.environ.get('DGP_BENCH_CPU_FULL')
+  full = (avail >= 40.0) if env is None else env == '1'
+  B = B_PER_GPU if full else chunk
+  if full: steps = 1
   qc = torch.from_numpy(p.static_covs(B)[0]); ow = torch.from_numpy(p.static_covs(B)[1]); eps = torch.from_numpy(p.static_covs(B)[2])
   sdf = sdf_cpu.double().expand(B, 1, GRID, GRID)
   # does this host's MKL accept batched torch.inverse (what the reference calls, plan_layer.py:227-228)?  Probe it on a tiny
@@ -195,10 +221,12 @@ def cpu_baseline(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, chunk=256, steps=3):
       DT.plan_layer_forward(th, start_cpu[:B].double(), goal_cpu[:B].double(), sdf, qc, ow, eps, P)
       ts.append(time.perf_counter() - t0)
   t_chunk = float(np.median(ts[1:]))
+  sample = ('dense PyTorch-CPU fp64 restatement of PlanLayer.forward on the FULL batch of 4096 trajectories in one call (MemAvailable %.0f GB >= 40), 1 warm-up + %d timed '
+            'step(s), %.3f s per step; explicit inverses via %s' % (avail, steps, t_chunk, inverse_impl)) if full else \
+           ('dense PyTorch-CPU fp64 restatement of PlanLayer.forward on %d of the 4096 trajectories (MemAvailable %.0f GB < 40: not the full batch), 1 warm-up + %d timed '
+            'steps, median %.3f s per %d-trajectory step, scaled by 4096/%d; explicit inverses via %s' % (B, avail, steps, t_chunk, B, B, inverse_impl))
   return {'value': 1.0 / (t_chunk * (B_PER_GPU / B)), 'unit': 'GN steps/s (batch 4096)', 'cores': cores, 'cpu_model': cpu_model(), 'kind': 'port',
-          'sample': 'dense PyTorch-CPU fp64 restatement of PlanLayer.forward on %d of the 4096 trajectories, 1 warm-up + %d timed '
-                    'steps, median %.3f s per %d-trajectory step, scaled by 4096/%d; explicit inverses via %s' % (B, steps, t_chunk, B, B, inverse_impl),
-          'torch_threads': torch.get_num_threads()}
+          'sample': sample, 'full_batch': bool(full), 'torch_threads': torch.get_num_threads()}
 
 
 def cpu_blocktri(th_hist_cpu, start_cpu, goal_cpu, sdf_cpu, steps=5):
@@ -245,11 +273,23 @@ def time_launches(launch, reps, warm_s=0.3):
   return sorted(us)[1]
 
 
+def traffic_provenance():
+  """Where `roofline.traffic` comes from: NOT measured by this run (PMC counters need rocprofv3 around the process) but read from the committed counter passes."""
+  try:
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic.json')))
+    c = d.get('collected', {})
+    return ('HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json; FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections of '
+            'the guide; collected %s at commit %s, profiles/tools/pmc_traffic.sh) -- not re-measured in this run' % (c.get('date', 'in round 5'), c.get('commit', '33f5ca1')))
+  except (OSError, ValueError):
+    return None
+
+
 def roofline_block(bytes_per_launch, us, kernel, traffic_key=None, note=None):
   achieved = bytes_per_launch / (us * 1e-6) / 1e9
   r = {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
        'traffic': measured_traffic(traffic_key) if traffic_key else None, 'kernel': kernel, 'kernel_avg_ms': us * 1e-3,
        'algorithmic_bytes_per_launch': bytes_per_launch}
+  if r['traffic'] is not None: r['traffic_source'] = traffic_provenance()
   if note: r['note'] = note
   return r
 
@@ -636,6 +676,9 @@ def train_iteration_sdf_grad(device, batches=(B_PER_GPU, 32), reps=100):
     if B == B_PER_GPU:      # the same per-sample grids stored as 4 x 4 tiles (API extension; the gradient: a sparse tensor of the tiled tensor's shape)
       from dgpmp2_amd.utils.sdf_utils import tile_sdf
       grids['per_sample_tiled'] = tile_sdf(grids['per_sample'].detach()).requires_grad_(True)
+    # the layer's DEFAULT gradient layout for per-sample grids since round 6 is the reference's dense (B,1,H,W) tensor; the rows above opt into sdf_grad = 'auto'
+    # (sparse taps for large leaf grids).  One row with the default, so that the price of the reference layout stays visible (1 GiB zero fill at B = 4096)
+    grids['per_sample_dense_default'] = grids['per_sample']
 
     def iteration(sdf_in, with_sdf):
       sdfb = sdf_in if sdf_in.shape[0] == B else sdf_in.expand(B, 1, GRID, GRID)
@@ -668,6 +711,7 @@ def train_iteration_sdf_grad(device, batches=(B_PER_GPU, 32), reps=100):
     blk = {}
     for name, leaf in grids.items():
       row = {}
+      pl.sdf_grad = 'dense' if name.endswith('_dense_default') else 'auto'
       for tag, with_sdf in (('no_sdf_grad', False), ('sdf_grad', True)):
         f = lambda leaf=leaf, with_sdf=with_sdf: iteration(leaf, with_sdf)
         out = f()
@@ -686,7 +730,8 @@ def train_iteration_sdf_grad(device, batches=(B_PER_GPU, 32), reps=100):
     res['B%d' % B] = blk
     del grids, planner
     torch.cuda.empty_cache()
-  res['note'] = ('planner.plan_layer.forward_with_errors + torch.autograd.grad of (dtheta, err_sg, err_gp, err_obs) w.r.t. (th, qc_inv, obscov_inv, eps[, sdf]); '
+  res['note'] = ("plan_layer.sdf_grad = 'auto' (opt-in: sparse tap gradients for large leaf grids) except in the *_dense_default rows (the layer's default, the reference's dense layout); "
+                 'planner.plan_layer.forward_with_errors + torch.autograd.grad of (dtheta, err_sg, err_gp, err_obs) w.r.t. (th, qc_inv, obscov_inv, eps[, sdf]); '
                  'per_sample: sdfb (B,1,256,256) leaf as learning/train_planner.py:267; shared: one (1,1,256,256) leaf expand()ed over the batch; wall us per iteration '
                  '(best of three batches of %d), eager and replayed from a HIP graph' % reps)
   return res
@@ -699,6 +744,8 @@ def main():
   ap.add_argument('--warmup', type=int, default=500)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-extras', action='store_true', help='skip the extra workload blocks (profiling runs)')
+  ap.add_argument('--strong', action='store_true', help='BASELINE configs[4] literally: ONE batch of 32768 trajectories split over the N ranks (strong scaling; N = 1: all of it '
+                                                        'on one GPU); the default is 4096 trajectories per rank (weak scaling, the metric BASELINE.json quotes)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -734,6 +781,10 @@ def main():
   from dgpmp2_amd.gpmp2.plan_layer import solver_config
 
   B, n, d = B_PER_GPU, N_STATES, 2 * DOF
+  if args.strong:
+    # configs[4]: the 32768 trajectories of the node as contiguous shards (dgpmp2_amd.parallel.shard_range: the first B mod N ranks hold one more)
+    lo, hi = parallel.shard_range(STRONG_TOTAL, rank, world)
+    B = hi - lo
   th0, start, goal, sdf = make_inputs(B, n, GRID, device, seed=rank)
   cfg = solver_config(num_states=n, dof=DOF, io_dtype=torch.float32)
   solver = _capi.Solver(cfg)
@@ -765,11 +816,14 @@ def main():
 
   prewarm_s = prewarm(step)
   gather_out = None
+  total_B = STRONG_TOTAL if args.strong else world * B
+  # whole-batch steps per region launch: weak scaling -- every rank steps its own 4096-trajectory batch, the batches add up; strong -- ONE 32768-trajectory batch per step
+  batches_per_launch = 1 if args.strong else world
   if dist is not None:
     # untimed: the first call of a collective sets up RCCL's channels / loads its kernels (milliseconds); the 4 MB x world output buffer is
     # allocated ONCE here and handed to the product's helper as `out=` (a GN loop that gathers every outer iteration does the same)
-    gather_out = parallel.gather_buffer(th_hist[-1], world * B)
-    for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)
+    gather_out = parallel.gather_buffer(th_hist[-1], total_B)
+    for _ in range(2): parallel.all_gather_trajectories(th_hist[-1], total_B, out=gather_out)
     torch.cuda.synchronize()
   for k in range(args.warmup): step(k)
   torch.cuda.synchronize()
@@ -797,7 +851,7 @@ def main():
     if ev: ev[0].record()
     for k in range(K if steps is None else steps): step(k)
     if dist is not None and gather:      # collect the final trajectories -- the only collective of the path -- through the product's helper; it is stream-ordered
-      gathered = parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)      # behind the K launches and cannot complete before every rank has contributed
+      gathered = parallel.all_gather_trajectories(th_hist[-1], total_B, out=gather_out)      # behind the K launches and cannot complete before every rank has contributed
     if ev: ev[1].record()
     while not cur_stream.query(): pass              # spin until the stream has drained: synchronize() then returns at once, not after an interrupt wake-up
     torch.cuda.synchronize()
@@ -811,7 +865,7 @@ def main():
   for e in evs: region(e)
   spans_ms = np.asarray([a_.elapsed_time(b_) for a_, b_ in evs])
   if dist is not None:
-    assert tuple(gathered.shape) == (world * B, n, d)
+    assert tuple(gathered.shape) == (total_B, n, d)
     t = torch.tensor(walls, dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)        # every region: the slowest rank's clock
     walls = t.cpu().numpy()
@@ -850,7 +904,7 @@ def main():
     ts = []
     for _ in range(20):
       torch.cuda.synchronize(); t0 = time.perf_counter()
-      parallel.all_gather_trajectories(th_hist[-1], world * B, out=gather_out)
+      parallel.all_gather_trajectories(th_hist[-1], total_B, out=gather_out)
       torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     region_fixed_us = float(np.median(ts)) * 1e6
 
@@ -870,17 +924,23 @@ def main():
     kname = 'gn_kernel<%d,%d,%d,float,0,%d>' % (DOF, lpt, cc, solver.step_kernel_variant(B))      # <dof, LPT, C, io, MODE_STEP, QK: 1 block elimination, 3 Woodbury>
     ks = kernel_stats().get(kname)
     out = {
-        'metric': 'Gauss-Newton steps/sec (whole node), batch=4096 x 64 states, 2D point robot',
-        'value': world * args.steps / elapsed, 'unit': 'GN steps/s (one step = one whole-batch step of 4096 trajectories; per-GPU batches add up)',
+        'metric': ('Gauss-Newton steps/sec (whole node), batch=32768 x 64 states sharded over the GPUs, 2D point robot (BASELINE configs[4])' if args.strong
+                   else 'Gauss-Newton steps/sec (whole node), batch=4096 x 64 states, 2D point robot'),
+        'value': batches_per_launch * args.steps / elapsed,
+        'unit': ('GN steps/s (one step = one step of the whole 32768-trajectory batch, every rank stepping its shard)' if args.strong
+                 else 'GN steps/s (one step = one whole-batch step of 4096 trajectories; per-GPU batches add up)'),
+        'value_first_region': batches_per_launch * args.steps / float(walls[0]),
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'prewarm_s': prewarm_s, 'ms_per_step': 1e3 * elapsed / args.steps,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[1]: 2D point robot, batch=4096 per GPU, 64 states, 256x256 shared SDF, '
-                               'static covariances, inputs = trajectories after (k mod 10) GN iterations; C-ABI dgp_gn_step launch rate '
+        'higher_is_better': True, 'scaling': 'strong' if args.strong else 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': ('BASELINE configs[4]: 2D point robot, ONE batch of 32768 trajectories split into contiguous shards over %d rank(s), ' % world if args.strong
+                                else 'BASELINE configs[1]: 2D point robot, batch=4096 per GPU, ') +
+                               '64 states, 256x256 shared SDF, static covariances, inputs = trajectories after (k mod 10) GN iterations; C-ABI dgp_gn_step launch rate '
                                '(err, err_ext and the SPD info flags written every step, as PlanLayer.forward does)',
-                   'batch_per_gpu': B, 'num_states': n, 'state_dim': d, 'sdf': [GRID, GRID], 'io_dtype': 'f32',
+                   'batch_per_gpu': B, 'batch_total': total_B, 'num_states': n, 'state_dim': d, 'sdf': [GRID, GRID], 'io_dtype': 'f32',
                    'parallelism': 'trajectory batch sharded, %d rank(s)' % world},
+        'build': __graft_entry__.build_provenance(),
         'rccl_ranks': world if dist is not None else 0,
-        'trajectory_steps_per_s': world * args.steps * B / elapsed,
+        'trajectory_steps_per_s': args.steps * total_B / elapsed,
         'regions': regions,
         'kernel_events': {'launches': int(kdur.size), 'mean_ms': float(kdur.mean()), 'median_ms': float(np.median(kdur)),
                           'note': 'per-launch begin/end events (dgp_time_next_launch), a separate pass after the timed regions'},
@@ -895,8 +955,8 @@ def main():
     out['roofline']['kernel_isolated_avg_ms'] = kernel_ms                # per-launch begin / end events, launches dispatched one by one
     out['roofline']['region_span_ms_per_launch'] = region_span_ms      # events around one K-launch region / K (median region): start-up and gaps included
     if steps_only is not None:
-      out['value_steps_only'] = world * args.steps / steps_only      # the same K-launch regions without the all-gather (median, max over ranks)
-      out['steps_per_s_at_5000'] = world * 5000 / long_region         # one region of 5000 launches + the all-gather: the fixed cost amortised
+      out['value_steps_only'] = batches_per_launch * args.steps / steps_only      # the same K-launch regions without the all-gather (median, max over ranks)
+      out['steps_per_s_at_5000'] = batches_per_launch * 5000 / long_region         # one region of 5000 launches + the all-gather: the fixed cost amortised
       out['scaling_note'] = ('value = K / median region INCLUDING one all-gather of the final trajectories and the wait for it (region_fixed_us, a constant); '
                              'value_steps_only = the same regions without it; steps_per_s_at_5000 = one 5000-launch region with it -- at --steps 20 the constant is '
                              '~20 %% of a region, so per-N efficiency is better read from the last two')
@@ -914,17 +974,17 @@ def main():
     out['fused_forward'] = {'gn_iterations_per_launch': GN_ITERS, 'ms_per_launch': fused_us * 1e-3, 'us_per_gn_iteration': fused_us / GN_ITERS,
                             'gn_steps_per_s_per_gpu': GN_ITERS / (fused_us * 1e-6),
                             'note': 'dgp_gn_solve: the 10 GN iterations of BASELINE configs[1] in one launch (rank 0, outside the timed region)'}
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not args.strong:
       out['two_streams'] = two_stream_rate(solver, B, th_ptrs, sp, gp, sdf_arg, device)
       out.update(extra_workloads(device, stream))
       out['sdf_fields'] = sdf_fields_rate(device)
       out['planner_step_api'] = planner_api_rate(device)
       out['planner_step_backward_api'] = planner_api_backward_rate(device)
       out['train_iteration_sdf_grad'] = train_iteration_sdf_grad(device)
-    if world == 1 and not args.no_cpu_baseline:
-      hist_cpu = [t.cpu() for t in th_hist]
-      out['cpu_baseline'] = cpu_baseline(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())
-      out['cpu_baseline_blocktri'] = cpu_blocktri(hist_cpu, start.cpu(), goal.cpu(), sdf.cpu())
+    if world == 1 and not args.no_cpu_baseline:      # (strong mode: the CPU baseline stays the 4096-trajectory batch-step the metric is quoted on)
+      hist_cpu = [t[:B_PER_GPU].cpu() for t in th_hist]
+      out['cpu_baseline'] = cpu_baseline(hist_cpu, start[:B_PER_GPU].cpu(), goal[:B_PER_GPU].cpu(), sdf.cpu())
+      out['cpu_baseline_blocktri'] = cpu_blocktri(hist_cpu, start[:B_PER_GPU].cpu(), goal[:B_PER_GPU].cpu(), sdf.cpu())
     print(json.dumps(out))
   if dist is not None:
     dist.barrier()

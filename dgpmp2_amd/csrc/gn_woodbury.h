@@ -153,11 +153,21 @@ template <bool RAGGED, typename Ctx>
 DGP_HD void wb_stage_issue(const GnParams& p, Ctx& cx, WbStaged& w) {
   typedef double V2 __attribute__((vector_size(16)));
   static_assert(WB_TYPES * WB_TYPE_DOUBLES / 2 == 144 && WB_T_STD == 0 && WB_T_FIRST == 1, "cell-to-lane assignment");
-  const V2* src = (const V2*)cx.wb_source(p);
   const int lane = cx.lane();
+#if defined(__HIP_DEVICE_COMPILE__)
+  const V2* src = (const V2*)cx.wb_source(p);      // (the kernel-argument segment is 64-byte aligned and wb_tab starts on a multiple of 16)
   w.c0 = src[lane];
   if constexpr (RAGGED) { w.c1 = src[64 + lane]; w.c2 = src[128 + (lane & 15)]; }
   else w.c1 = src[64 + (lane & 7)];
+#else
+  // host (tests/emul): GnParams lives on a stack that is only 8-byte aligned -- a 16-byte ALIGNED vector load of its table is undefined there (found by the
+  // -ftrivial-auto-var-init=pattern build of the emulator, round 6: a general-protection fault once the stack layout shifted)
+  const double* src = cx.wb_source(p);
+  auto cell = [&](int c) { V2 v; __builtin_memcpy(&v, src + 2 * c, 16); return v; };
+  w.c0 = cell(lane);
+  if constexpr (RAGGED) { w.c1 = cell(64 + lane); w.c2 = cell(128 + (lane & 15)); }
+  else w.c1 = cell(64 + (lane & 7));
+#endif
 }
 template <bool RAGGED, typename Ctx>
 DGP_HD void wb_stage_commit(Ctx& cx, const WbStaged& w) {

@@ -4,6 +4,7 @@ corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes: gfx950 FETCH_SIZ
 widths uncalibrated), then launches of dgp_gn_step on ONE workload:
    gn_step (BASELINE configs[1], shared SDF) | per_sample_sdf (one 256x256 grid per trajectory; 6 grid sets cycled so that the
    touched lines do not fit the 256 MiB Infinity Cache) | per_sample_sdf_tiled (the same as 4 x 4 tiles) | learned_covariances (per-state tensors) | config4_xyh (d = 6, 512x512)
+   | config4_perstate (d = 6 with per-state covariance tensors: the learned mode)
 usage: python profiles/tools/pmc_probe.py [workload]"""
 import ctypes, os, subprocess, sys
 import torch
@@ -41,7 +42,7 @@ del big
 
 B, n = B_PER_GPU, N_STATES
 dof, G, kw, covs, keep = 2, GRID, {}, None, []
-if workload == 'config4_xyh':
+if workload in ('config4_xyh', 'config4_perstate', 'config4_auto_tile'):      # config4_perstate (round 6): the d = 6 learned mode, per-state Q_c^-1 tensors (the Kronecker kernels)
   dof, G, kw = 3, 512, dict(non_holonomic=True, K_d=0.01, epsilon_dist=0.2, reg=0.0)
 th0, start, goal, sdf = make_inputs(B, n, G, dev, dof=dof)
 s = _capi.Solver(solver_config(n, dof, torch.float32, **kw))
@@ -53,8 +54,8 @@ if workload == 'per_sample_sdf_tiled':      # the same six grid sets stored as 4
   from dgpmp2_amd.utils.sdf_utils import tile_sdf
   grids = [tile_sdf(make_per_sample_sdfs(B, G, dev, seed=1 + i)) for i in range(6)]
   sas = [s.sdf_arg(t.data_ptr(), G, G, G * G, layout=_capi.DGP_SDF_TILED4) for t in grids]
-if workload == 'learned_covariances':
-  qc = torch.eye(dof, device=dev).expand(B, n - 1, dof, dof).contiguous(); ow = torch.full((B, n), 1e4, device=dev); ep = torch.full((B, n), 0.4, device=dev)
+if workload in ('learned_covariances', 'config4_perstate'):
+  qc = torch.eye(dof, device=dev).expand(B, n - 1, dof, dof).contiguous(); ow = torch.full((B, n), 1e4, device=dev); ep = torch.full((B, n), 0.2 if dof == 3 else 0.4, device=dev)
   keep = [qc, ow, ep]
   covs = s.covs_arg(_capi.DGP_QC_PERSTATE, qc.data_ptr(), ow.data_ptr(), ep.data_ptr())
 dth = torch.empty_like(th0); err = torch.empty(B, device=dev); eex = torch.empty(B, device=dev); info = torch.zeros(B, dtype=torch.int32, device=dev)

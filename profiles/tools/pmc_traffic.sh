@@ -12,9 +12,10 @@ for W in ${PMC_WORKLOADS:-gn_step per_sample_sdf per_sample_sdf_tiled learned_co
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT" -o fetch -- $P > "$OUT/fetch.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT" -o write -- $P > "$OUT/write.log" 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum -d "$OUT" -o l2 -- $P > "$OUT/l2.log" 2>&1
-  if [ "$W" = gn_step ]; then
+  if [ "$W" = gn_step ] || [ "$W" = config4_xyh ] || [ "$W" = config4_perstate ]; then      # the SQ issue / wait counters: the headline kernel and (round 6) the d = 6 family
     timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR -d "$OUT" -o sq1 -- $P > "$OUT/sq1.log" 2>&1
     timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM -d "$OUT" -o sq2 -- $P > "$OUT/sq2.log" 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VMEM -d "$OUT" -o sq3 -- $P > "$OUT/sq3.log" 2>&1
   fi
   ls "$OUT" | head -20
 done
