@@ -292,12 +292,14 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
           return hipGetLastError();                                                                                        \
         }                                                                                                                  \
       }                                                                                                                    \
-      if constexpr (DGP_STEP_ERRS == 1 && DOF == 3 && !DGP_ALLOW_ALL_TWINS) return hipErrorInvalidValue;      /* (host-checked: dgp_host::gn_step_errors -- a miscompiled twin) */ \
+      /* (round 6: the d = 6 block-elimination twin is back -- its wrong results were the exec-join miscompile the build now repairs, profiles/r06_compiler_fault.md; */ \
+      /*  -DDGP_EXCLUDE_REPAIRED_TWINS=1 restores the round-5 exclusions of the two twins for the reproducer builds) */ \
+      if constexpr (DGP_STEP_ERRS == 1 && DOF == 3 && DGP_EXCLUDE_REPAIRED_TWINS) return hipErrorInvalidValue; \
       else if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));            \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
-      /* (host-checked: the d = 6 general twins are not built; hipcc 7.0 miscompiled the twin <2,32,4,float,STEP,general> -- dtheta off by 1e-2 .. 0.3) */ \
-      if constexpr (DGP_STEP_ERRS == 1 && (DOF == 3 || (L == 32 && sizeof(IO) == 4 && !DGP_ALLOW_ALL_TWINS))) return hipErrorInvalidValue;      \
+      /* (host-checked: the d = 6 general twins are not built) */ \
+      if constexpr (DGP_STEP_ERRS == 1 && (DOF == 3 || (L == 32 && sizeof(IO) == 4 && DGP_EXCLUDE_REPAIRED_TWINS))) return hipErrorInvalidValue;      \
       else if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));           \
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));  \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                \

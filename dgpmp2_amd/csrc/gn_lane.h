@@ -490,9 +490,13 @@ DGP_HD int32_t imax32(int32_t a, int32_t b) { return a > b ? a : b; }
 #ifndef DGP_STEP_ERRS
 #define DGP_STEP_ERRS 0
 #endif
-// Reproducer builds only (profiles/tools/r06_twin_repro.sh): 1 lifts the host-side exclusion of the step-errors twins that came out wrong on the GPU
-#ifndef DGP_ALLOW_ALL_TWINS
-#define DGP_ALLOW_ALL_TWINS 0
+// Reproducer builds only (profiles/tools/r06_twin_repro.sh): DGP_TWIN_REPRO 1 = the run-time switch DGP_TWIN_NO_ERRS of dgp_host::gn_step_errors;
+// DGP_EXCLUDE_REPAIRED_TWINS 1 = the round-5 host-side exclusion of the two step-errors twins that came out wrong before the build repaired its assembly
+#ifndef DGP_TWIN_REPRO
+#define DGP_TWIN_REPRO 0
+#endif
+#ifndef DGP_EXCLUDE_REPAIRED_TWINS
+#define DGP_EXCLUDE_REPAIRED_TWINS 0
 #endif
 DGP_HD bool grid_is_tiled(const GnParams& p) { return DGP_TL == 1 ? true : (DGP_TL == 2 ? p.sdf_layout != 0 : false); }
 // Elements of one grid: row-major H x W, or ceil(H / 4) x ceil(W / 4) tiles of 16 -- tile (y / 4, x / 4), row (y % 4), column (x % 4) inside it: the 2 x 2 footprint

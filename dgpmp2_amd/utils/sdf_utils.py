@@ -41,7 +41,8 @@ def _tiled_cls():
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
-      out = super().__torch_function__(func, types, args, kwargs or {})
+      with torch._C.DisableTorchFunctionSubclass():      # (not torch.Tensor.__torch_function__: its blanket as_subclass() of every result fails on the sparse
+        out = func(*args, **(kwargs or {}))              #  gradients autograd.grad returns for a tiled leaf)
       hw = None
       stack = list(args) + list((kwargs or {}).values())
       while stack and hw is None:                 # the first tiled operand (also inside the list argument of cat / stack)
@@ -51,6 +52,7 @@ def _tiled_cls():
 
       def tag(o):
         if not isinstance(o, torch.Tensor): return o
+        if o.layout is not torch.strided: return o      # a sparse gradient of a tiled grid: a plain sparse tensor of the tiled shape
         ok = hw is not None and o.dim() >= 4 and tuple(o.shape[-2:]) == (4, 4) and (hw[0] + 3) // 4 == o.shape[-4] and (hw[1] + 3) // 4 == o.shape[-3]
         if ok:
           if not isinstance(o, TiledSdf): o = o.as_subclass(TiledSdf)

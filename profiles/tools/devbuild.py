@@ -28,6 +28,7 @@ def main():
   ap.add_argument('--flag', action='append', default=[], help='extra hipcc argument, e.g. --flag=-mllvm --flag=-amdgpu-spill-sgpr-to-vgpr=false')
   ap.add_argument('-o', default='libdgpmp2_dev.so')
   ap.add_argument('--show', default=',16,4,')
+  ap.add_argument('--raw', action='store_true', help='plain hipcc -c: no repair of the device assembly')
   a = ap.parse_args()
   for u in a.units: assert u in ALL, (u, ALL)
   work = os.path.join('/tmp', 'dgp_dev_' + a.o.replace('.', '_'))
@@ -54,9 +55,20 @@ def main():
         f.write('hipError_t dgp_launch_%s(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t) { return hipErrorInvalidValue; }\n' % u)
   d = os.path.join(work, 'stubs'); os.makedirs(d)
   jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', stub, '-o', os.path.join(d, 'stubs.o')])
-  procs = [subprocess.Popen(j) for j in jobs]
-  rcs = [p.wait() for p in procs]
+  # every unit through the product's own compile pipeline (__graft_entry__.compile_hip_unit: device assembly, the exec-join repair, assembler, bundler, host object);
+  # --raw: plain hipcc -c -save-temps (the unrepaired compiler output, for the reproducer builds of profiles/r06_compiler_fault.md)
+  sys.path.insert(0, ROOT)
+  import __graft_entry__ as G
+  from concurrent.futures import ThreadPoolExecutor
+  def one(j):
+    if a.raw or j[-3].endswith('stubs.hip'): return subprocess.call(j), None
+    flags = [x for x in j[1:-3] if x not in ('--offload-arch=gfx950', '-c', '-save-temps=obj')]
+    return 0, G.compile_hip_unit(hipcc, flags, j[-3], j[-1])
+  with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex: res = list(ex.map(one, jobs))
+  rcs = [r[0] for r in res]
   if any(rcs): raise SystemExit('hipcc failed: %s' % rcs)
+  for j, r in zip(jobs, res):
+    if r[1] and (r[1][0] or r[1][1]): print('%-28s exec-join repair: %d instruction(s) moved, %d finding(s) left' % (os.path.basename(j[-1]), r[1][0], r[1][1]))
   out = os.path.join(ROOT, 'dgpmp2_amd', 'lib', a.o)
   subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[-1] for j in jobs] + ['-o', out])
   stats = {}

@@ -20,23 +20,35 @@ VEC = re.compile(r'^\s+(v_accvgpr_write_b32|scratch_store_|buffer_store_dword.*o
                  r'|v_accvgpr_read_b32|scratch_load_)')
 IGNORES_EXEC = re.compile(r'^\s+(v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)')
 OTHER_EXEC = re.compile(r'exec')      # any other instruction that names exec (s_and_saveexec, s_mov exec, s_andn2 ... exec): the region in front of it is not a join prologue
+ENTERS_BODY = re.compile(r'^\s+(s_cbranch_execz|s_cbranch_execnz|s_and_saveexec_b64|s_andn2_saveexec_b64|s_mov_b64 exec,|s_and_b64 exec,|s_andn2_b64 exec,)')
 BRANCH = re.compile(r'^\s+(s_cbranch|s_branch|s_endpgm|s_setpc)')
 
 
 def check(path):
   out = []
-  kernel, label, pending = None, None, []
-  for ln, line in enumerate(open(path), 1):
+  kernel, label, pending, prev = None, None, [], ''
+  text = open(path).read()
+  # out-of-line bodies: `s_cbranch_execnz .LBBx` jumps INTO the body of the `if` (lanes left), the fall-through is the join
+  bodies = set(re.findall(r's_cbranch_execnz (\.LBB\d+_\d+)', text))
+  for ln, line in enumerate(text.split('\n'), 1):
     m = KERNEL.match(line)
-    if m: kernel, label, pending = m.group(1), None, []; continue
+    if m: kernel, label, pending, prev = m.group(1), None, [], ''; continue
     m = LABEL.match(line)
-    if m: label, pending = (m.group(1) or m.group(2)), []; continue
-    if label is None: continue
+    if m:
+      # a block that FOLLOWS the instruction that narrowed exec (or the branch that skips the body when no lane is left) is the BODY of the `if`: it runs under the
+      # narrowed mask by design, and a tail-duplicated copy of the restore may end it -- spill code inside it serves the body's own lanes.  Only a block reached
+      # from the body (fall-through) or from the skip branch is a join.
+      body = bool(ENTERS_BODY.match(prev)) or (m.group(1) in bodies)
+      label, pending = (None if body else (m.group(1) or m.group(2))), []
+      continue
+    if line.lstrip().startswith(';') or not line.strip(): continue
+    this = line
+    if label is None: prev = this; continue
     if RESTORE.match(line):
       for l2, t in pending: out.append((kernel, label, l2, t.strip(), line.strip()))
-      label, pending = None, []
+      label, pending, prev = None, [], this
       continue
-    if line.lstrip().startswith(';'): continue
+    prev = this
     if BRANCH.match(line) or OTHER_EXEC.search(line):
       label, pending = None, []      # another exec write / the block ends: whatever was collected ran under a mask that belongs to it
       continue
@@ -44,11 +56,80 @@ def check(path):
   return out
 
 
+SLOT_W = re.compile(r'^\s+(?:v_accvgpr_write_b32 (a\d+),|scratch_store_\w+ off, v\S+, off(?: offset:(\d+))?)')
+SLOT_R = re.compile(r'^\s+(?:v_accvgpr_read_b32 v\d+, (a\d+)\s*$|scratch_load_\w+ v\S+, off, off(?: offset:(\d+))?)')
+
+
+def _regs(tok):
+  """'v12' / 'v[12:15]' -> set of VGPR numbers"""
+  m = re.match(r'v\[(\d+):(\d+)\]', tok)
+  if m: return set(range(int(m.group(1)), int(m.group(2)) + 1))
+  m = re.match(r'v(\d+)$', tok)
+  return {int(m.group(1))} if m else set()
+
+
+def _reload_kind(lines, i, inst):
+  """A reload in front of the exec restore fills its register for the branch's lanes only.  'reload-live': the first thing that happens to the register BEHIND the
+  restore (same block) is a read -- the other lanes consume a register nobody filled for them: the mirror image of the `store` signature;
+  'reload': overwritten first, or not touched again before the block ends (the value served the branch's lanes in front of the restore)."""
+  m = re.match(r'\s*(?:v_accvgpr_read_b32|scratch_load_\w+) (v\d+|v\[\d+:\d+\])', inst)
+  if not m: return 'reload'
+  mine = _regs(m.group(1))
+  j = i + 1
+  while j < len(lines) and not RESTORE.match(lines[j]): j += 1
+  # were the registers consumed in front of the restore already?  then the reload served the branch
+  for k in range(i + 1, j):
+    ops = re.findall(r'v\[\d+:\d+\]|v\d+', lines[k].split(';')[0])
+    if len(ops) > 1 and any(_regs(o) & mine for o in ops[1:]): return 'reload'
+  j += 1
+  while j < len(lines):
+    l = lines[j].split(';')[0]
+    if LABEL.match(lines[j]) or BRANCH.match(l) or KERNEL.match(lines[j]): return 'reload'
+    ops = re.findall(r'v\[\d+:\d+\]|v\d+', l)
+    if ops and l.strip() and not l.lstrip().startswith(('s_', '.')):
+      stores = l.lstrip().startswith(('global_store', 'scratch_store', 'buffer_store', 'flat_store', 'ds_write', 'ds_store'))
+      srcs = ops if stores else ops[1:]
+      if any(_regs(o) & mine for o in srcs): return 'reload-live'
+      if not stores and (_regs(ops[0]) & mine):
+        mine -= _regs(ops[0])
+        if not mine: return 'reload'
+    j += 1
+  return 'reload'
+
+
+def classify(path, findings=None):
+  """-> [(kernel, label, line, instruction, restore, kind)], kind:
+       'store'   spill store at a join top whose slot holds NOTHING else for the other lanes: no write of the slot since its last read -- the miscompile (every lane
+                 reads the slot later, only the branch's lanes wrote it);
+       'merge'   spill store at a join top behind an earlier, not yet consumed write of the same slot (the two writes may complement each other: the slot of a
+                 value defined on both paths): reported, not counted;
+       'reload'  reload in front of the restore: wrong only if the register is read by other lanes afterwards -- reported, not counted (the every-kernel GPU tests cover them)."""
+  findings = check(path) if findings is None else findings
+  if not findings: return []
+  lines = open(path).read().split('\n')
+  out = []
+  for kernel, label, ln, inst, rest in findings:
+    mw = SLOT_W.match('\t' + inst)
+    if not mw:
+      out.append((kernel, label, ln, inst, rest, _reload_kind(lines, ln - 1, inst))); continue
+    slot = mw.group(1) or ('scratch+%s' % (mw.group(2) or '0'))
+    kind = 'store'
+    i = ln - 2
+    while i >= 0 and not KERNEL.match(lines[i]):
+      l = lines[i]
+      w, r = SLOT_W.match(l), SLOT_R.match(l)
+      if r and (r.group(1) or ('scratch+%s' % (r.group(2) or '0'))) == slot: break           # consumed: whatever was written before is dead
+      if w and (w.group(1) or ('scratch+%s' % (w.group(2) or '0'))) == slot: kind = 'merge'; break
+      i -= 1
+    out.append((kernel, label, ln, inst, rest, kind))
+  return out
+
+
 if __name__ == '__main__':
   bad = 0
   for f in sys.argv[1:]:
-    for kernel, label, ln, inst, rest in check(f):
-      bad += 1
-      print('%s:%d  %s  %s:  `%s`  in front of  `%s`' % (f, ln, kernel, label, inst, rest))
-  print('%d finding(s)' % bad)
+    for kernel, label, ln, inst, rest, kind in classify(f):
+      bad += kind == 'store'
+      print('%-6s %s:%d  %s  %s:  `%s`  in front of  `%s`' % (kind, f, ln, kernel, label, inst, rest))
+  print('%d finding(s) of the miscompile signature' % bad)
   sys.exit(1 if bad else 0)

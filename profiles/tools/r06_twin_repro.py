@@ -2,7 +2,7 @@
 
   DGP_LIB_PATH=dgpmp2_amd/lib/libdgpmp2_dev_<variant>.so python profiles/tools/r06_twin_repro.py [d6static|d4general] [repeats]
 
-The library must be a devbuild with -DDGP_ALLOW_ALL_TWINS=1 (profiles/tools/r06_twin_repro.sh builds the variants: optimisation levels, -mllvm switches).
+The library must be a devbuild with -DDGP_TWIN_REPRO=1, --raw: the unrepaired compiler output (profiles/tools/r06_twin_repro.sh builds the variants: optimisation levels, -mllvm switches).
 For the case it runs dgp_gn_step_errors (ONE launch: the twin kernel with the errors epilogue) against dgp_gn_step (the standard kernel, pinned to the C oracle by
 tests/test_hip_every_kernel.py) and the C oracle itself, `repeats` times on the same inputs, and prints one line per (length, repeat):
   rel. error of the twin's dtheta vs the standard kernel, vs the oracle, and whether two runs of the twin agree bit for bit (determinism).

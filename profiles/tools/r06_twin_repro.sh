@@ -21,7 +21,7 @@ if [ "$1" = build ]; then
   shift
   names=${@:-O3 O2 O1 noalias nocontract noaa nodpp waitzero nosgpr2vgpr noagpr nomachsched nopostra}
   for v in $names; do
-    ( python profiles/tools/devbuild.py $UNITS -D DGP_ALLOW_ALL_TWINS=1 ${V[$v]} -o libdgpmp2_dev_$v.so --show ',16,4,float,0,1' > /tmp/r06_build_$v.log 2>&1; echo "built $v rc $?" ) &
+    ( python profiles/tools/devbuild.py $UNITS -D DGP_TWIN_REPRO=1 --raw ${V[$v]} -o libdgpmp2_dev_$v.so --show ',16,4,float,0,1' > /tmp/r06_build_$v.log 2>&1; echo "built $v rc $?" ) &
     while [ $(jobs -r | wc -l) -ge 1 ]; do sleep 2; done
   done
   wait
