@@ -965,3 +965,119 @@ def test_planner_api_long_trajectory():
   (gth,) = torch.autograd.grad(d2, thr, T(gbar))
   g_o = AT.step_gradients(p, th, start, goal, sdf_np, gbar, np.zeros(B))
   assert rel_err(gth.cpu().numpy(), g_o['th']) < 1e-6
+
+
+def test_auto_tile_gives_the_rowmajor_results_in_rowmajor_shapes(golden):
+  """plan_layer.auto_tile (round 6): a per-sample ROW-MAJOR sdfb -- what an unmodified reference caller passes -- is tiled once per batch of grids and every launch reads
+  the tiles; results, dense and sparse gradients come back as for the row-major path, in sdfb's own shape; the tiling pass runs once per (tensor, version)."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  pl = planner.plan_layer
+  rs = np.random.RandomState(11)
+  base = O.circles_sdf(G, g['circles'])
+  sdf = T(np.stack([base + 0.03 * rs.randn(G, G) for _ in range(B)])[:, None])
+  start, goal, th = T(g['start']), T(g['goal']), T(g['th_hist'][2])
+  gd = T(rs.randn(B, n, 4))
+  close = lambda a_, b_, tol=1e-11: rel_err(a_.detach().cpu().numpy(), b_.detach().cpu().numpy()) < tol
+
+  def run(leaf):
+    thr = th.clone().requires_grad_(True)
+    out, (sg, gp, ob) = planner.step_with_errors(thr, start, goal, None, leaf)
+    ((out[0] * gd).sum() + ob.sum() + out[3].sum()).backward()
+    return out[0].detach(), out[2], ob.detach(), thr.grad, leaf.grad
+
+  ref = run(sdf.clone().requires_grad_(True))
+  pl.auto_tile = True
+  leaf = sdf.clone().requires_grad_(True)
+  got = run(leaf)
+  tiles = pl._tile_cache[5]
+  assert close(ref[0], got[0]) and close(ref[1], got[1]) and close(ref[2], got[2]) and close(ref[3], got[3], 1e-9)
+  assert got[4].shape == sdf.shape and not got[4].is_sparse and close(ref[4], got[4], 1e-9)
+  leaf.grad = None
+  run(leaf)
+  assert pl._tile_cache[5] is tiles                                  # the same batch of grids: no second tiling pass
+  pl.sdf_grad = 'sparse'
+  leaf2 = sdf.clone().requires_grad_(True)
+  got2 = run(leaf2)
+  assert leaf2.grad.is_sparse and leaf2.grad.shape == sdf.shape and close(ref[4], leaf2.grad.to_dense(), 1e-9)
+  pl.sdf_grad = 'dense'
+  # planning calls (no graph) and the fused loop read the tiles too
+  with torch.no_grad():
+    a = planner.step(th, start, goal, None, sdf)[0]
+  assert close(ref[0], a)
+  smooth = T(base)[None, None].repeat(B, 1, 1, 1)
+  f_t = planner.forward(th, start, goal, None, smooth)
+  pl.auto_tile = False
+  f_r = planner.forward(th, start, goal, None, smooth)
+  assert close(f_r[0], f_t[0], 1e-5) and f_r[6] == f_t[6]
+  # forward() returns python lists by default, as the reference does (ADVICE r5); the lazy views are an opt-in
+  assert all(type(x) is list for x in f_r[2:8]) and type(f_r[4][0]) is list and len(f_r[4]) == B
+  planner.lazy_results = True
+  f_l = planner.forward(th, start, goal, None, smooth)
+  assert type(f_l[2]) is not list and f_l[2] == f_r[2] and f_l[4] == f_r[4] and f_l[6] + [1] == f_r[6] + [1]
+
+
+def test_graphed_iteration_replays_the_eager_iteration(golden):
+  """planner.graphed_iteration(fn) (round 6): a training iteration written eagerly against the planner -- step_with_errors with learned per-state covariances, a loss,
+  autograd.grad -- is captured in a HIP graph at the first call and replayed afterwards: the results equal the eager call's bit for bit for every new set of inputs,
+  one capture serves all calls of a signature, a new batch shape captures again."""
+  g = golden('g3_c2mini')
+  B, n, G = 8, 64, int(g['G'])
+  planner = make_planner(n, B)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].expand(B, 1, G, G)
+  start, goal = T(g['start']), T(g['goal'])
+  gen = torch.Generator(device=DEV).manual_seed(5)
+  A = torch.randn(B, n - 1, 2, 2, device=DEV, dtype=torch.float64, generator=gen) * 0.2
+  qc = (torch.eye(2, device=DEV, dtype=torch.float64) + A @ A.transpose(-1, -2)).requires_grad_(True)
+  ow = (torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 1e4 + 50).requires_grad_(True)
+  ep = (torch.rand(B, n, 1, 1, device=DEV, dtype=torch.float64, generator=gen) * 0.5 + 0.1).requires_grad_(True)
+
+  def iteration(th, th_opt, qc_, ow_, ep_):
+    dth, _, eex, sg, gp_, ob = planner.plan_layer.forward_with_errors(th, start, goal, None, sdf, qc_, ow_, ep_)
+    loss = ((dth - (th_opt - th)) ** 2).sum(-1).mean() + 1e-3 * (sg.mean() + gp_.mean() + ob.mean())
+    return (dth, loss) + torch.autograd.grad(loss, (qc_, ow_, ep_))
+
+  it = planner.graphed_iteration(iteration)
+  for k in (1, 3, 5):
+    th, th_opt = T(g['th_hist'][k]), T(g['th_hist'][9])
+    want = [t.clone() for t in iteration(th, th_opt, qc, ow, ep)]
+    got = it(th, th_opt, qc, ow, ep)
+    torch.cuda.synchronize()
+    for a, b in zip(got, want):
+      assert torch.equal(a, b)
+  assert it.captures == 1
+  with torch.no_grad(): ow.mul_(0.5)                                 # new values in a long-lived input: copied into the graph's static tensor
+  th, th_opt = T(g['th_hist'][2]), T(g['th_hist'][9])
+  want = [t.clone() for t in iteration(th, th_opt, qc, ow, ep)]
+  for a, b in zip(it(th, th_opt, qc, ow, ep), want): assert torch.equal(a, b)
+  assert it.captures == 1
+  # another batch size is another signature (the planner itself is batch-agnostic at this level)
+  it2 = planner.graphed_iteration(lambda th_: planner.step(th_, start[:4], goal[:4], None, sdf[:4])[0])
+  with torch.no_grad():
+    a4 = it2(T(g['th_hist'][1])[:4]).clone(); e4 = planner.step(T(g['th_hist'][1])[:4], start[:4], goal[:4], None, sdf[:4])[0]
+  assert torch.equal(a4, e4)
+
+
+def test_tiled_grid_size_travels_with_the_tensor_on_the_gpu(golden):
+  """a padded 130 x 130 field (33 x 33 tiles, like 132 x 132) keeps its logical size through .to(device) / .float() / indexing / clone -- the step on the
+  tiles equals the step on the row-major field; a plain tensor of the same tiles is refused."""
+  from dgpmp2_amd.utils.sdf_utils import tile_sdf
+  g = golden('g3_c2mini')
+  B, n = 8, 64
+  planner = make_planner(n, B)
+  rs = np.random.RandomState(2)
+  H = 130
+  yy, xx = np.meshgrid(np.linspace(5, -5, H), np.linspace(-5, 5, H), indexing='ij')
+  field = np.sqrt((xx - 0.5) ** 2 + (yy + 0.3) ** 2) - 1.1
+  cpu = torch.from_numpy(np.stack([field + 0.02 * rs.randn(H, H) for _ in range(B)])[:, None])
+  tiles = tile_sdf(cpu).to(DEV).clone()[0:B]
+  assert tiles.hw == (H, H) and tuple(tiles.shape) == (B, 1, 33, 33, 4, 4)
+  start, goal, th = T(g['start']), T(g['goal']), T(g['th_hist'][2])
+  with torch.no_grad():
+    d_t = planner.step(th, start, goal, None, tiles)[0]
+    d_r = planner.step(th, start, goal, None, cpu.to(DEV))[0]
+    d_f = planner.step(th.float(), start.float(), goal.float(), None, tiles.float())[0]
+  assert rel_err(d_t.cpu().numpy(), d_r.cpu().numpy()) < 1e-11 and rel_err(d_f.double().cpu().numpy(), d_r.cpu().numpy()) < 1e-4
+  with pytest.raises(ValueError, match='carries no logical grid size'):
+    planner.step(th, start, goal, None, tiles.as_subclass(torch.Tensor))
