@@ -604,6 +604,24 @@ def planner_api_backward_rate(device, reps=200):
   except Exception as e:      # noqa: BLE001  (measurement extra: a torch build without graph capture must not cost the bench line)
     print('bench: HIP-graph capture of the training iteration failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
     ga = gt1 = gk = gdi = gdl = None
+  # round 6: the SAME iteration called eagerly through planner.graphed_iteration -- a loop that hands in fresh (th, qc_inv, obscov_inv, eps) every call, as a training
+  # loop does: the helper copies them into the graph's static tensors and replays (utils/graph_utils.py); held against the hand-written replay figure above
+  helper_us = None
+  try:
+    def iteration_fn(th_, qc_, ow_, ep_):
+      dth, _, _, sg, gp_, ob = planner.plan_layer.forward_with_errors(th_, start, goal, None, sdfb, qc_, ow_, ep_)
+      return torch.autograd.grad((dth, sg, gp_, ob), (th_, qc_, ow_, ep_), (g, cws, cw, cw))
+    it = planner.graphed_iteration(iteration_fn)
+    fresh = [(thr.detach().clone().requires_grad_(True), qc.detach().clone().requires_grad_(True), ow.detach().clone().requires_grad_(True),
+              ep.detach().clone().requires_grad_(True)) for _ in range(2)]
+    kk = [0]
+
+    def through_helper():
+      kk[0] ^= 1
+      it(*fresh[kk[0]])
+    helper_us = wall(through_helper)
+  except Exception as e:      # noqa: BLE001
+    print('bench: graphed_iteration failed (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
   reps = max(20, reps // 10)
   c = wall(tbptt_fb) / 10.0
   fb = wall(forward_backward)
@@ -613,6 +631,7 @@ def planner_api_backward_rate(device, reps=200):
                                        'without Python, Function.apply or the autograd engine -- what is left is the kernels (results bit-identical to the eager calls, '
                                        'tests/test_planner_api.py)'},
           'train_iteration_api': {'two_calls_us': t2, 'step_with_errors_us': t1, 'step_with_errors_hip_graph_replay_us': gt1,
+                                  'step_with_errors_through_graphed_iteration_us': helper_us,      # eager-style calls with fresh inputs: 4 input copies + one replay
                                   'diag_identity_mode': {'step_with_errors_us': tdi, 'hip_graph_replay_us': gdi, 'layer_only_hip_graph_replay_us': gdl,
                                                          'raw_module_output_us': tdr, 'raw_module_output_hip_graph_replay_us': gdr,
                                                          'note': "the reference's default learned mode: get_covariances(out, 'diag_identity') -> one scalar per GP factor -> DGP_QC_SCALAR "

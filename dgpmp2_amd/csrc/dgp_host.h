@@ -374,7 +374,7 @@ inline int fill_solve_backward(const DgpHandle* h, int32_t batch, const void* st
   int rc = fill_call(h, batch, th_out, start, goal, sdf, nullptr, p);
   if (rc != DGP_OK) return rc;
   if (is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward is not implemented for num_states > 256 (chain the per-step backward instead)");
-  if (!dgp::use_static_kernels(p)) return fail(DGP_EUNSUPPORTED, "dgp_gn_solve_backward needs a diagonal static Q_c_inv");
+  // (static covariances by construction: fill_call without covs.  A diagonal Q_c_inv runs the static / Woodbury chain kernels, any other the general ones -- round 6)
   if (max_iters < 1) return fail(DGP_EINVAL, "max_iters must be >= 1, got %d", max_iters);
   clear_extensions(g);
   rc = fill_gsdf(h, sdf, g_sdf, g_sdf_batch_stride, g_sdf_copies, p, g);

@@ -16,17 +16,19 @@ int drop_events(int rc) {
   return rc;
 }
 
-// status of a launch: hipErrorNotSupported is this file's own code for "tiled grid beyond what the tiled translation units hold" (see launch())
+// status of a launch.  kTiledTooLong is this file's PRIVATE code for "tiled grid beyond what the tiled translation units hold" (see launch()): not a value the HIP
+// runtime returns, so a genuine hipErrorNotSupported of a launch is reported as what it is
+static const hipError_t kTiledTooLong = (hipError_t)0x7f5d0001;
 int hip_rc(hipError_t e, const char* what) {
   if (e == hipSuccess) return DGP_OK;
-  if (e == hipErrorNotSupported)
+  if (e == kTiledTooLong)
     return fail(DGP_EUNSUPPORTED, "%s: tiled grids (DGP_SDF_TILED4) are implemented for num_states <= %d (launch shapes (16,4) and (32,4))", what, dgp_host::kMaxStatesTiled);
   return fail(DGP_EHIP, "%s launch failed: %s", what, hipGetErrorString(e));
 }
 
 hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dgp::GnGradParams* g, hipStream_t s) {
   const bool tiled = p.sdf_layout != 0 && p.sdf != nullptr;
-  if (tiled && p.n > dgp_host::kMaxStatesTiled) return hipErrorNotSupported;
+  if (tiled && p.n > dgp_host::kMaxStatesTiled) return kTiledTooLong;
   if (mode == dgp_host::kModeStepErrs) {          // dgp_gn_step_errors as ONE launch: the step kernels with the errors epilogue (gn_inst.hip with -DDGP_STEP_ERRS=1; host-checked: available)
     static const DgpLaunchFn etab[2][2][3] = {{{dgp_launch_2e_f32_g0, dgp_launch_2e_f32_g3, dgp_launch_2e_f32_g1}, {dgp_launch_2e_f64_g0, dgp_launch_2e_f64_g3, dgp_launch_2e_f64_g1}},
                                              {{dgp_launch_3e_f32_g0, dgp_launch_3e_f32_g3, nullptr}, {dgp_launch_3e_f64_g0, dgp_launch_3e_f64_g3, nullptr}}};

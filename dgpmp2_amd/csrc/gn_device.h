@@ -24,6 +24,11 @@ struct DevCtx {
   // errors' prologue hands its trajectory gradient to the main program).  WORKGROUP scope (the fences inside __syncthreads; the workgroup is this one wavefront,
   // its CU's vector L1 is write-through and shared by the whole workgroup): an agent-scope fence (__threadfence) writes back / invalidates the XCD's L2 on gfx950 --
   // a thousand wavefronts doing that cost the single-launch training-iteration backward 20 us (measured: 57 instead of 36 us) for nothing.
+  // What this relies on, spelled out: __syncthreads() IS fence(release, workgroup) + s_barrier + fence(acquire, workgroup) over all address spaces
+  // (hip/amd_detail/amd_device_functions.h); LLVM's AMDGPU memory model makes workgroup-scope release / acquire on gfx90a+ sufficient for global memory when the
+  // workgroup's waves share one CU's L1 -- i.e. NOT in threadgroup-split mode (the build never passes -mtgsplit; every kernel is __launch_bounds__(64): a launch with
+  // more than one wavefront per workgroup fails) -- and the re-read must be a VECTOR load: the compiler only scalarises loads it can prove unclobbered, and these
+  // addresses are stored to by the kernel itself (th_out / the gradient rows are plain non-const pointers).
   __device__ __forceinline__ void mem_sync() const { __syncthreads(); }
   __device__ __forceinline__ char* lds() const { return lds_; }
   __device__ __forceinline__ char* stash() const { return stash_; }
@@ -304,7 +309,11 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));  \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                \
     } else if constexpr (GROUP == GROUP_CHAIN) {                                                                           \
-      if (!qstat) return hipErrorInvalidValue;                                                                             \
+      if (p.qc_mode != dgp::QC_STATIC) return hipErrorInvalidValue;                                                        \
+      if (!qstat) {      /* round 6: a NON-DIAGONAL static Q_c_inv -- the general-covariance chain kernels (no covariance gradient: static) */ \
+        DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_GENERAL, true>));                                       \
+        return hipGetLastError();                                                                                          \
+      }                                                                                                                    \
       if constexpr (CC == 4) {                                                                                             \
         if (dgp::wb_applies(p, L, CC)) {                                                                                   \
           if (p.n == L * CC) DGP_LAUNCH_BWD((gn_backward_kernel<DOF, L, CC, IO, dgp::QK_WB, true>));                       \

@@ -20,6 +20,10 @@
 // source also compiles for the host, where tests/emul runs 64 lock-stepped threads as a wavefront
 // emulator to check the kernel logic without a GPU.  The product path only ever uses the device context.
 //
+// NOTE on the comments that speak of kernels hipcc "miscompiled" (rounds 2-5): one mechanism explains them all -- register-allocator spill stores placed in front of
+// the exec restore of a join block -- and the build repairs it in the device assembly since round 6 (profiles/r06_compiler_fault.md, __graft_entry__.compile_hip_unit).
+// The design decisions those comments record were taken before that was known; where they also rest on a measurement they still stand.
+//
 // Reference math (paths relative to /root/reference/diff_gpmp2/):
 //   GP factor        gpmp2/gp/gp_factor.py:31-37 (Phi), :65-73 (Q^-1), :100-110 (error, H1=Phi, H2=-I)
 //   prior factor     gpmp2/gp/prior_factor.py:15-18;  weights gpmp2/plan_layer.py:64-68
@@ -140,7 +144,7 @@ struct GnParams {
   double wb_tab[WB_TYPES * WB_TYPE_DOUBLES];
 };
 // The table is read as 16-byte cells.  NO alignment attribute on the member: it raises the alignment of the whole by-value kernel
-// argument to 16, hipcc 7.0 then lowers the argument loads of EVERY kernel differently, and the <3,64,2,double,STEP,per-state>
+// argument to 16, hipcc then lowers the argument loads of EVERY kernel differently, and the <3,64,2,double,STEP,per-state>
 // kernel built that way writes through a wild address (same source without the attribute: identical code to the previous round's,
 // exact results).  The offset is a multiple of 16 as it stands; the kernel-argument segment itself is 64-byte aligned.
 static_assert(offsetof(GnParams, wb_tab) % 16 == 0, "wb_tab must start on a 16-byte boundary of the kernel-argument segment");
@@ -2009,7 +2013,7 @@ template <int D, int LPT, int S, bool LEAN, bool LDL6 = false, typename Ctx>
 DGP_HD void pcr_round_any(Ctx& cx, int i, Sym<D>& Dm, Mat<D>& U, double (&r)[D], SpdCheck<Ctx>& ok) {
   constexpr bool last = (2 * S >= LPT);
   // Only the rounds whose exchanges are DPP row shifts (LPT = 16; LPT = 32 from stride 2 on).  With the lean order on the ds_bpermute
-  // rounds of LPT = 64, hipcc 7.0 built a <3,64,2,double,STEP,general> kernel that returns wrong results (4e-2 off; the same source
+  // rounds of LPT = 64, hipcc built a <3,64,2,double,STEP,general> kernel that returns wrong results (4e-2 off; the same source
   // is exact on the CPU wavefront emulator, every other shape is exact on the GPU) -- found by tests/stress_random_configs.py.
   // And not in the general-covariance kernels (LEAN = false there): <3,16,4,double,STEP,general> -- 355 spilled VGPRs, 1.4 KB of scratch
   // per lane -- came out wrong (O(1) errors) with the lean rounds, again only on the GPU (tests/test_hip_every_kernel.py pins every
@@ -3130,7 +3134,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
   int my_iters = 0;
   SpdCheck<Ctx> ok = {&cx, 0};            // accumulates over the GN iterations of MODE_SOLVE
   // MODE_SOLVE, d = 4: the trajectory is parked in LDS between the two ends of an iteration (lds_put_rows).  NOT for d = 6: with the
-  // state parked, hipcc 7.0 produced d = 6 fused-loop kernels -- <3,64,2,double,SOLVE,per-state>, <3,64,4,double,SOLVE,general>; the
+  // state parked, hipcc produced d = 6 fused-loop kernels -- <3,64,2,double,SOLVE,per-state>, <3,64,4,double,SOLVE,general>; the
   // ones that spill hundreds of SGPR lane masks into VGPR lanes -- that return garbage, non-deterministically, although the LDS
   // contents are intact (checked in-kernel against a register copy).  Found by tests/stress_random_configs.py, which now drives
   // the fused loop; the d = 6 fused kernels therefore keep their state in registers, as in round 1.
@@ -3213,7 +3217,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
       if (block_store) {
         if constexpr (WaveStore<IO, C, D>::kUsable && LPT != 32)
         {
-          // write-through for d = 4 only: on d = 6 it is worth 0.2 of 26 us, and with it hipcc 7.0 miscompiled <3,64,2,float,STEP,per-state>
+          // write-through for d = 4 only: on d = 6 it is worth 0.2 of 26 us, and with it hipcc miscompiled <3,64,2,float,STEP,per-state>
           // (wrong by O(1) for every n, found by tests/test_hip_every_kernel.py) -- the d = 6 kernels keep the code of
           // the build they were verified on
           if constexpr (D == 4) store_rows_through_lds_wt<IO, C, D>(cx, p.dtheta, (int64_t)cx.wave() * TPW * n * D, dx);
@@ -3261,7 +3265,7 @@ DGP_HD void gn_lane_program(const GnParams& p, Ctx& cx) {
         for (int a = 0; a < D; ++a) s2 += (traj_ok && j * C + k < n) ? dx[k][a] * dx[k][a] : 0.0;
       s2 = group_sum<LPT>(cx, s2);
       if (active) {
-        // (the history stores stay HERE, behind the solve: issued from the before_pcr hook, hipcc 7.0 built a
+        // (the history stores stay HERE, behind the solve: issued from the before_pcr hook, hipcc built a
         //  <3,16,1,double,SOLVE,general> kernel that stores through a wild address -- tests/stress_random_configs.py)
         if (j == 0) {
           if (p.err_hist) st<IO>(p.err_hist, b * (int64_t)p.max_iters + it, div_M(p, e));

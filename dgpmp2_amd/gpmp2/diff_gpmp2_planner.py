@@ -9,7 +9,7 @@ examples/diff_gpmp2_*) run unchanged on top of the HIP solver.
                kernel (dgp_gn_solve), every trajectory with its own convergence test, when no autograd graph is needed;
                with requires_grad inputs (the reference keeps the graph across iterations, examples/diff_gpmp2_2d_example.py:77)
                the same launch also records the trajectory history and the backward pass is ONE more launch (dgp_gn_solve_backward);
-               learn modules, a plan_time limit, a non-diagonal Q_c_inv or more than 256 states chain differentiable step() calls.
+               learn modules, a plan_time limit or more than 256 states chain differentiable step() calls.
 
 The learned-covariance modules (LearnModuleConv / LearnModuleFCN, stock torch.nn in the reference) are out of this
 build's scope: pass your own modules as `learn_module_conv` / `learn_module_fcn`; get_covariances() (the plumbing between
@@ -361,13 +361,22 @@ class DiffGPMP2Planner(nn.Module):
   lazy_results = False
 
   def _chain_backward_available(self, B=1, max_iters=1):
-    """dgp_gn_solve_backward covers static covariances with a diagonal Q_c_inv and trajectories of up to 256 states; anything else
-    differentiates through chained step() calls (_forward_stepwise).  So does a loop whose history -- (max_iters, B, n, d) doubles, allocated in
-    full whatever the iterations that run (the reference's YAML default is max_iters = 100) -- would exceed `fused_history_budget`: the stepwise
-    path keeps state for the iterations that ran and stops when every trajectory has converged."""
-    q = self.plan_layer._qc_rows
-    diag = all(q[i][j] == 0.0 for i in range(len(q)) for j in range(len(q)) if i != j)
-    return diag and self.num_traj_states <= 256 and max_iters * B * self.num_traj_states * self.state_dim * 8 <= self.fused_history_budget
+    """dgp_gn_solve_backward covers static covariances (any Q_c_inv: a diagonal one runs the static / Woodbury chain kernels, a non-diagonal one the general ones,
+    round 6) and trajectories of up to 256 states; anything else differentiates through chained step() calls (_forward_stepwise).  So does a loop whose history --
+    (max_iters, B, n, d) doubles, allocated in full whatever the iterations that run (the reference's YAML default is max_iters = 100) -- would exceed
+    `fused_history_budget`: the stepwise path keeps state for the iterations that ran and stops when every trajectory has converged; that fall-back is logged once per
+    planner (it changes the cost of a forward() + backward() by an order of magnitude)."""
+    if self.num_traj_states > 256: return False
+    need = max_iters * B * self.num_traj_states * self.state_dim * 8
+    if need > self.fused_history_budget:
+      if not self.__dict__.get('_warned_history'):
+        self.__dict__['_warned_history'] = True
+        import warnings
+        warnings.warn('dgpmp2_amd: forward() with a graph: the fp64 trajectory history of the fused loop (max_iters %d x B %d x n %d x d %d = %.1f GiB) exceeds '
+                      'fused_history_budget (%.1f GiB): differentiating through chained step() calls instead (slower; raise DiffGPMP2Planner.fused_history_budget or '
+                      'lower max_iters)' % (max_iters, B, self.num_traj_states, self.state_dim, need / 2.0 ** 30, self.fused_history_budget / 2.0 ** 30), RuntimeWarning)
+      return False
+    return True
 
   def _forward_fused(self, th_initb, startb, goalb, sdfb, max_iters, tol_delta, start_t, with_graph=False):
     """The whole batch in ONE launch of the fused loop.  with_graph: th_currb carries the autograd graph of the loop (w.r.t. th_initb, startb,

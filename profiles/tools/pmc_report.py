@@ -54,4 +54,8 @@ for wdir in sorted(glob.glob(os.path.join(root, '*'))):
     print('# traffic not derivable:', ex)
 if len(sys.argv) > 2 and traffic:
   if 'gn_step' in traffic: traffic['hbm_bytes_per_launch'] = traffic['gn_step']['hbm_bytes_per_launch']      # (the key round 1 wrote)
+  import subprocess, time      # provenance: bench.py quotes it next to roofline.traffic
+  try: commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, universal_newlines=True).stdout.strip() or None
+  except OSError: commit = None
+  traffic['collected'] = {'date': time.strftime('%Y-%m-%d', time.gmtime()), 'commit': commit or os.environ.get('DGP_COLLECT_COMMIT', 'round 6')}
   json.dump(traffic, open(sys.argv[2], 'w'), indent=1, sort_keys=True)

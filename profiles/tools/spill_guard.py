@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Build-time guard against the spill level at which hipcc 7.0 has miscompiled these kernels (six faults in round 2, every
+"""Build-time guard against the spill level at which hipcc has miscompiled these kernels (six faults in round 2, every
 one among the heaviest spillers, none among the spill-free kernels).
 
 A kernel is in the DANGER ZONE when its gfx950 assembly shows >= 300 spilled VGPRs, >= 150 spilled SGPRs or >= 1 KB of scratch per lane --

@@ -141,8 +141,9 @@ void run_wave(const dgp::GnParams& p, const dgp::GnGradParams* g, int mode, int 
         else dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>(p, cx);
       } else if (mode == dgp::MODE_EVAL) {
         dgp::gn_lane_program<DOF, LPT, C, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>(p, cx);
-      } else if (mode == 4) {
-        dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC, true>(p, *g, cx);      // (dgp_gn_solve_backward: static covariances only, host-checked)
+      } else if (mode == 4) {      // (dgp_gn_solve_backward: static covariances only, host-checked; a non-diagonal Q_c_inv runs the general-covariance chain kernel)
+        if (qk == dgp::QK_STATIC) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC, true>(p, *g, cx);
+        else dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_GENERAL, true>(p, *g, cx);
       } else {
         if (qk == dgp::QK_STATIC) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_STATIC>(p, *g, cx);
         else if (qk == dgp::QK_SCALED) dgp::gn_backward_lane_program<DOF, LPT, C, IO, dgp::QK_SCALED>(p, *g, cx);

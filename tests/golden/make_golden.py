@@ -675,7 +675,8 @@ def g7_tbptt():
 #   examples/diff_gpmp2_2d_example.py:77) -- w.r.t. the initial trajectory, the grids, the start and goal means.  Samples stop after
 #   different numbers of iterations (tol_delta) and one runs into max_iters; the last dtheta of a sample IS applied (planner_utils.py:3-16).
 # ------------------------------------------------------------------------------------------------
-def g8_forward_grads():
+def g8_forward_grads(qc_inv=None, name='g8_forward_grads'):
+  """qc_inv (round 6): a NON-DIAGONAL static Q_c_inv -> fixture g8_forward_grads_qc (the differentiable fused forward() of the general-covariance chain kernels)"""
   import io, contextlib
   B, n, Gsz = 4, 16, 48
   start, goal = rand_start_goal(B, seed=41)
@@ -687,6 +688,10 @@ def g8_forward_grads():
   gbar = torch.randn(B, n, 4, generator=g)
   gp, obs, plp, opt = params_2d(n, max_iters=9)
   opt['tol_delta'] = 0.5
+  extra = {}
+  if qc_inv is not None:
+    gp['Q_c_inv'] = torch.as_tensor(qc_inv, dtype=torch.float64)
+    extra['Q_c_inv'] = np.asarray(qc_inv, dtype=np.float64)
   planner = DiffGPMP2Planner(gp, obs, plp, opt, ENV, PointRobot2D(torch.tensor(0.4), 1, n), batch_size=1)
   leaves = [x.clone().requires_grad_(True) for x in (th0, sdf, start, goal)]
   with contextlib.redirect_stdout(io.StringIO()):
@@ -694,10 +699,11 @@ def g8_forward_grads():
   gr = torch.autograd.grad((gbar * thf).sum(), leaves)
   maxlen = max(len(e) for e in e_iter)
   pad = lambda L: np.asarray([list(e) + [np.nan] * (maxlen - len(e)) for e in L])
-  save('g8_forward_grads', th0=th0, G=Gsz, circles=np.asarray(circ), free_sample=0, free_value=3.0, start=start, goal=goal, gbar=gbar, max_iters=9, tol_delta=0.5,
+  save(name, th0=th0, G=Gsz, circles=np.asarray(circ), free_sample=0, free_value=3.0, start=start, goal=goal, gbar=gbar, max_iters=9, tol_delta=0.5,
        th_final=thf, iters=np.asarray(k), err_init=np.asarray(e_init), err_final=np.asarray(e_final), err_iter=pad(e_iter), errext_iter=pad(ee_iter),
-       g_th0=gr[0], g_sdf=gr[1], g_start=gr[2], g_goal=gr[3])
+       g_th0=gr[0], g_sdf=gr[1], g_start=gr[2], g_goal=gr[3], **extra)
 
 
 if __name__ == '__main__':
   g1_factors(); g1_custom(); g2_system(); g3_c1(); g3_c2mini(); g4_forward(); g5_grads(); g3_c3_vel(); g3_c4_xyh(); g6_helpers(); g6_dataset(); g7_errors(); g7_tbptt(); g8_forward_grads()
+  g8_forward_grads(qc_inv=[[1.3, 0.4], [0.4, 0.9]], name='g8_forward_grads_qc')

@@ -743,6 +743,44 @@ def case_solve_backward(be, golden, io):
 ALL_CASES.append(case_solve_backward)
 
 
+def case_solve_backward_general_qc(be, golden, io):
+  """Round 6: dgp_gn_solve_traced + dgp_gn_solve_backward with a NON-DIAGONAL static Q_c_inv (the general-covariance chain kernels) vs the reference's torch
+  autograd through DiffGPMP2Planner.forward with gp_params['Q_c_inv'] = [[1.3, 0.4], [0.4, 0.9]] (fixture g8_forward_grads_qc; diff_gpmp2_planner.py:92-174):
+  iteration counts, final trajectories, gradients w.r.t. the initial trajectory, the grids, the start and goal means; and the chain against single-step
+  backward launches chained by hand."""
+  g = golden('g8_forward_grads_qc')
+  B, n = g['th0'].shape[:2]
+  G = int(g['G'])
+  p = P2d(n, Q_c_inv=g['Q_c_inv'])
+  K, tol_delta = int(g['max_iters']), float(g['tol_delta'])
+  sdf = np.broadcast_to(O.circles_sdf(G, g['circles']), (B, 1, G, G)).copy()
+  sdf[int(g['free_sample'])] = float(g['free_value'])
+  th0, st, go, sdf, gbar = rnd(g['th0'], io), rnd(g['start'], io), rnd(g['goal'], io), rnd(sdf, io), rnd(g['gbar'], io)
+  tho, its, hist, info = be.solve_traced(p, th0, st, go, sdf, K, tol_delta, io=io)
+  assert np.all(info == 0) and np.array_equal(its, g['iters'])
+  ref = be.solve(p, th0, st, go, sdf, K, tol_delta, io=io)
+  assert np.array_equal(tho, ref[0]) and np.array_equal(its, ref[1])
+  assert rel_err(tho, g['th_final']) < (1e-8 if io == 'f64' else 2e-3)
+  r = be.solve_backward(p, st, go, sdf, K, hist, tho, its, gbar, io=io)
+  tol = 5e-8 if io == 'f64' else 2e-3
+  for k, key in (('th', 'g_th0'), ('start', 'g_start'), ('goal', 'g_goal')) + ((('sdf', 'g_sdf'),) if io == 'f64' else ()):
+    assert rel_err(r[k], g[key]) < tol, (k, rel_err(r[k], g[key]))
+  if io != 'f64': return
+  gcur = gbar.copy()
+  acc = dict(start=np.zeros_like(st), goal=np.zeros_like(go), sdf=np.zeros_like(sdf))
+  for k in range(K - 1, -1, -1):
+    on = its > k
+    thk = np.where(on[:, None, None], np.nan_to_num(hist[k]), tho)
+    nxt = np.where((its > k + 1)[:, None, None], np.nan_to_num(hist[min(k + 1, K - 1)]), tho)
+    one = be.backward(p, thk, st, go, sdf, nxt - thk, gcur * on[:, None, None], None, io=io)
+    gcur = gcur + one['th'] * on[:, None, None]
+    for key in acc: acc[key] += one[key] * on.reshape((B,) + (1,) * (one[key].ndim - 1))
+  assert rel_err(r['th'], gcur) < 1e-10 and rel_err(r['start'], acc['start']) < 1e-10 and rel_err(r['goal'], acc['goal']) < 1e-10 and rel_err(r['sdf'], acc['sdf']) < 1e-10
+
+
+ALL_CASES.append(case_solve_backward_general_qc)
+
+
 def case_step_errors(be, golden, io):
   """dgp_gn_step_errors / dgp_gn_step_errors_backward: one iteration of the reference's training loop (learning/train_planner.py:311-327 --
   step(), th + dtheta, unweighted_errors_batch) as single calls, against the reference's autograd through exactly that composition (fixture

@@ -128,7 +128,7 @@ def test_step_kernel_variant_choice(api, monkeypatch):
 
 
 def test_spill_guard_every_heavy_spiller_was_verified_on_a_gpu():
-  """hipcc 7.0 has miscompiled these kernels six times, every time among the heaviest spillers.  A kernel at that spill
+  """hipcc has miscompiled these kernels six times, every time among the heaviest spillers.  A kernel at that spill
   level (profiles/tools/spill_guard.py: >= 300 spilled VGPRs, >= 150 spilled SGPRs or >= 1 KB scratch per lane) must be listed, with its spill
   counts, in dgpmp2_amd/csrc/spill_baseline.json -- which is only ever rewritten after tests/test_hip_every_kernel.py ran green on a GPU
   against the build that produced those counts.  A new or grown heavy spiller fails HERE, before it ships unverified."""

@@ -5,7 +5,7 @@ the shape exactly (n = LPT * C: full-line row I/O, the exact-fit Woodbury kernel
 ragged Woodbury kernels).  Backward: every instantiation against an INDEPENDENT gradient oracle -- torch autograd over the dense
 restatement of the reference's step (oracle/autograd_torch.py, itself pinned to the reference's autograd fixtures) -- second test.
 
-Why this exists: hipcc 7.0 has miscompiled several of the largest d = 6 kernels (wrong results or wild stores, while the same source
+Why this exists: hipcc has miscompiled several of the largest d = 6 kernels (wrong results or wild stores, while the same source
 is exact on the CPU wavefront emulator and in every other instantiation).  Which instantiation breaks changes with
 unrelated edits, so the sampled stress run (tests/stress_random_configs.py) is not enough: this test pins every one, every round.
 A failure names the kernel's template arguments."""

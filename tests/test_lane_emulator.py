@@ -40,6 +40,7 @@ def test_emul_eval_errors_backward(be, golden): PC.case_eval_errors_backward(be,
 def test_emul_eval_errors_backward_f32(be, golden): PC.case_eval_errors_backward(be, golden, 'f32')
 def test_emul_solve_backward(be, golden): PC.case_solve_backward(be, golden, 'f64')
 def test_emul_solve_backward_f32(be, golden): PC.case_solve_backward(be, golden, 'f32')
+def test_emul_solve_backward_general_qc(be, golden): PC.case_solve_backward_general_qc(be, golden, 'f64')
 def test_emul_step_errors(be, golden): PC.case_step_errors(be, golden, 'f64')
 def test_emul_step_errors_f32(be, golden): PC.case_step_errors(be, golden, 'f32')
 def test_emul_sdf_gradient_delivery(be, golden): PC.case_sdf_gradient_delivery(be, golden, 'f64')

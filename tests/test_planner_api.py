@@ -1081,3 +1081,24 @@ def test_tiled_grid_size_travels_with_the_tensor_on_the_gpu(golden):
   assert rel_err(d_t.cpu().numpy(), d_r.cpu().numpy()) < 1e-11 and rel_err(d_f.double().cpu().numpy(), d_r.cpu().numpy()) < 1e-4
   with pytest.raises(ValueError, match='carries no logical grid size'):
     planner.step(th, start, goal, None, tiles.as_subclass(torch.Tensor))
+
+
+def test_forward_with_grad_and_a_non_diagonal_qc_is_two_launches(golden):
+  """Round 6: gp_params['Q_c_inv'] non-diagonal -- the differentiable forward() is still ONE fused launch + ONE backward launch (the general-covariance
+  chain kernels), against the reference's autograd through its own forward() with that Q_c_inv (fixture g8_forward_grads_qc)."""
+  from dgpmp2_amd.robot_models import PointRobot2D
+  from dgpmp2_amd.gpmp2 import DiffGPMP2Planner
+  g = golden('g8_forward_grads_qc')
+  B, n, G = 4, 16, int(g['G'])
+  gp, ob, pp, op, ev = ref_params(n, max_iters=int(g['max_iters']), tol_delta=float(g['tol_delta']))
+  gp['Q_c_inv'] = torch.tensor(g['Q_c_inv'], dtype=torch.float64)
+  planner = DiffGPMP2Planner(gp, ob, pp, op, ev, PointRobot2D(torch.tensor(0.4, dtype=torch.float64), B, n, use_cuda=True), batch_size=B, use_cuda=True)
+  sdf = T(O.circles_sdf(G, g['circles']))[None, None].repeat(B, 1, 1, 1)
+  sdf[int(g['free_sample'])] = float(g['free_value'])
+  L = [T(g['th0']).requires_grad_(True), sdf.requires_grad_(True), T(g['start']).requires_grad_(True), T(g['goal']).requires_grad_(True)]
+  thf, hid, e_init, e_final, e_iter, ee_iter, jb, tb = planner.forward(L[0], L[2], L[3], None, L[1])
+  assert type(thf.grad_fn).__name__.startswith('_GNSolve') and jb == list(g['iters'])
+  assert rel_err(thf.detach().cpu().numpy(), g['th_final']) < 1e-8 and rel_err(np.asarray(e_init), g['err_init']) < 1e-10
+  gr = torch.autograd.grad((T(g['gbar']) * thf).sum(), L)
+  for got, key in zip(gr, ('g_th0', 'g_sdf', 'g_start', 'g_goal')):
+    assert rel_err(got.cpu().numpy(), g[key]) < 5e-8, (key, rel_err(got.cpu().numpy(), g[key]))
