@@ -77,10 +77,13 @@ def _reload_kind(lines, i, inst):
   mine = _regs(m.group(1))
   j = i + 1
   while j < len(lines) and not RESTORE.match(lines[j]): j += 1
-  # were the registers consumed in front of the restore already?  then the reload served the branch
+  # (consumed in front of the restore too?  that serves the branch's lanes; what matters is whether anybody reads the register BEHIND the restore before it is rewritten.
+  #  Registers rewritten in front of the restore drop out.)
   for k in range(i + 1, j):
-    ops = re.findall(r'v\[\d+:\d+\]|v\d+', lines[k].split(';')[0])
-    if len(ops) > 1 and any(_regs(o) & mine for o in ops[1:]): return 'reload'
+    l = lines[k].split(';')[0]
+    ops = re.findall(r'v\[\d+:\d+\]|v\d+', l)
+    if ops and l.lstrip().startswith('v_') and not any(_regs(o) & mine for o in ops[1:]): mine -= _regs(ops[0])
+  if not mine: return 'reload'
   j += 1
   while j < len(lines):
     l = lines[j].split(';')[0]

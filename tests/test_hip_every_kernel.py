@@ -257,7 +257,7 @@ def test_hip_every_tiled_twin_kernel(be, dof, io, monkeypatch):
       if cov != 'scalar':      # the fused loop (DGP_QC_SCALAR is a step-only mode)
         sa = be.solve(p, th, start, goal, sdf, K, 0.0, **kw); sb = bt.solve(p, th, start, goal, sdf, K, 0.0, **kw)
         cmp(tag, 'fused loop', sb[0], sa[0], t=100 * tol)
-      if cov == 'static':      # ... and its backward
+      if cov in ('static', 'static_diag', 'static_full'):      # ... and its backward (static_full: the general-covariance chain twins, round 6)
         tho, its, hist, info = be.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
         tht, itt, hist_t, info_t = bt.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
         cmp(tag, 'traced loop', tht, tho, t=100 * tol)
@@ -266,23 +266,24 @@ def test_hip_every_tiled_twin_kernel(be, dof, io, monkeypatch):
   assert not bad, '%d tiled-twin results differ from the row-major kernels:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
+@pytest.mark.parametrize('cov', ['static', 'static_full'])      # static_full (round 6): a non-diagonal Q_c_inv -- the general-covariance chain kernels
 @pytest.mark.parametrize('io', ['f64', 'f32'])
 @pytest.mark.parametrize('dof', [2, 3])
-def test_hip_every_chain_backward_kernel(be, dof, io, monkeypatch):
+def test_hip_every_chain_backward_kernel(be, dof, io, cov, monkeypatch):
   """Every instantiation of the fused loop's backward (dgp_gn_solve_backward: 2 robots x 2 I/O types x 9 shapes x block elimination / Woodbury exact
   fit / Woodbury ragged) and of the traced fused loop in front of it: the history must reproduce the plain loop bit for bit, and the gradients
   must equal the chain of single-step backward launches (dgp_gn_step_backward, each instantiation of which the test above holds against the
   independent autograd oracle) walked by hand through that history.  Three iterations, the second trajectory stopping after the first
   (tol_delta between the two trajectories' first updates), the third batch element in a second, partially filled wavefront."""
-  rs = np.random.RandomState(300 * dof + (io == 'f32'))
+  rs = np.random.RandomState(300 * dof + (io == 'f32') + 7 * (cov != 'static'))
   bad = []
   K = 3
   for lpt, c in SHAPES:
     monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
     for n in (lpt * c, max(4, lpt * c - 2)):
       B = 64 // lpt + 1
-      p, th, start, goal, sdf, _, _, _, _ = _inputs(rs, dof, n, B, 'static', io)
-      tag = 'dof %d %s shape (%d,%d) n %d' % (dof, io, lpt, c, n)
+      p, th, start, goal, sdf, _, _, _, _ = _inputs(rs, dof, n, B, cov, io)
+      tag = 'dof %d %s %s shape (%d,%d) n %d' % (dof, io, cov, lpt, c, n)
       d0 = be.step(p, th, start, goal, sdf, io=io)[0]
       nrm = np.sqrt((d0.reshape(B, -1) ** 2).sum(1))
       order = np.argsort(nrm)
@@ -310,5 +311,6 @@ def test_hip_every_chain_backward_kernel(be, dof, io, monkeypatch):
         eb = np.abs(a_ - b_).max() / max(np.abs(b_).max(), np.abs(gcur).max() if key == 'sdf' else 0.0, 1e-300)
         # f32 I/O: the hand-walked chain rounds th_k, dtheta_k and the running cotangent to fp32 between the launches, the chain kernel keeps them in fp64
         # (the grid gradient is summed by atomics in an order that differs between the one launch and the K: 1e-7 of cancellation noise)
-        if not eb < ((1e-7 if key == 'sdf' else 1e-9) if io == 'f64' else 5e-3): bad.append((tag, key, eb))
+        # (static_full: the general kernels' PCR rounds use explicit block inverses, six rounds deep at 64 lanes -- 1.3e-9 met on <3,64,1,double>: rounding, not a fault)
+        if not eb < ((1e-7 if key == 'sdf' else (5e-9 if cov == 'static_full' else 1e-9)) if io == 'f64' else 5e-3): bad.append((tag, key, eb))
   assert not bad, '%d chain-backward results differ from the chained single-step backward:\n' % len(bad) + '\n'.join(map(str, bad))
