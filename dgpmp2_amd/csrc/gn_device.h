@@ -303,8 +303,7 @@ hipError_t launch_typed(DgpShape sh, int mode, const dgp::GnParams& p, const dgp
       else if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_STATIC>));            \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_STATIC>));                                       \
     } else if constexpr (GROUP == GROUP_GENERIC) {                                                                         \
-      /* (host-checked: the d = 6 general twins are not built) */ \
-      if constexpr (DGP_STEP_ERRS == 1 && (DOF == 3 || (L == 32 && sizeof(IO) == 4 && DGP_EXCLUDE_REPAIRED_TWINS))) return hipErrorInvalidValue;      \
+      if constexpr (DGP_STEP_ERRS == 1 && L == 32 && sizeof(IO) == 4 && DGP_EXCLUDE_REPAIRED_TWINS) return hipErrorInvalidValue;      \
       else if (mode == dgp::MODE_STEP) DGP_LAUNCH((gn_kernel<DOF, L, CC, IO, dgp::MODE_STEP, dgp::QK_GENERAL>));           \
       else if (mode == dgp::MODE_SOLVE) DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_SOLVE, dgp::QK_GENERAL>));  \
       else DGP_LAUNCH_NOSTEP((gn_kernel<DOF, L, CC, IO, dgp::MODE_EVAL, dgp::QK_GENERAL>));                                \

@@ -9,7 +9,7 @@ the backward launches autograd issues, optionally the optimiser step) and replay
     def iteration(th, start, goal, im, sdf, th_opt):                  # a function of its tensor arguments (+ module parameters) only
       out, (e_sg, e_gp, e_obs) = planner.step_with_errors(th, start, goal, im, sdf, conv_out, dtheta)
       loss = criterion(out[0], th_opt - th) + e_gp.mean() + e_sg.mean() + e_obs.mean()
-      grads = torch.autograd.grad(loss, params)                       # or loss.backward(); see `grads_of`
+      grads = torch.autograd.grad(loss, params)                       # or loss.backward() into long-lived .grad tensors
       return (out[0], loss) + grads
 
     it = planner.graphed_iteration(iteration)
@@ -40,11 +40,8 @@ class GraphedIteration(object):
 
   @staticmethod
   def _signature(args):
-    sig = []
-    for a in args:
-      if _is_tensor(a): sig.append((tuple(a.shape), a.dtype, a.device, bool(a.requires_grad), type(a)))
-      else: sig.append(('value', a))
-    return tuple(sig)
+    # (cheap on purpose -- this runs on every call: torch.Size and dtypes hash fast; the device and the tensor class are fixed per call site)
+    return tuple([(a.shape, a.dtype, a.requires_grad) if isinstance(a, torch.Tensor) else ('value', a) for a in args])
 
   def _capture(self, sig, args):
     dev = next((a.device for a in args if _is_tensor(a) and a.is_cuda), None)
@@ -78,9 +75,14 @@ class GraphedIteration(object):
     if e is None:
       e = self._capture(sig, args)      # (the capture ran `fn` on copies of these very inputs, but a capture does not execute: replay below)
     statics, graph, outs, single = e
-    with torch.no_grad():
-      for s, a in zip(statics, args):
-        if _is_tensor(a) and s is not a and s.data_ptr() != a.data_ptr(): s.copy_(a, non_blocking=True)
+    dst, src = [], []
+    for s, a in zip(statics, args):
+      if isinstance(a, torch.Tensor) and s is not a: dst.append(s); src.append(a)
+    if dst:
+      with torch.no_grad():
+        try: torch._foreach_copy_(dst, src)      # ONE multi-tensor launch for all inputs (four separate copy_ calls cost more host time than the replay)
+        except (RuntimeError, AttributeError, TypeError):
+          for s, a in zip(dst, src): s.copy_(a, non_blocking=True)
     graph.replay()
     if self.clone_outputs: outs = tuple(o.clone() if _is_tensor(o) else o for o in outs)
     return outs[0] if single else outs
