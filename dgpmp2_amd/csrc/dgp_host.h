@@ -426,13 +426,13 @@ int gn_step_errors(const DgpHandle* h, int32_t batch, const void* th, const void
   const bool errs = unw_sg || unw_gp || unw_obs;
   if (errs && is_long(p.n)) return fail(DGP_EUNSUPPORTED, "dgp_gn_step_errors is not implemented for num_states > 256");
   // ONE launch where the step kernels with the errors epilogue exist (round 5): row-major grid, up to 128 states (the two four-states-per-lane shapes); d = 4: every
-  // covariance representation for both robots (the d = 6 general twins -- q_full / a non-diagonal Q_c_inv -- since round 6); everything else: the error kernel
-  // stream-ordered behind the step, as in round 4.  (Round 5 excluded two more twins -- <3,16,4,float,STEP,static> and <2,32,4,float,STEP,general> -- after wrong
+  // covariance representation, d = 6: everything but the general family (q_full / a non-diagonal Q_c_inv: those twins were built and measured in round 6 -- exact, but
+  // 92 us against 66 + 8 us for the two launches, profiles/r06_d6_general_twin.txt: not shipped); everything else: the error kernel stream-ordered behind the step, as in round 4.  (Round 5 excluded two more twins -- <3,16,4,float,STEP,static> and <2,32,4,float,STEP,general> -- after wrong
   // results on the GPU: the exec-join miscompile of profiles/r06_compiler_fault.md, which the build repairs since round 6.)
   const int qk = dgp::kernel_variant(p);
   const bool twin_ok = DGP_EXCLUDE_REPAIRED_TWINS ? (!(h->cfg.dof == 3 && (qk == dgp::QK_GENERAL || (qk == dgp::QK_STATIC && !p.wb_ok))) &&
                                                      !(qk == dgp::QK_GENERAL && h->cfg.io_dtype == DGP_F32 && p.n > 64))
-                                                  : true;
+                                                  : !(h->cfg.dof == 3 && qk == dgp::QK_GENERAL);
   if (errs && p.sdf_layout == 0 && p.n <= kMaxStatesTiled && twin_ok && !h->force_lpt) {
     p.unw_sg = unw_sg; p.unw_gp = unw_gp; p.unw_obs = unw_obs;
 #if DGP_TWIN_REPRO      // reproducer builds (-DDGP_TWIN_REPRO=1): DGP_TWIN_NO_ERRS=1 launches the twin kernel with its epilogue switched off at run time (is the main body or the epilogue wrong?)

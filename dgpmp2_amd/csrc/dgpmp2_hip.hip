@@ -31,9 +31,10 @@ hipError_t launch(const DgpHandle* h, int mode, const dgp::GnParams& p, const dg
   if (tiled && p.n > dgp_host::kMaxStatesTiled) return kTiledTooLong;
   if (mode == dgp_host::kModeStepErrs) {          // dgp_gn_step_errors as ONE launch: the step kernels with the errors epilogue (gn_inst.hip with -DDGP_STEP_ERRS=1; host-checked: available)
     static const DgpLaunchFn etab[2][2][3] = {{{dgp_launch_2e_f32_g0, dgp_launch_2e_f32_g3, dgp_launch_2e_f32_g1}, {dgp_launch_2e_f64_g0, dgp_launch_2e_f64_g3, dgp_launch_2e_f64_g1}},
-                                             {{dgp_launch_3e_f32_g0, dgp_launch_3e_f32_g3, dgp_launch_3e_f32_g1}, {dgp_launch_3e_f64_g0, dgp_launch_3e_f64_g3, dgp_launch_3e_f64_g1}}};
+                                             {{dgp_launch_3e_f32_g0, dgp_launch_3e_f32_g3, nullptr}, {dgp_launch_3e_f64_g0, dgp_launch_3e_f64_g3, nullptr}}};
     const int grp = dgp_dev::launch_group(dgp::MODE_STEP, p);
     if (tiled || (grp != dgp_dev::GROUP_STATIC && grp != dgp_dev::GROUP_KRON && grp != dgp_dev::GROUP_GENERIC)) return hipErrorInvalidValue;
+    if (grp == dgp_dev::GROUP_GENERIC && h->cfg.dof != 2) return hipErrorInvalidValue;      // (host-checked: dgp_host::gn_step_errors)
     const DgpShape she = dgp_host::choose_shape(h, p.B, dgp_host::shape_family(dgp::MODE_STEP, p), /*four states per lane=*/true);
     return etab[h->cfg.dof - 2][h->cfg.io_dtype == DGP_F64 ? 1 : 0][grp == dgp_dev::GROUP_KRON ? 1 : (grp == dgp_dev::GROUP_GENERIC ? 2 : 0)](she, dgp::MODE_STEP, p, g, s);
   }

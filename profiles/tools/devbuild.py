@@ -51,7 +51,7 @@ def main():
   with open(stub, 'w') as f:
     f.write('#include "%s"\n' % os.path.join(CSRC, 'gn_device.h'))
     for u in ALL:
-      if u not in a.units and not (u[1] == 'e' and u[-1] not in '013'):      # (the twin units the ABI references: groups 0, 1, 3)
+      if u not in a.units and not (u[1] == 'e' and u[-1] not in ('013' if u[0] == '2' else '03')):      # (the twin units the ABI references: groups 0, 3 and -- d = 4 -- 1)
         f.write('hipError_t dgp_launch_%s(DgpShape, int, const dgp::GnParams&, const dgp::GnGradParams*, hipStream_t) { return hipErrorInvalidValue; }\n' % u)
   d = os.path.join(work, 'stubs'); os.makedirs(d)
   jobs.append([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', stub, '-o', os.path.join(d, 'stubs.o')])
