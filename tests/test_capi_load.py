@@ -151,9 +151,9 @@ def test_exec_join_checker_and_repair(tmp_path):
   """Round 6: the static checker of the hipcc miscompile signature (profiles/r06_compiler_fault.md) and the repair the build applies, on a synthetic kernel:
   a spill store at the top of a join block in front of the exec restore is found and moved behind it; the body of the `if`, an out-of-line body, a slot that
   holds an earlier unconsumed write (`merge`) and a reload whose register is rewritten are left alone; the built library's record carries no surviving finding."""
-  import json
+  import json, sys
   sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
-  import exec_join_check as C, exec_join_patch as P
+  import exec_join_check as CK, exec_join_patch as P
   asm = '''
 _Z6kernelv:
 	v_accvgpr_write_b32 a7, v9
@@ -169,26 +169,31 @@ _Z6kernelv:
 	s_or_b64 exec, exec, s[0:1]
 	v_accvgpr_read_b32 v4, a1
 	s_and_saveexec_b64 s[0:1], vcc
-	s_cbranch_execnz .LBB0_4
-.LBB0_3:
+	s_cbranch_execz .LBB0_4
+; %bb.3:
+	global_store_dword v[0:1], v4, off
+.LBB0_4:
 	v_accvgpr_read_b32 v20, a2
 	v_mov_b32_e32 v20, 0
 	s_or_b64 exec, exec, s[0:1]
-	s_endpgm
-.LBB0_4:
-	v_accvgpr_write_b32 a9, v1
+	s_and_saveexec_b64 s[0:1], vcc
+	s_cbranch_execnz .LBB0_6
+.LBB0_5:
 	s_or_b64 exec, exec, s[0:1]
-	s_branch .LBB0_3
+	s_endpgm
+.LBB0_6:
+	v_accvgpr_write_b32 a9, v1
+	s_branch .LBB0_5
 .Lfunc_end0:
 '''
   src, dst = str(tmp_path / 'k.s'), str(tmp_path / 'k_fixed.s')
   open(src, 'w').write(asm)
-  kinds = sorted((f[3].split()[1].rstrip(','), f[5]) for f in C.classify(src))
+  kinds = sorted((f[3].split()[1].rstrip(','), f[5]) for f in CK.classify(src))
   assert kinds == [('a1', 'store'), ('a7', 'merge'), ('v20', 'reload')], kinds      # a5 (the body) and a9 (the out-of-line body) are not join blocks
   assert P.patch(src, dst) == 1
-  fixed = open(dst).read().split('\\n')
+  fixed = open(dst).read().split('\n')
   i_or = next(i for i, l in enumerate(fixed) if 's_or_b64 exec, exec, s[0:1]' in l)
-  assert 'v_accvgpr_write_b32 a1, v10' in fixed[i_or + 1] and not any(f[5] == 'store' for f in C.classify(dst))
+  assert 'v_accvgpr_write_b32 a1, v10' in fixed[i_or + 1] and not any(f[5] == 'store' for f in CK.classify(dst))
   assert sum('v_accvgpr_write_b32 a7, v11' in l for l in fixed[:i_or]) == 1       # the merge-class store stays where it was
   stats = os.path.join(ROOT, 'dgpmp2_amd', 'lib', 'kernel_stats.json')
   if os.path.exists(stats):
