@@ -318,7 +318,8 @@ def sdf_fields_rate(device, batch=256):
   return {'workload': '%d occupancy images of %dx%d (3-7 random discs), padlen 1, float32 in, float64 out' % (batch, GRID, GRID), 'us_per_call': us, 'us_per_image': us / batch,
           'host_scipy_ms_per_image': host_ms, 'bit_identical_to_host': bool(np.array_equal(out[0].cpu().numpy(), ref)),
           'roofline': {'bound': 'hbm', 'achieved': alg / us * 1e-3, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': alg / us * 1e-3 / HBM_PEAK_GBS, 'traffic': None},
-          'note': 'algorithmic bytes = image in + field out per padded pixel; the call is bound by the row pass, whose search length is the distance itself (DESIGN.md section 3)'}
+          'note': 'algorithmic bytes = image in + field out per padded pixel; the call is bound by the row pass, whose search length is the distance itself (DESIGN.md sections 3 and 9; round 6: '
+                  'bit-plane column pass + eight offsets per trip of the row search, profiles/r06_sdf_edt_ab.txt)'}
 
 
 def extra_workloads(device, stream, reps=1500):

@@ -35,7 +35,10 @@ def images(B, G, seed):
   return ims
 
 
-for (B, G) in ((1, 256), (1, 512), (64, 256), (64, 512), (1024, 256), (4096, 256)):
+CASES = ((1, 256), (1, 512), (64, 256), (64, 512), (1024, 256), (4096, 256))
+if os.environ.get('DGP_EDT_CASES'):      # e.g. "4096x256,64x512"
+  CASES = tuple(tuple(int(v) for v in c.split('x')) for c in os.environ['DGP_EDT_CASES'].split(','))
+for (B, G) in CASES:
   ims = images(min(B, 64), G, G + B)
   ims = np.tile(ims, (B // ims.shape[0], 1, 1)) if B > ims.shape[0] else ims
   d = torch.as_tensor(ims).cuda()
@@ -50,4 +53,4 @@ for (B, G) in ((1, 256), (1, 512), (64, 256), (64, 512), (1024, 256), (4096, 256
   same = bool(np.array_equal(out[0].cpu().numpy(), ref))
   alg = B * ((G * G) * 4 + (G + 2) ** 2 * 8)
   print(json.dumps({'batch': B, 'grid': G, 'gpu_us_per_batch': round(us, 1), 'gpu_us_per_image': round(us / B, 2), 'scipy_ms_per_image': round(cpu_ms, 2),
-                    'algorithmic_GBs': round(alg / us * 1e-3, 1), 'bit_identical_to_scipy': same}))
+                    'algorithmic_GBs': round(alg / us * 1e-3, 1), 'bit_identical_to_scipy': same, 'variant': os.environ.get('DGP_EDT_TAG', '')}))

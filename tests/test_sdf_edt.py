@@ -109,7 +109,10 @@ def test_hip_matches_the_reference_fixtures_bit_for_bit():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('H,W,fill', [(1, 1, 0.5), (1, 37, 0.5), (41, 1, 0.5), (17, 23, 0.1), (64, 64, 0.02), (63, 65, 0.98), (128, 200, 0.7), (257, 255, 0.995),
-                                      (300, 70, 0.3), (2, 2550, 0.9), (3, 3000, 0.9), (2600, 4, 0.95)])      # (the last three: the widest row of the padded search (61 KB of LDS), a wider one (clamped search), taller than wide)
+                                      (300, 70, 0.3), (2, 2550, 0.9), (3, 3000, 0.9), (2600, 4, 0.95),      # (the last three: the widest row of the padded search (61 KB of LDS), a wider one (clamped search), taller than wide)
+                                      # round 6 -- the limits of the tile form of the row pass (8 rows up to 284 padded columns, 4 rows up to 570, one row per workgroup beyond) and of the
+                                      # bit-plane column pass (32 rows per word; up to 1024 padded rows), with pad = 1: exactly at and one past each of them
+                                      (30, 282, 0.9), (31, 283, 0.9), (62, 568, 0.95), (63, 569, 0.95), (1022, 9, 0.97), (1023, 9, 0.97), (94, 40, 0.5), (95, 41, 0.05)])
 @pytest.mark.parametrize('pad', [0, 1, 3])
 def test_hip_matches_scipy_and_oracle_on_ragged_batches(H, W, fill, pad):
   rs = np.random.RandomState(H * 1000 + W + pad)
