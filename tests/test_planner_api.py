@@ -1052,6 +1052,14 @@ def test_graphed_iteration_replays_the_eager_iteration(golden):
   want = [t.clone() for t in iteration(th, th_opt, qc, ow, ep)]
   for a, b in zip(it(th, th_opt, qc, ow, ep), want): assert torch.equal(a, b)
   assert it.captures == 1
+  # the copy-free form: write into the graph's own input tensors, replay
+  th, th_opt = T(g['th_hist'][4]), T(g['th_hist'][9])
+  want = [t.clone() for t in iteration(th, th_opt, qc, ow, ep)]
+  statics = it.static_inputs(th, th_opt, qc, ow, ep)
+  with torch.no_grad():
+    statics[0].copy_(th); statics[1].copy_(th_opt)
+  for a, b in zip(it.replay(th, th_opt, qc, ow, ep), want): assert torch.equal(a, b)
+  assert it.captures == 1
   # another batch size is another signature (the planner itself is batch-agnostic at this level)
   it2 = planner.graphed_iteration(lambda th_: planner.step(th_, start[:4], goal[:4], None, sdf[:4])[0])
   with torch.no_grad():
