@@ -199,3 +199,28 @@ _Z6kernelv:
   if os.path.exists(stats):
     s = json.load(open(stats))
     if '_exec_join' in s: assert not [j for j in s['_exec_join'] if j['kind'] in ('store', 'reload-live')]
+
+
+def test_exec_join_repair_on_the_compilers_own_output(tmp_path):
+  """Round 6: the llc-only reproducer (profiles/r06_exec_join_repro: the optimised IR of gn_kernel<2,16,2,float,STEP,general>) through the installed llc -- the checker finds the
+  misplaced spill copies of profiles/r06_compiler_fault.md in the compiler's own output, the patch moves them behind the exec restore, and the patched text still assembles.
+  Skipped where llc is absent or no longer shows the signature (a fixed compiler)."""
+  import gzip, subprocess, sys
+  llvm = os.environ.get('LLVM_BIN', '/opt/rocm/lib/llvm/bin')
+  llc, clang = os.path.join(llvm, 'llc'), os.path.join(llvm, 'clang')
+  irgz = os.path.join(ROOT, 'profiles', 'r06_exec_join_repro', 'gn_kernel_2_16_2_float_step_general.ll.gz')
+  if not (os.path.exists(llc) and os.path.exists(clang)): pytest.skip('no llc / clang under %s' % llvm)
+  sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
+  import exec_join_check as CK, exec_join_patch as P
+  ir, raw, fixed = str(tmp_path / 'one.ll'), str(tmp_path / 'one.s'), str(tmp_path / 'one_fixed.s')
+  open(ir, 'wb').write(gzip.open(irgz).read())
+  subprocess.check_call([llc, '-mtriple=amdgcn-amd-amdhsa', '-mcpu=gfx950', '-O3', ir, '-o', raw])
+  stores = [f for f in CK.classify(raw) if f[5] == 'store']
+  if not stores: pytest.skip('this llc does not place spill code in front of the exec restore any more')
+  assert all('v_accvgpr_write_b32' in f[3] or 'scratch_store' in f[3] for f in stores)
+  assert P.patch(raw, fixed) == len(stores)
+  assert not [f for f in CK.classify(fixed) if f[5] in ('store', 'reload-live')]
+  # same instructions, same count: only their order inside the join blocks changed
+  body = lambda path: sorted(l.split(';')[0].strip() for l in open(path) if l.startswith('\t') and not l.strip().startswith(('.', ';')))
+  assert body(raw) == body(fixed)
+  subprocess.check_call([clang, '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', fixed, '-o', str(tmp_path / 'one.o')])
