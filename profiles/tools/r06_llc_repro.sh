@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round 6: the exec-join miscompile (profiles/r06_compiler_fault.md) as an llc-only reproducer -- ONE kernel's optimised LLVM IR, 0.3 s per run.
+# Round 6: the exec-join miscompile (profiles/r06_compiler_fault.md) as llc-only reproducers: (1) a 90-line MIR function through -run-pass=greedy, with its control (the same
+# function without the SGPR COPY in front of the exec restore); (2) ONE real kernel's optimised LLVM IR, 0.3 s per run.
 #   profiles/tools/r06_llc_repro.sh            run llc on the committed IR, run the checker, show the join block before / after the register allocator
 #   profiles/tools/r06_llc_repro.sh regen      re-derive the IR from the source first (hipcc -emit-llvm of the unit, opt internalize + globaldce around the one kernel)
 set -u
@@ -13,6 +14,15 @@ if [ "${1:-}" = regen ]; then
   "$B/opt" -S -passes='internalize,globaldce' -internalize-public-api-list=$K "$W/unit.ll" -o "$W/one.ll" || exit 1
   gzip -9 -c "$W/one.ll" > "$IRGZ"
 fi
+M=$R/profiles/r06_exec_join_repro/exec_join_prologue.mir
+echo "== (1) exec_join_prologue.mir through -run-pass=greedy: the join block bb.2"
+"$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -run-pass=greedy -verify-machineinstrs "$M" -o - 2>/dev/null | awk '/^  bb.2:/,/S_BRANCH/' | grep -E "SI_SPILL|S_OR_B64|COPY" | sed 's/, implicit.*//; s/ :: .*//'
+echo "== control: the same function without the SGPR COPY in front of the exec restore"
+grep -v 'sgpr12_sgpr13 = COPY' "$M" | sed 's/\$sgpr12_sgpr13/$sgpr6_sgpr7/g' > "$W/control.mir"
+"$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -run-pass=greedy -verify-machineinstrs "$W/control.mir" -o - 2>/dev/null | awk '/^  bb.2:/,/S_BRANCH/' | grep -E "SI_SPILL|S_OR_B64|COPY" | sed 's/, implicit.*//; s/ :: .*//'
+echo "== the MIR function compiled to assembly (-start-before=greedy) and the checker on it"
+"$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -start-before=greedy "$M" -o "$W/mir.s" 2>/dev/null; python "$R/profiles/tools/exec_join_check.py" "$W/mir.s"
+echo "== (2) the IR of gn_kernel<2,16,2,float,STEP,general>"
 gzip -dc "$IRGZ" > "$W/one.ll"
 "$B/llc" --version | grep -i "version" | head -2
 "$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -O3 "$W/one.ll" -o "$W/one.s" || exit 1

@@ -224,3 +224,25 @@ def test_exec_join_repair_on_the_compilers_own_output(tmp_path):
   body = lambda path: sorted(l.split(';')[0].strip() for l in open(path) if l.startswith('\t') and not l.strip().startswith(('.', ';')))
   assert body(raw) == body(fixed)
   subprocess.check_call([clang, '-x', 'assembler', '-target', 'amdgcn-amd-amdhsa', '-mcpu=gfx950', '-c', fixed, '-o', str(tmp_path / 'one.o')])
+
+
+def test_exec_join_mir_reproducer_and_its_control(tmp_path):
+  """The 90-line MIR reproducer of the spill placement (profiles/r06_exec_join_repro/exec_join_prologue.mir) through `llc -run-pass=greedy`: with an SGPR COPY in front of
+  the exec restore of the join block the VGPR save lands in front of both; without the COPY it lands behind the restore.  Skipped without llc or on a fixed compiler."""
+  import subprocess
+  llc = os.path.join(os.environ.get('LLVM_BIN', '/opt/rocm/lib/llvm/bin'), 'llc')
+  if not os.path.exists(llc): pytest.skip('no llc')
+  mir = open(os.path.join(ROOT, 'profiles', 'r06_exec_join_repro', 'exec_join_prologue.mir')).read()
+  control = '\n'.join(l for l in mir.split('\n') if 'sgpr12_sgpr13 = COPY' not in l).replace('$sgpr12_sgpr13', '$sgpr6_sgpr7')
+
+  def join_block(text, name):
+    path = str(tmp_path / name)
+    open(path, 'w').write(text)
+    out = subprocess.run([llc, '-mtriple=amdgcn-amd-amdhsa', '-mcpu=gfx950', '-run-pass=greedy', '-verify-machineinstrs', path, '-o', '-'], check=True, capture_output=True, text=True).stdout
+    blk = out[out.index('  bb.2:'):]
+    blk = blk[:blk.index('S_BRANCH')]
+    return [('save' if 'SI_SPILL' in l else 'restore' if 'S_OR_B64' in l else 'copy') for l in blk.split('\n') if any(k in l for k in ('SI_SPILL', 'S_OR_B64 $exec', '= COPY'))]
+  got = join_block(mir, 'a.mir')
+  if got == ['copy', 'restore', 'save']: pytest.skip('this llc places the save behind the exec restore: fixed compiler')
+  assert got == ['save', 'copy', 'restore'], got
+  assert join_block(control, 'b.mir') == ['restore', 'save']
