@@ -20,37 +20,70 @@ VEC = re.compile(r'^\s+(v_accvgpr_write_b32|scratch_store_|buffer_store_dword.*o
                  r'|v_accvgpr_read_b32|scratch_load_)')
 IGNORES_EXEC = re.compile(r'^\s+(v_readlane_b32|v_writelane_b32|v_readfirstlane_b32)')
 OTHER_EXEC = re.compile(r'exec')      # any other instruction that names exec (s_and_saveexec, s_mov exec, s_andn2 ... exec): the region in front of it is not a join prologue
-ENTERS_BODY = re.compile(r'^\s+(s_cbranch_execz|s_cbranch_execnz|s_and_saveexec_b64|s_andn2_saveexec_b64|s_mov_b64 exec,|s_and_b64 exec,|s_andn2_b64 exec,)')
 BRANCH = re.compile(r'^\s+(s_cbranch|s_branch|s_endpgm|s_setpc)')
 
 
+SAVEEXEC = re.compile(r'^\s+s_(?:and|andn2|or|xor)_saveexec_b64 (s\[\d+:\d+\]|vcc)')
+SAVE_COPY = re.compile(r'^\s+s_mov_b64 (s\[\d+:\d+\]), exec\s*$')
+EXEC_WRITE = re.compile(r'^\s+s_(?:mov|and|andn2)_b64 exec, ')
+RESTORE_SRC = re.compile(r'^\s+s_or_b64 exec, exec, (s\[\d+:\d+\]|vcc)')
+
+
 def check(path):
+  """-> [(kernel, label, line, instruction, restore)]: spill-like vector instructions between the label of a JOIN block and the exec restore that follows it.
+  A block is a join of a divergent `if` (or the exit of a divergent loop) when the lanes that SKIPPED the body arrive there:
+    * it is the target of an `s_cbranch_execz` (the wavefront jumps over the body when no lane is left), or
+    * it is the fall-through of an `s_cbranch_execnz` (out-of-line body, or the back edge of a divergent loop), or
+    * the `if` has no skip branch at all (short bodies: `s_and_saveexec sN` -- or `s_mov_b64 sN, exec` ... `s_mov_b64 exec, sM` -- and straight on) and the block is a fall-through block behind it that restores from that sN.
+  A block that is only entered from inside the body of an `if` WITH a skip branch -- the body's last block in front of a tail-duplicated restore, uniform branches inside the
+  body -- is NOT a join: what it holds in front of the restore is the body's own code, meant for the body's lanes.  (Round 6, second pass: the first version of this checker took
+  every labelled block in front of a restore for a join, and the repair moved two register saves of a body's exit shuffle in gn_backward_kernel<2,16,4,float,general>[tiled]
+  behind the instructions that reuse their source registers; the MIR census profiles/tools/r06_mir_census.py showed the difference.)"""
   out = []
-  kernel, label, pending, prev = None, None, [], ''
   text = open(path).read()
-  # out-of-line bodies: `s_cbranch_execnz .LBBx` jumps INTO the body of the `if` (lanes left), the fall-through is the join
-  bodies = set(re.findall(r's_cbranch_execnz (\.LBB\d+_\d+)', text))
-  for ln, line in enumerate(text.split('\n'), 1):
+  lines = text.split('\n')
+  skip_targets = set(re.findall(r's_cbranch_execz (\.LBB\d+_\d+)', text))
+  kernel, label, pending, prev, allowed = None, None, [], '', None
+  saved = set()        # `s_mov_b64 sN, exec` seen, the exec write that narrows the mask not yet
+  open_nb = set()      # saved-exec registers of `if`s without a skip branch whose restore has not been seen yet (straight-line code only)
+  for i, line in enumerate(lines):
+    ln = i + 1
     m = KERNEL.match(line)
-    if m: kernel, label, pending, prev = m.group(1), None, [], ''; continue
+    if m: kernel, label, pending, prev, allowed = m.group(1), None, [], '', None; open_nb.clear(); saved.clear(); continue
     m = LABEL.match(line)
     if m:
-      # a block that FOLLOWS the instruction that narrowed exec (or the branch that skips the body when no lane is left) is the BODY of the `if`: it runs under the
-      # narrowed mask by design, and a tail-duplicated copy of the restore may end it -- spill code inside it serves the body's own lanes.  Only a block reached
-      # from the body (fall-through) or from the skip branch is a join.
-      body = bool(ENTERS_BODY.match(prev)) or (m.group(1) in bodies)
-      label, pending = (None if body else (m.group(1) or m.group(2))), []
+      name, asm_label = (m.group(1) or m.group(2)), m.group(1) is not None
+      join = (asm_label and name in skip_targets) or bool(re.match(r'^\s+s_cbranch_execnz', prev))
+      if asm_label: open_nb.clear(); saved.clear()            # a branch target: other paths arrive here, the straight-line bookkeeping ends
+      if join: label, allowed = name, None
+      elif open_nb: label, allowed = name, set(open_nb)
+      else: label, allowed = None, None
+      pending = []
       continue
     if line.lstrip().startswith(';') or not line.strip(): continue
-    this = line
-    if label is None: prev = this; continue
-    if RESTORE.match(line):
-      for l2, t in pending: out.append((kernel, label, l2, t.strip(), line.strip()))
-      label, pending, prev = None, [], this
+    m, mc, mw = SAVEEXEC.match(line), SAVE_COPY.match(line), EXEC_WRITE.match(line)
+    if mc: saved.add(mc.group(1))            # `s_mov_b64 sN, exec`: the other way of opening an `if` (... s_and_b64 sM, sN, cond; s_mov_b64 exec, sM)
+    if m or mw:
+      ahead = [l for l in lines[i + 1:i + 12] if l.strip() and not l.lstrip().startswith(';')][:4]
+      if not any(re.match(r'^\s+s_cbranch_exec', l) for l in ahead):
+        if m: open_nb.add(m.group(1))
+        else: open_nb |= saved
+      saved.clear()
+    if label is None:
+      prev = line
+      if BRANCH.match(line): open_nb.clear()
       continue
-    prev = this
+    if RESTORE.match(line):
+      src = RESTORE_SRC.match(line)
+      if allowed is None or (src and src.group(1) in allowed):
+        for l2, t in pending: out.append((kernel, label, l2, t.strip(), line.strip()))
+      if src: open_nb.discard(src.group(1))
+      label, pending, prev, allowed = None, [], line, None
+      continue
+    prev = line
     if BRANCH.match(line) or OTHER_EXEC.search(line):
-      label, pending = None, []      # another exec write / the block ends: whatever was collected ran under a mask that belongs to it
+      label, pending, allowed = None, [], None      # another exec write / the block ends: whatever was collected ran under a mask that belongs to it
+      if BRANCH.match(line): open_nb.clear()
       continue
     if VEC.match(line) and not IGNORES_EXEC.match(line): pending.append((ln, line))
   return out

@@ -27,6 +27,11 @@ gzip -dc "$IRGZ" > "$W/one.ll"
 "$B/llc" --version | grep -i "version" | head -2
 "$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -O3 "$W/one.ll" -o "$W/one.s" || exit 1
 python "$R/profiles/tools/exec_join_check.py" "$W/one.s"
+echo "== which allocator runs it takes (llc switches; code size as a proxy for what the switch costs)"
+for o in "" "-sgpr-regalloc=basic" "-sgpr-regalloc=fast" "-vgpr-regalloc=basic"; do
+  "$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -O3 $o "$W/one.ll" -o "$W/alt.s" 2>/dev/null
+  echo "  [${o:-default: greedy / greedy}]  $(python "$R/profiles/tools/exec_join_check.py" "$W/alt.s" | tail -1)  $(grep -E '^; codeLenInByte' "$W/alt.s" | tr -d ';')"
+done
 echo "== the join block in the MIR: after the pass in front of the VGPR allocation run, and after that run (print-after=greedy, third dump)"
 "$B/llc" -mtriple=amdgcn-amd-amdhsa -mcpu=gfx950 -O3 "$W/one.ll" -o /dev/null -print-after=amdgpu-reserve-wwm-regs -print-after=greedy 2> "$W/pa.txt"
 python - "$W/pa.txt" <<'PY'

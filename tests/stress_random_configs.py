@@ -145,7 +145,16 @@ for case in range(args.cases):
     e1 = np.abs(fw[0] - c_dth).reshape(B, -1).max(1) / (np.abs(c_dth).reshape(B, -1).max(1) + 1e-300)
     tu = 1e-9 if io == 'f64' else 2e-4
     e2 = max(PC.rel_err(fw[4], s2), PC.rel_err(fw[5], g2), PC.rel_err(fw[6], o2))
-    assert e1.max() < tw and e2 < tu and not fw[3].any(), ('step_errors', case, e1.max(), e2)
+    if not e1.max() < tw:
+      # (round 6, seed 92 case 50: 2.5 x over on an fp64 draw.)  Same arbiter as above: against the extended-precision solution the twin may be no further off than 3 x the STANDARD
+      # kernel's result of the same system (which the main check has just accepted or arbitrated) or 3 x the fp64 C oracle -- a miscompiled twin is wrong by O(1), not by a factor
+      xt, _, _, _ = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh), q_full=q_full, nthreads=4, extended=True)
+      xs_ = np.abs(xt).reshape(B, -1).max(1) + 1e-300
+      e_tw, e_std, e_co = (np.abs(a_ - xt).reshape(B, -1).max(1) / xs_ for a_ in (fw[0], dth, c_dth))
+      over = e1 >= tw
+      assert np.all(e_tw[over] <= 3.0 * np.maximum(e_std[over], e_co[over]) + 1e-300), ('step_errors', case, e1.max(), e_tw[over].max(), e_std[over].max(), e_co[over].max())
+      print('%3d twin cond(step-errors twin %.1e, standard kernel %.1e, fp64 C oracle %.1e off the extended-precision solve)' % (case, e_tw[over].max(), e_std[over].max(), e_co[over].max()), flush=True)
+    assert e2 < tu and not fw[3].any(), ('step_errors', case, e1.max(), e2)
     if n <= 128 and W >= 4 and H >= 4:
       be.sdf_tiled = True
       try: dt_, et_, xt_, it_ = be.step(p, th, start, goal, sdf, **kwc)

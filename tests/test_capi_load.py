@@ -201,6 +201,58 @@ _Z6kernelv:
     if '_exec_join' in s: assert not [j for j in s['_exec_join'] if j['kind'] in ('store', 'reload-live')]
 
 
+def test_exec_join_checker_tells_joins_from_body_tails(tmp_path):
+  """Second pass of round 6: (1) the last block of an `if` body in front of a tail-duplicated restore is NOT a join -- its register saves belong to the body's lanes (the first
+  checker `repaired` such an exit shuffle in a shipped kernel); (2) an `if` without a skip branch joins in the fall-through block that restores from its saved mask;
+  (3) a store whose source register is rewritten in front of the restore is not moved -- the finding stays, which fails the build."""
+  import sys
+  sys.path.insert(0, os.path.join(ROOT, 'profiles', 'tools'))
+  import exec_join_check as CK, exec_join_patch as P
+  asm = '''
+_Z2k1v:
+	s_and_saveexec_b64 s[0:1], vcc
+	s_cbranch_execz .LBB0_4
+; %bb.1:
+	s_cmp_eq_u64 s[20:21], 0
+	s_cbranch_scc1 .LBB0_3
+; %bb.2:
+	global_store_dword v[0:1], v2, off
+.LBB0_3:
+	v_accvgpr_write_b32 a7, v71
+	v_mov_b32_e32 v71, v64
+	s_or_b64 exec, exec, s[0:1]
+	s_branch .LBB0_5
+.LBB0_4:
+	s_or_b64 exec, exec, s[0:1]
+.LBB0_5:
+	s_and_saveexec_b64 s[2:3], s[4:5]
+	v_readlane_b32 s24, v254, 51
+; %bb.6:
+	v_mov_b32_e32 v8, 0
+; %bb.7:
+	v_accvgpr_write_b32 a30, v236
+	s_mov_b64 s[6:7], s[86:87]
+	s_or_b64 exec, exec, s[2:3]
+	s_and_saveexec_b64 s[8:9], vcc
+	s_cbranch_execz .LBB0_9
+; %bb.8:
+	global_store_dword v[0:1], v2, off
+.LBB0_9:
+	v_accvgpr_write_b32 a31, v237
+	v_mov_b32_e32 v237, v3
+	s_or_b64 exec, exec, s[8:9]
+	s_endpgm
+.Lfunc_end0:
+'''
+  src, dst = str(tmp_path / 'k.s'), str(tmp_path / 'k_fixed.s')
+  open(src, 'w').write(asm)
+  found = sorted((f[1], f[3].split()[1].rstrip(','), f[5]) for f in CK.classify(src))
+  assert found == [('%bb.7', 'a30', 'store'), ('.LBB0_9', 'a31', 'store')], found      # .LBB0_3 (the body's tail, entered from inside the body only) is not reported
+  assert P.patch(src, dst) == 1                                                        # a31's source register v237 is rewritten in front of the restore: not movable
+  left = [(f[1], f[5]) for f in CK.classify(dst)]
+  assert left == [('.LBB0_9', 'store')], left
+
+
 def test_exec_join_repair_on_the_compilers_own_output(tmp_path):
   """Round 6: the llc-only reproducer (profiles/r06_exec_join_repro: the optimised IR of gn_kernel<2,16,2,float,STEP,general>) through the installed llc -- the checker finds the
   misplaced spill copies of profiles/r06_compiler_fault.md in the compiler's own output, the patch moves them behind the exec restore, and the patched text still assembles.

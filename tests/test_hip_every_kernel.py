@@ -226,6 +226,9 @@ def test_hip_every_tiled_twin_kernel(be, dof, io, monkeypatch):
   monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
   bad = []
   tol = 1e-9 if io == 'f64' else 2e-4
+  # gradients / fused loops: twin and standard kernel run the same fp64 arithmetic on the same numbers (only the grid's storage order differs) -- measured agreement 6e-10
+  # (profiles/r06_body_tail_diff.txt).  Round 6 tightened this from 100 x tol = 2e-2 for fp32 I/O: a kernel with a 3 % error in g_th had passed under the old bound.
+  tight = 1e-7 if io == 'f64' else 2e-5
   K = 3
 
   def cmp(tag, what, a_, b_, scale_with=None, t=None):
@@ -253,16 +256,16 @@ def test_hip_every_tiled_twin_kernel(be, dof, io, monkeypatch):
       if cov == 'scalar': bkw['qc'] = PC.rnd(qc[:, :, None, None] * np.eye(dof), io)      # (the scaled backward twin through DGP_QC_SCALAR as well)
       for kq in ((kw, 'backward'),) + (((bkw, 'backward (dense blocks)'),) if cov == 'scalar' else ()):
         ra = be.backward(p, th, start, goal, sdf, a[0], gb, ge, sdf_grad=gm, **kq[0]); rb = bt.backward(p, th, start, goal, sdf, a[0], gb, ge, sdf_grad=gm, **kq[0])
-        for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'): cmp(tag, kq[1] + ' ' + key, rb[key], ra[key], scale_with=ra['th'] if key == 'sdf' else None, t=100 * tol)
+        for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'): cmp(tag, kq[1] + ' ' + key, rb[key], ra[key], scale_with=ra['th'] if key == 'sdf' else None, t=tight)
       if cov != 'scalar':      # the fused loop (DGP_QC_SCALAR is a step-only mode)
         sa = be.solve(p, th, start, goal, sdf, K, 0.0, **kw); sb = bt.solve(p, th, start, goal, sdf, K, 0.0, **kw)
-        cmp(tag, 'fused loop', sb[0], sa[0], t=100 * tol)
+        cmp(tag, 'fused loop', sb[0], sa[0], t=tight)
       if cov in ('static', 'static_diag', 'static_full'):      # ... and its backward (static_full: the general-covariance chain twins, round 6)
         tho, its, hist, info = be.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
         tht, itt, hist_t, info_t = bt.solve_traced(p, th, start, goal, sdf, K, 0.0, io=io)
-        cmp(tag, 'traced loop', tht, tho, t=100 * tol)
+        cmp(tag, 'traced loop', tht, tho, t=tight)
         ca = be.solve_backward(p, start, goal, sdf, K, hist, tho, its, gb, io=io, sdf_grad=gm); cb = bt.solve_backward(p, start, goal, sdf, K, hist, tho, its, gb, io=io, sdf_grad=gm)
-        for key in ('th', 'start', 'goal', 'sdf'): cmp(tag, 'chain backward ' + key, cb[key], ca[key], scale_with=ca['th'] if key == 'sdf' else None, t=100 * tol)
+        for key in ('th', 'start', 'goal', 'sdf'): cmp(tag, 'chain backward ' + key, cb[key], ca[key], scale_with=ca['th'] if key == 'sdf' else None, t=tight)
   assert not bad, '%d tiled-twin results differ from the row-major kernels:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
