@@ -18,6 +18,9 @@ from oracle import gpmp2_oracle as O, blocktri as BT
 
 pytestmark = pytest.mark.gpu
 
+# Gradients of the fp32-I/O kernels against the fp64 ORACLES: the backward takes the forward's dtheta as an input, rounded to fp32, and the oracle its own fp64 one -- cond(Lambda) x 6e-8,
+# measured up to 1e-3 (round 6, DGP_F32_GRAD_SCALE=0.002: gpurun_out/r06d/tight.txt).  These bounds cannot be sharper; test_hip_every_f32_kernel_matches_its_f64_sibling is.
+F32_GRAD_SCALE = float(os.environ.get('DGP_F32_GRAD_SCALE', 1.0))
 SHAPES = [(l, c) for l in (16, 32, 64) for c in (1, 2, 4)]
 COVS = ['static', 'static_full', 'perstate', 'qfull']
 ERRS_LENGTHS = (64, 37, 128, 100)      # test_hip_every_step_errors_kernel: the 16- and the 32-lane shape, exact fit and ragged
@@ -123,7 +126,7 @@ def test_hip_every_scaled_kernel_vs_c_oracle(be, dof, io, monkeypatch):
         # (the grid gradient is a sum of signed tap contributions accumulated by atomics: judged against the size of the summands, for which the trajectory gradient stands in)
         scale = max(np.abs(r2[key]).max(), np.abs(r2['th']).max() if key == 'sdf' else 0.0, (1e-300 if io == 'f64' else 1e-6 * np.abs(r2['th']).max()))
         eb = np.abs(r1[key] - r2[key]).max() / scale if np.all(np.isfinite(r1[key])) else np.inf
-        if not eb < (1e-7 if io == 'f64' else 5e-3): bad.append(('dof %d %s shape (%d,%d) n %d backward' % (dof, io, lpt, c, n), key, eb))
+        if not eb < (1e-7 if io == 'f64' else 5e-3 * F32_GRAD_SCALE): bad.append(('dof %d %s shape (%d,%d) n %d backward' % (dof, io, lpt, c, n), key, eb))
   assert not bad, '%d scaled-mask kernel instantiations differ from the C oracle:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
@@ -165,7 +168,7 @@ def test_hip_every_backward_kernel_vs_autograd_oracle(be, dof, io, monkeypatch):
         # f32 I/O: the kernels are handed the forward output dtheta ROUNDED to fp32 and rebuild rho = e - H dtheta from it, so the gradients
         # carry cond(Lambda) * 6e-8 relative to the oracle's (which differentiates its own fp64 dtheta): up to 4e-4 on the random q_full
         # systems here.  The fp64 run pins the mathematics at 1e-6; this one only has to catch code-generation faults (O(1) errors).
-        if not eb < (1e-6 if io == 'f64' else 2e-3): bad.append((tag, key, eb))
+        if not eb < (1e-6 if io == 'f64' else 2e-3 * F32_GRAD_SCALE): bad.append((tag, key, eb))
   assert not bad, '%d backward results differ from the autograd oracle:\n' % len(bad) + '\n'.join(map(str, bad))
 
 
@@ -210,8 +213,64 @@ def test_hip_every_step_errors_kernel(be, dof, io, monkeypatch):
         for key in ('th', 'start', 'goal', 'qc', 'ow', 'eps'):
           if want[key] is None or r[key] is None: continue
           eb = np.abs(r[key] - want[key]).max() / max(np.abs(want[key]).max(), 1e-300) if np.all(np.isfinite(r[key])) else np.inf
-          if not eb < (1e-7 if io == 'f64' else 2e-3): bad.append((tag, 'backward shape %s' % ((lpt, c),), key, eb))
+          if not eb < (1e-7 if io == 'f64' else 2e-3 * F32_GRAD_SCALE): bad.append((tag, 'backward shape %s' % ((lpt, c),), key, eb))
   assert not bad, '%d step-errors results differ:\n' % len(bad) + '\n'.join(map(str, bad))
+
+
+@pytest.mark.parametrize('dof', [2, 3])
+def test_hip_every_f32_kernel_matches_its_f64_sibling(be, dof, monkeypatch):
+  """Round 6: the fp32-I/O kernels against the fp64-I/O kernels of the same family, shape and length on the SAME numbers (inputs that are exact in fp32).  Both run the same fp64
+  lane program -- separate compilations of it -- so they agree to the rounding of the fp32 outputs (a few 1e-8 of the largest entry), whatever the conditioning of the system:
+  the oracle comparisons above must allow the fp32 kernels 1e-5 (step) and 5e-3 (gradients: the fp32 rounding of dtheta, an INPUT of the backward, times the condition number),
+  which is wide enough for a kernel that is wrong in a few per cent of one output (profiles/r06_body_tail_diff.txt).  The fp64 siblings are held to 1e-9 / 1e-7 above, so this
+  pins every fp32 instantiation -- step, step + errors, backward, backward with error cotangents, their tiled twins, the fused loop -- at 1e-5."""
+  rs = np.random.RandomState(900 + dof)
+  bt = harness.Backend(be.kind); bt.sdf_tiled = True
+  bad = []
+  tol = 1e-5
+
+  def cmp(tag, what, a32, a64, t=None, scale_with=None):
+    if a32 is None or a64 is None: return
+    if not np.all(np.isfinite(a32)): bad.append((tag, what, 'non-finite')); return
+    a32 = a32.astype(np.float64)
+    if a32.shape != a64.shape and a32.shape[1:] == a64.shape[1:]: a32 = a32.sum(0, keepdims=True)      # (the float64 partial grids of a shared grid's gradient, unsummed)
+    e = np.abs(a32 - a64).max() / max(np.abs(a64).max(), 0.0 if scale_with is None else np.abs(scale_with).max(), 1e-300)
+    if not e < (t or tol): bad.append((tag, what, e))
+  up = lambda a: None if a is None else np.asarray(a, dtype=np.float64)
+  for lpt, c in SHAPES:
+    monkeypatch.setenv('DGP_FORCE_SHAPE', '%d,%d' % (lpt, c))
+    for cov in ('static', 'static_diag', 'static_full', 'perstate', 'qfull', 'scalar'):
+      for n in (lpt * c, max(4, lpt * c - 3)):
+        B = 64 // lpt + 1
+        p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, 'perstate' if cov == 'scalar' else cov, 'f32')
+        if cov == 'scalar': qc = PC.rnd(rs.uniform(0.3, 3.0, (B, n - 1)) ** 2, 'f32')
+        tag = 'dof %d shape (%d,%d) n %d cov %s' % (dof, lpt, c, n, cov)
+        k32 = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io='f32')
+        k64 = dict(qc=up(qc), ow=up(ow), eps=up(eps), q_full=q_full, io='f64')
+        a64 = (up(th), up(start), up(goal), up(sdf))
+        for b_, kind in ((be, ''),) + (((bt, ' [tiled]'),) if c == 4 and n <= 128 else ()):
+          f32 = b_.step(p, th, start, goal, sdf, **k32); f64 = b_.step(p, *a64, **k64)
+          if f32[3].any() or f64[3].any(): bad.append((tag + kind, 'info')); continue
+          for i, name in enumerate(('dtheta', 'err', 'err_ext')): cmp(tag + kind, 'step ' + name, f32[i], f64[i])
+          dth = f32[0]                       # (fp32-exact: the same dtheta goes into both backward kernels)
+          gb = PC.rnd(rs.randn(B, n, 2 * dof), 'f32'); ge = PC.rnd(rs.randn(B), 'f32')
+          r32 = b_.backward(p, th, start, goal, sdf, dth, gb, ge, sdf_grad='f64', **k32)
+          r64 = b_.backward(p, *a64, up(dth), up(gb), up(ge), sdf_grad='dense', **k64)
+          for key in ('th', 'start', 'goal', 'sdf', 'qc', 'ow', 'eps'): cmp(tag + kind, 'backward ' + key, r32[key], r64[key], scale_with=r64['th'] if key == 'sdf' else None)
+          if cov != 'scalar':
+            s32 = b_.solve(p, th, start, goal, sdf, 2, 0.0, **k32); s64 = b_.solve(p, *a64, 2, 0.0, **k64)
+            cmp(tag + kind, 'fused loop', s32[0], s64[0])      # (two iterations: the trajectory between them is rounded to fp32 in one kernel only -- a difference of 6e-8 going in)
+        if n <= 128 and c == 4 and cov != 'scalar':      # the step-errors twins and the backward with the errors' cotangents
+          ce, cs, cg, co = (PC.rnd(rs.randn(B), 'f32') for _ in range(4))
+          w32 = be.step_errors(p, th, start, goal, sdf, **k32); w64 = be.step_errors(p, *a64, **k64)
+          # (the errors are taken at th + dtheta SUMMED IN THE I/O TYPE, as torch forms th_curr_b + dthetab: the fp32 kernel's point is 6e-8 away from the fp64 kernel's, and the
+          #  start / goal error -- a difference of nearly equal numbers at a trajectory that starts where it should -- moves by up to 4e-4 of itself)
+          for i, name in ((0, 'dtheta'), (4, 'unw_sg'), (5, 'unw_gp'), (6, 'unw_obs')): cmp(tag, 'step_errors ' + name, w32[i], w64[i], t=2e-3 if name == 'unw_sg' else None)
+          gd = PC.rnd(rs.randn(B, n, 2 * dof), 'f32')
+          q32 = be.step_errors_backward(p, th, start, goal, sdf, w32[0], gd, ce, cs, cg, co, sdf_grad='none', **k32)
+          q64 = be.step_errors_backward(p, *a64, up(w32[0]), up(gd), up(ce), up(cs), up(cg), up(co), sdf_grad='none', **k64)
+          for key in ('th', 'start', 'goal', 'qc', 'ow', 'eps'): cmp(tag, 'step_errors backward ' + key, q32[key], q64[key])
+  assert not bad, '%d fp32 results differ from the fp64 sibling kernels:\n' % len(bad) + '\n'.join(map(str, bad[:60]))
 
 
 @pytest.mark.parametrize('io', ['f64', 'f32'])
@@ -315,5 +374,5 @@ def test_hip_every_chain_backward_kernel(be, dof, io, cov, monkeypatch):
         # f32 I/O: the hand-walked chain rounds th_k, dtheta_k and the running cotangent to fp32 between the launches, the chain kernel keeps them in fp64
         # (the grid gradient is summed by atomics in an order that differs between the one launch and the K: 1e-7 of cancellation noise)
         # (static_full: the general kernels' PCR rounds use explicit block inverses, six rounds deep at 64 lanes -- 1.3e-9 met on <3,64,1,double>: rounding, not a fault)
-        if not eb < ((1e-7 if key == 'sdf' else (5e-9 if cov == 'static_full' else 1e-9)) if io == 'f64' else 5e-3): bad.append((tag, key, eb))
+        if not eb < ((1e-7 if key == 'sdf' else (5e-9 if cov == 'static_full' else 1e-9)) if io == 'f64' else 5e-3 * F32_GRAD_SCALE): bad.append((tag, key, eb))
   assert not bad, '%d chain-backward results differ from the chained single-step backward:\n' % len(bad) + '\n'.join(map(str, bad))
