@@ -278,6 +278,23 @@ def test_hip_every_f32_kernel_matches_its_f64_sibling(be, dof, monkeypatch):
           q32 = be.step_errors_backward(p, th, start, goal, sdf, w32[0], gd, ce, cs, cg, co, sdf_grad='none', **k32)
           q64 = be.step_errors_backward(p, *a64, up(w32[0]), up(gd), up(ce), up(cs), up(cg), up(co), sdf_grad='none', **k64)
           for key in ('th', 'start', 'goal', 'qc', 'ow', 'eps'): cmp(tag, 'step_errors backward ' + key, q32[key], q64[key])
+  # the loop kernels of longer trajectories (gn_long.h: 257 ... 1024 / 640 states)
+  monkeypatch.delenv('DGP_FORCE_SHAPE', raising=False)
+  for n in (257, 384, 1024 if dof == 2 else 640):
+    for cov in ('static', 'static_full', 'perstate', 'qfull'):
+      B = 3
+      p, th, start, goal, sdf, qc, ow, eps, q_full = _inputs(rs, dof, n, B, cov, 'f32')
+      tag = 'dof %d n %d cov %s (loop kernels)' % (dof, n, cov)
+      k32 = dict(qc=qc, ow=ow, eps=eps, q_full=q_full, io='f32')
+      k64 = dict(qc=up(qc), ow=up(ow), eps=up(eps), q_full=q_full, io='f64')
+      a64 = (up(th), up(start), up(goal), up(sdf))
+      f32 = be.step(p, th, start, goal, sdf, **k32); f64 = be.step(p, *a64, **k64)
+      if f32[3].any() or f64[3].any(): bad.append((tag, 'info')); continue
+      for i, name in enumerate(('dtheta', 'err', 'err_ext')): cmp(tag, 'step ' + name, f32[i], f64[i])
+      gb = PC.rnd(rs.randn(B, n, 2 * dof), 'f32'); ge = PC.rnd(rs.randn(B), 'f32')
+      r32 = be.backward(p, th, start, goal, sdf, f32[0], gb, ge, sdf_grad='dense', **k32)      # (no float64 partial grids beyond 256 states: the fp32 grid gradient is summed by fp32
+      r64 = be.backward(p, *a64, up(f32[0]), up(gb), up(ge), sdf_grad='dense', **k64)            #  atomics in an order that changes from run to run -- left out here)
+      for key in ('th', 'start', 'goal', 'qc', 'ow', 'eps'): cmp(tag, 'backward ' + key, r32[key], r64[key])
   assert not bad, '%d fp32 results differ from the fp64 sibling kernels:\n' % len(bad) + '\n'.join(map(str, bad[:60]))
 
 
