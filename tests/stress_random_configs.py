@@ -160,7 +160,14 @@ for case in range(args.cases):
       try: dt_, et_, xt_, it_ = be.step(p, th, start, goal, sdf, **kwc)
       finally: be.sdf_tiled = False
       e3 = np.abs(dt_ - c_dth).reshape(B, -1).max(1) / (np.abs(c_dth).reshape(B, -1).max(1) + 1e-300)
-      assert e3.max() < tw and not it_.any(), ('tiled grids', case, e3.max())
+      if not e3.max() < tw:      # (round 6, seed 173 case 182: 5.0e-7 on a system where the standard kernel itself is 4.3e-7 off the extended-precision solve.)  The same arbiter
+        xt, _, _, _ = BT.gn_step(p, th, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh), q_full=q_full, nthreads=4, extended=True)
+        xs_ = np.abs(xt).reshape(B, -1).max(1) + 1e-300
+        e_tl, e_std, e_co = (np.abs(a_ - xt).reshape(B, -1).max(1) / xs_ for a_ in (dt_, dth, c_dth))
+        over = e3 >= tw
+        assert np.all(e_tl[over] <= 3.0 * np.maximum(e_std[over], e_co[over]) + 1e-300), ('tiled grids', case, e3.max(), e_tl[over].max(), e_std[over].max(), e_co[over].max())
+        print('%3d twin cond(tiled twin %.1e, standard kernel %.1e, fp64 C oracle %.1e off the extended-precision solve)' % (case, e_tl[over].max(), e_std[over].max(), e_co[over].max()), flush=True)
+      assert not it_.any(), ('tiled grids', case, e3.max())
     if forced: os.environ['DGP_FORCE_SHAPE'] = '%d,%d' % forced
   # (not for n > 256 with fp32 I/O: the loop kernels keep the fused loop's state in th_out, i.e. rounded to fp32 between iterations, so neither the f64-I/O
   #  loop nor a host-side chain of f32 steps -- which rounds dtheta AND the sum -- is a reference at better than cond(Lambda) x 6e-8 per iteration;
