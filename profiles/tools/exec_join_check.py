@@ -72,6 +72,8 @@ def check(path):
     if label is None:
       prev = line
       if BRANCH.match(line): open_nb.clear()
+      src = RESTORE_SRC.match(line)
+      if src: open_nb.discard(src.group(1))      # (restored inside a block that is no candidate: that `if` is closed)
       continue
     if RESTORE.match(line):
       src = RESTORE_SRC.match(line)
