@@ -244,7 +244,7 @@ int dgp_gn_solve_traced(const DgpHandle* h, int32_t batch,
  * th_out, iters and the cotangent g_th_out (B,n,d) of the final trajectory, ONE launch walks th_{k+1} = th_k + dtheta(th_k) backwards
  * per trajectory (adjoint solve + per-factor chain rule per iteration, the running cotangent in registers) and writes dL/d th_init
  * (B,n,d), dL/d start, dL/d goal (B,1,d) and ACCUMULATES dL/d sdf (layout / partial copies as in dgp_gn_step_backward; the caller
- * zeroes it).  Static covariances with a diagonal Q_c_inv (what forward() runs without learn modules), num_states <= 256;
+ * zeroes it).  Static covariances (what forward() runs without learn modules; any Q_c_inv since round 6 -- a non-diagonal one runs the general chain kernels), num_states <= 256;
  * DGP_EUNSUPPORTED otherwise -- chain dgp_gn_step_backward then.  The per-iteration errors have no cotangent: forward() returns them
  * as python floats (:138-141). */
 int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch,
@@ -257,8 +257,8 @@ int dgp_gn_solve_backward(const DgpHandle* h, int32_t batch,
 /* One iteration of the reference's training loop (learning/train_planner.py:311-327): dgp_gn_step, then the unweighted errors of
  * DiffGPMP2Planner.unweighted_errors_batch at th + dtheta (the sum formed in io_dtype, as torch forms th_curr_b + dthetab), no th + dtheta
  * tensor in between.  unw_* (B), any may be NULL (all NULL: dgp_gn_step).  ONE launch (the step kernels with an errors epilogue) for row-major
- * grids and num_states <= 128 -- dof = 2: every covariance representation; dof = 3: static (Q_c_inv = c I, no velocity limits), DGP_QC_SCALAR and
- * per-state (B,n-1,dof,dof) covariances; otherwise two stream-ordered launches. */
+ * grids and num_states <= 128 -- dof = 2: every covariance representation; dof = 3: everything but the general family (q_full tensors, a non-diagonal
+ * Q_c_inv: measured slower in one launch than in two, profiles/r06_d6_general_twin.txt); otherwise two stream-ordered launches. */
 int dgp_gn_step_errors(const DgpHandle* h, int32_t batch,
                        const void* th, const void* start, const void* goal,
                        const DgpSdf* sdf, const DgpCovs* covs,
