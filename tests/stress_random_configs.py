@@ -187,7 +187,18 @@ for case in range(args.cases):
       good = not i2.any() and np.all(np.isfinite(cur)); ref_name = 'the f64-I/O fused loop on the same fp32-rounded inputs'    # that); compare the two I/O builds
     if good and not sinfo.any():
       es = np.abs(tho - cur).max() / (np.abs(cur).max() + 1e-300)
-      assert es < (1e-7 if io == 'f64' else 1e-5) * (30 if p.reg < 0.01 else 1), ('fused loop differs from ' + ref_name, case, es, dict(dof=dof, n=n, B=B, io=io, shape=forced, H=H, W=W, per_sample=per_sample, cov=cov, qmode=qmode, reg=p.reg, flags=kw))
+      bound = (1e-7 if io == 'f64' else 1e-5) * (30 if p.reg < 0.01 else 1)
+      if not es < bound:
+        # (round 6, seed 196 case 24: 4.5e-6 on a weakly regularised d = 6 system -- the fused loop and the step kernels run in different launch shapes, three Gauss-Newton
+        #  iterations amplify the rounding.)  Arbiter: three chained steps of the extended-precision C oracle; the fused loop may be no further from them than 3 x the reference is
+        xc = th.copy()
+        for k in range(3):
+          xd, _, _, _ = BT.gn_step(p, xc, start, goal, sdf, qc=qc, ow=None if ow is None else ow.reshape(sh), eps=None if eps is None else eps.reshape(sh), q_full=q_full, nthreads=4, extended=True)
+          xc = xc + xd
+        nx = np.abs(xc).max() + 1e-300
+        e_f, e_r = np.abs(tho - xc).max() / nx, np.abs(cur - xc).max() / nx
+        assert e_f <= 3.0 * max(e_r, bound), ('fused loop differs from ' + ref_name, case, es, e_f, e_r)
+        print('%3d fused-loop cond(fused loop %.1e, %s %.1e off three extended-precision steps)' % (case, e_f, ref_name, e_r), flush=True)
   # the backward kernel of the same configuration against an INDEPENDENT gradient oracle: torch autograd over the dense restatement of
   # the reference's step (oracle/autograd_torch.py; pinned to the reference's own autograd fixtures) -- every backward variant, on
   # batches small enough for the dense solve
