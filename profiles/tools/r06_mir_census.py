@@ -7,7 +7,9 @@ join top): it can prove the `store` class and must leave `reload`s in front of a
 instruction in front of it in that block was put there by the allocator under the wrong mask.  Per unit: hipcc --cuda-device-only -S -mllvm -stop-after=greedy,2 (MIR instead of assembly) -> count, per
 kernel, the vector COPYs / SI_SPILL_*_SAVE / SI_SPILL_*_RESTORE in front of an exec restore.
 
-  python profiles/tools/r06_mir_census.py [unit ...]        units as in devbuild.py (2_f32_g1, 3e_f32_g0, 2t_f32_g2, ...; default: all of the product build)  -> one line per unit + totals"""
+  python profiles/tools/r06_mir_census.py [unit ...]        units as in devbuild.py (2_f32_g1, 3e_f32_g0, 2t_f32_g2, ...; default: all of the product build)  -> one line per unit + totals
+  python profiles/tools/r06_mir_census.py --check           all units, then compared with what the build repaired (dgpmp2_amd/lib/kernel_stats.json: _exec_join_repaired): the units
+                                                            must be the same and every finding must be a copy into an A(V) register = two moved instructions; exit status 1 otherwise"""
 import os, re, subprocess, sys, tempfile
 from concurrent.futures import ThreadPoolExecutor
 
@@ -62,19 +64,31 @@ def census(unit, work):
 
 
 def main():
-  units = sys.argv[1:] or ALL
+  check = '--check' in sys.argv[1:]
+  units = [u for u in sys.argv[1:] if u != '--check'] or ALL
   work = tempfile.mkdtemp(prefix='dgp_census_')
   tot = [0, 0, 0, 0]; nk = 0; hit = 0
+  found = {}
   print('# unit: kernels | kernels with vector code in front of a join\'s exec restore | SI_SPILL saves / SI_SPILL restores / copies into A(V) registers / other vector copies')
   with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as ex:
     for unit, n, out in ex.map(lambda u: census(u, work), units):
       c = [sum(v[i] for v in out.values()) for i in range(4)]
       nk += n; hit += len(out)
       for i in range(4): tot[i] += c[i]
+      if any(c): found[unit] = c
       print('%-10s %3d | %3d | %d / %d / %d / %d' % (unit, n, len(out), c[0], c[1], c[2], c[3]), flush=True)
       for k, v in sorted(out.items()):
         print('    %s: saves %d restores %d copies->A(V) %d other copies %d' % (k, *v))
   print('# total: %d kernels, %d with findings | saves %d restores %d copies->A(V) %d other vector copies %d' % (nk, hit, *tot))
+  if check:
+    import json
+    rep = json.load(open(os.path.join(ROOT, 'dgpmp2_amd', 'lib', 'kernel_stats.json'))).get('_exec_join_repaired', {})
+    rep = {k.replace('gn_inst_', ''): v for k, v in rep.items()}
+    want = {u: 2 * (c[0] + c[2]) for u, c in found.items()}      # a 64-bit copy / save = two instructions in the assembly
+    odd = {u: c for u, c in found.items() if c[1] or c[3]}
+    ok = want == rep and not odd
+    print('# check against the build\'s repairs %s: %s' % (rep, 'SAME' if ok else 'DIFFERENT (census %s%s)' % (want, ', reloads / plain copies: %s' % odd if odd else '')))
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == '__main__':
